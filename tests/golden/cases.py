@@ -1,0 +1,66 @@
+"""Case definitions shared by the golden generator (runs the REFERENCE, this container only) and the
+parity tests (run the oracle on CPU / the HIP path on the GPU).  Pure data + closed-form fills: nothing
+here comes from the reference's sources."""
+from __future__ import annotations
+
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import mnasnet_oracle as O  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+# name: (cin, cout, k, stride, pad, groups, N, H, W)   -- SURVEY 8(c)(1)
+PRIMITIVES = {
+    "pw_16_48": (16, 48, 1, 1, 0, 1, 2, 12, 12),
+    "pw_72_24": (72, 24, 1, 1, 0, 1, 2, 12, 12),
+    "pw_96_576": (96, 576, 1, 1, 0, 1, 2, 6, 7),
+    "dw3_48": (48, 48, 3, 1, 1, 48, 2, 12, 12),
+    "dw5_72": (72, 72, 5, 1, 2, 72, 2, 12, 12),
+    "dw5_240": (240, 240, 5, 1, 2, 240, 2, 7, 9),
+    "dense_3_32_s2": (3, 32, 3, 2, 1, 1, 2, 12, 12),
+    "dense_16_24_s2": (16, 24, 3, 2, 1, 1, 2, 12, 12),
+    "dense_80_96_s1": (80, 96, 3, 1, 1, 1, 2, 7, 9),
+}
+# name: (C, t, k, N, H, W)   -- SURVEY 8(c)(2)
+BLOCKS = {
+    "block_16_3_3": (16, 3, 3, 2, 14, 14),
+    "block_24_3_5": (24, 3, 5, 2, 14, 14),
+    "block_96_6_5": (96, 6, 5, 2, 14, 14),
+}
+# name: (cin, cout, t, layers, k, reduce, ccf, N, H, W)  -- SURVEY 8(c)(3)
+STAGES = {
+    "stage_16_24_ccfT": (16, 24, 3, 3, 3, True, True, 2, 16, 16),
+    "stage_16_24_ccfF": (16, 24, 3, 3, 3, True, False, 2, 16, 16),
+}
+# name: (ccf, N, H, W, train)   -- SURVEY 8(c)(4)
+NETS = {
+    "net_ccfT_64_train": (True, 2, 64, 64, True),
+    "net_ccfF_64_train": (False, 2, 64, 64, True),
+    "net_ccfF_rect_train": (False, 2, 96, 64, True),
+    "net_ccfT_224_eval": (True, 1, 224, 224, False),    # BASELINE.json configs[0]
+    "net_ccfF_224_eval": (False, 1, 224, 224, False),
+}
+HEADS = ("256", "512_256", "320", "512")
+STATE_SEED = 1
+INPUT_SEED = 7
+COT_SEED = 11
+
+
+def det_input(shape, seed=INPUT_SEED):
+    return O.det_uniform(shape, seed)
+
+
+def cotangent(shape, seed=COT_SEED):
+    """dL/d(out): L = sum(out * cotangent) gives a non-trivial, reproducible backward."""
+    return O.det_uniform(shape, seed)
+
+
+def summarize(t):
+    """(sum, sum|.|, sum of squares) in float64 -- the 'checksum' stored for large tensors."""
+    d = t.detach().double()
+    return [float(d.sum()), float(d.abs().sum()), float((d * d).sum())]
