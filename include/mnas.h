@@ -1,0 +1,221 @@
+/*
+ * mnas.h -- C ABI of libmnas_hip.so: the MI355X (gfx950) kernels behind the MNASNet training hot path.
+ *
+ * The reference (snakers4/mnasnet-pytorch) has no FFI of its own: its hot path is
+ *     ConvBlock.forward      src/models/mnasnet.py:58-62   (conv -> BatchNorm2d -> ReLU)
+ *     MBConv_block.forward   src/models/mnasnet.py:131-137 (x + seq(x))
+ *     loss.backward()        src/train.py:439              (autograd mirror of the above)
+ * executed by PyTorch ATen.  This library is what a maintainer binds instead of ATen for that path
+ * (INTEGRATION.md shows the ctypes stub).  Every entry point:
+ *   - takes plain pointers + sizes (no torch types), device pointers unless stated otherwise;
+ *   - launches on the HIP stream passed as `stream` (a hipStream_t cast to void*), never synchronises,
+ *     never allocates or frees, keeps no pointer after returning, has no global mutable state;
+ *   - returns 0 (MNAS_OK) or a non-zero hipError_t / MNAS_E* code; never throws across the ABI.
+ *
+ * Data layout in HBM
+ *   activations / activation gradients : NHWC, bf16, dense, C % 8 == 0 (16-byte channel groups)
+ *   network input                      : NCHW fp32 (what train.py:427 hands over), read by the stem kernel
+ *   network output / its gradient      : NCHW fp32 (what classifiers.py:109 consumes)
+ *   BatchNorm is never applied in place: a conv kernel writes the RAW conv output y (bias included) and
+ *   per-workgroup partial (sum, sum of squares); mnas_bn_fwd_finalize turns them into a per-channel
+ *   (scale, shift); every CONSUMER applies relu(scale*y+shift) while loading ("act-on-load").
+ *   In backward the consumer of a gradient computes dy = c1*(g*[scale*y+shift>0]) + c2*y + c3 while
+ *   loading ("dy-on-load"); c1..c3 come from mnas_bn_bwd_finalize.
+ *
+ * BN coefficient block ("bnbuf"): float[8][C] per ConvBlock application
+ *   row 0 scale  s = gamma*invstd         row 4 c3
+ *   row 1 shift  t = beta - mean*s        row 5 batch mean
+ *   row 2 c1                              row 6 invstd
+ *   row 3 c2                              row 7 (reserved)
+ */
+#ifndef MNAS_H
+#define MNAS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNAS_OK 0
+#define MNAS_EINVAL 10001   /* unsupported shape / argument */
+#define MNAS_BN_ROWS 8
+
+/* "act-on-load" input: value = scale ? relu(scale[c]*data+shift[c]) : data */
+typedef struct MnasActIn {
+    const void*  data;    /* bf16 NHWC */
+    const float* scale;   /* [C] or NULL */
+    const float* shift;   /* [C] or NULL */
+} MnasActIn;
+
+/* "dy-on-load" input: dy = c1*(g*[s*y+t>0]) + c2*y + c3, coef = bnbuf rows 0..4 */
+typedef struct MnasGradIn {
+    const void*  g;       /* bf16 NHWC: dL/d(activated output) */
+    const void*  y;       /* bf16 NHWC: saved raw conv output */
+    const float* coef;    /* float[5][C] */
+} MnasGradIn;
+
+int mnas_version(void);                 /* ABI version, currently 1 */
+const char* mnas_arch(void);            /* "gfx950" */
+
+/* ---- 1x1 / dense kxk convolution as an implicit GEMM on MFMA (bf16 in, fp32 accumulate) -------------
+ * Replaces ATen conv2d forward / conv2d input-gradient for ConvBlock's groups==1 convs
+ * (mnasnet.py:48-54 with kernel_size 1 or 3).
+ * mode 0 (forward):  out[n,ho,wo,co] = bias[co] + sum_{kh,kw,ci} act(in)[n,ho*s+kh-p,wo*s+kw-p,ci] * W
+ *                    in  = (N,Hi,Wi,Ci) read through `act`;  out = (N,Ho,Wo,Co)
+ * mode 1 (dgrad):    out[n,hi,wi,ci] = resid + sum_{kh,kw,co} dy[n,(hi+p-kh)/s,(wi+p-kw)/s,co] * W
+ *                    in  = dy (N,Hi,Wi,Ci) read through `grad` (Hi,Wi,Ci are the FORWARD OUTPUT dims and
+ *                    channels), out = (N,Ho,Wo,Co) are the FORWARD INPUT dims/channels.
+ * w: packed bf16 [Co_pad16][Kpad32], K = kh*kw*Ci ordered (tap, ci) -- see mnas_pack_weights.
+ * stats (optional, forward): float[nparts][2][Co] partial (sum, sumsq) of the fp32 output, one row per
+ * pixel-workgroup; rows are fully overwritten (no memset needed). */
+typedef struct MnasConvGemm {
+    int32_t mode;
+    int32_t N, Hi, Wi, Ci;
+    int32_t Ho, Wo, Co;
+    int32_t kh, kw, stride, pad;
+    int32_t nparts;          /* pixel-workgroups (grid.x); 1..4096 */
+    int32_t reserved;
+    MnasActIn  act;
+    MnasGradIn grad;
+    const void*  w;
+    const float* bias;       /* [Co] or NULL */
+    const void*  resid;      /* bf16 (N,Ho,Wo,Co) or NULL */
+    void*        out;        /* bf16 (N,Ho,Wo,Co) */
+    float*       stats;      /* or NULL */
+} MnasConvGemm;
+int mnas_conv_gemm(const MnasConvGemm* a, void* stream);
+
+/* ---- weight gradient of the same convs: dW[co][tap][ci] = sum_pix dy[pix][co] * act(x)[src(pix,tap)][ci]
+ * Replaces ATen conv2d weight-gradient.  x = (N,Hi,Wi,Ci) forward input, dy = (N,Ho,Wo,Co).
+ * partial: float[nsplit][Co][K] (K = kh*kw*Ci), one slab per pixel split, fully overwritten;
+ * reduce + relayout with mnas_wgrad_finalize. */
+typedef struct MnasConvWgrad {
+    int32_t N, Hi, Wi, Ci;
+    int32_t Ho, Wo, Co;
+    int32_t kh, kw, stride, pad;
+    int32_t nsplit;
+    MnasActIn  x;
+    MnasGradIn dy;
+    float* partial;
+} MnasConvWgrad;
+int mnas_conv_wgrad(const MnasConvWgrad* a, void* stream);
+
+/* grad[co][ci][kh][kw] (reference layout, fp32) (+)= sum_s partial[s][co][tap*Ci+ci] */
+int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps,
+                        float* grad, int accumulate, void* stream);
+
+/* ---- depthwise kxk (k in {3,5}, stride 1, pad k/2), LDS-tiled direct conv on the vector ALU ----------
+ * Replaces ATen conv2d fwd/bwd for ConvBlock's groups==C convs (mnasnet.py:122-125, 76-81). */
+typedef struct MnasDwFwd {
+    int32_t N, H, W, C, k;
+    int32_t nparts;          /* persistent workgroups per channel block; rows of `stats` */
+    MnasActIn in;
+    const float* w;          /* fp32 [k*k][C] (tap-major) */
+    const float* bias;       /* [C] or NULL */
+    void*  out;              /* bf16 (N,H,W,C) raw output */
+    float* stats;            /* float[nparts][2][C] or NULL */
+} MnasDwFwd;
+int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
+
+typedef struct MnasDwBwd {
+    int32_t N, H, W, C, k;
+    int32_t nparts;
+    MnasActIn  x;            /* forward input (act-on-load) */
+    MnasGradIn dy;           /* gradient of the forward output (dy-on-load) */
+    const float* w;          /* fp32 [k*k][C] */
+    void*  gin;              /* bf16 (N,H,W,C): dL/d act(x) */
+    float* wpartial;         /* float[nparts][k*k][C], fully overwritten */
+} MnasDwBwd;
+int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
+/* grad[c][0][kh][kw] (+)= sum_p wpartial[p][tap][c] */
+int mnas_dw_wgrad_finalize(const float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
+                           void* stream);
+
+/* ---- stem: dense 3x3 stride 2 pad 1 on the fp32 NCHW network input (mnasnet.py:179) ------------------ */
+typedef struct MnasStemFwd {
+    int32_t N, H, W, Ho, Wo, Co;      /* Ci == 3 */
+    int32_t nparts;
+    const float* x;          /* fp32 NCHW (N,3,H,W) */
+    const void*  w;          /* packed bf16 [Co_pad16][32]: mnas_pack_weights(MNAS_PACK_FWD, Co, 27, 1, 1) of
+                                the reference [Co][3][3][3] tensor viewed as [Co][27] (k = ci*9+kh*3+kw) */
+    const float* bias;
+    void*  out;              /* bf16 (N,Ho,Wo,Co) */
+    float* stats;            /* float[nparts][2][Co] */
+} MnasStemFwd;
+int mnas_stem_fwd(const MnasStemFwd* a, void* stream);
+typedef struct MnasStemWgrad {
+    int32_t N, H, W, Ho, Wo, Co;
+    int32_t nparts;
+    const float* x;
+    MnasGradIn dy;
+    float* partial;          /* float[nparts][Co][27], fully overwritten */
+} MnasStemWgrad;
+int mnas_stem_wgrad(const MnasStemWgrad* a, void* stream);
+
+/* ---- BatchNorm2d bookkeeping (replaces ATen native_batch_norm / native_batch_norm_backward) ---------- */
+/* partial: float[nparts][2][C] (sum, sumsq over `count` elements per channel).
+ * training=1: batch stats -> bnbuf rows 0,1,5,6; running_mean/var momentum update (unbiased var),
+ *             num_batches_tracked (int64 device scalar, may be NULL) += 1.
+ * training=0: bnbuf rows 0,1 from the running stats; nothing else is touched (partial may be NULL). */
+int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, double count,
+                         const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         float momentum, float eps, int training, float* bnbuf, void* stream);
+/* partial[p][0][c] = sum dz, partial[p][1][c] = sum dz*xhat over the rows of workgroup p, where
+ * dz = g*[s*y+t>0], xhat = (y-mean)*invstd.  g,y: bf16 [rows][C]. */
+int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnbuf, int64_t rows, int C,
+                       int nparts, float* partial, void* stream);
+/* dgamma (+)= sum dz*xhat ; dbeta (+)= sum dz ; bnbuf rows 2..4 = c1,c2,c3 */
+int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count,
+                         float* bnbuf, float* dgamma, float* dbeta, int accumulate, void* stream);
+
+/* ---- element-wise glue ------------------------------------------------------------------------------ */
+/* out = act(a) + act(b)   (b.data may be NULL -> out = act(a)); rows x C bf16.  The MBConv_block residual
+ * (mnasnet.py:133).  If out_nchw_f32 != NULL the result is ALSO/INSTEAD written as fp32 NCHW (N,C,H,W)
+ * with rows = N*HW (the features output handed to AdaptiveAvgPool2d, classifiers.py:109). */
+int mnas_add_act(const MnasActIn* a, const MnasActIn* b, int64_t rows, int C, void* out_bf16,
+                 float* out_nchw_f32, int HW, void* stream);
+/* bf16 NHWC <- fp32 NCHW  (incoming gradient of the features output) */
+int mnas_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int HW, void* stream);
+
+/* ---- weight packing (fp32 reference layout [Co][Ci/g][kh][kw] -> kernel layouts) -------------------- */
+#define MNAS_PACK_FWD   0   /* bf16 [Co_pad16][Kpad32], k = tap*Ci+ci            (mnas_conv_gemm mode 0) */
+#define MNAS_PACK_DGRAD 1   /* bf16 [Ci_pad16][Kpad32], k = tap*Co+co            (mnas_conv_gemm mode 1) */
+#define MNAS_PACK_DW    2   /* fp32 [k*k][C]                                      (mnas_dw_*)            */
+int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int kh, int kw, void* dst, void* stream);
+/* sizes in BYTES of the packed buffers */
+int64_t mnas_packed_bytes(int kind, int Co, int Ci, int kh, int kw);
+
+/* ---- fused Adam over a flat fp32 parameter/gradient buffer (train.py:219-221: Adam(lr)) -------------- */
+int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- batched launch: run a pre-built list of the calls above with ONE host->library transition ------- */
+#define MNAS_OP_CONV_GEMM 1
+#define MNAS_OP_CONV_WGRAD 2
+#define MNAS_OP_WGRAD_FINALIZE 3
+#define MNAS_OP_DW_FWD 4
+#define MNAS_OP_DW_BWD 5
+#define MNAS_OP_DW_WGRAD_FINALIZE 6
+#define MNAS_OP_STEM_FWD 7
+#define MNAS_OP_STEM_WGRAD 8
+#define MNAS_OP_BN_FWD_FINALIZE 9
+#define MNAS_OP_BN_BWD_REDUCE 10
+#define MNAS_OP_BN_BWD_FINALIZE 11
+#define MNAS_OP_ADD_ACT 12
+#define MNAS_OP_NCHW_TO_NHWC 13
+#define MNAS_OP_PACK_WEIGHTS 14
+typedef struct MnasOp {
+    int32_t opcode;
+    int32_t i[15];
+    double  d[4];
+    void*   p[12];
+} MnasOp;
+/* Field use per opcode is documented next to mnas_run_ops in csrc/mnas_abi.hip. Stops at the first error
+ * and returns it (index of the failing op in *failed_at if non-NULL). */
+int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_at);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNAS_H */

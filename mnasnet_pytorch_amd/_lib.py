@@ -1,0 +1,129 @@
+"""ctypes binding of libmnas_hip.so (include/mnas.h).  No CPU fallback: if the library is missing the
+import of the product path fails loudly; if a launcher returns non-zero a RuntimeError is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmnas_hip.so")
+
+c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
+
+
+class MnasActIn(C.Structure):
+    _fields_ = [("data", c_void_p), ("scale", c_void_p), ("shift", c_void_p)]
+
+
+class MnasGradIn(C.Structure):
+    _fields_ = [("g", c_void_p), ("y", c_void_p), ("coef", c_void_p)]
+
+
+class MnasConvGemm(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("stride", C.c_int32), ("pad", C.c_int32), ("nparts", C.c_int32), ("reserved", C.c_int32),
+                ("act", MnasActIn), ("grad", MnasGradIn), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p),
+                ("out", c_void_p), ("stats", c_void_p)]
+
+
+class MnasConvWgrad(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32), ("Ho", C.c_int32),
+                ("Wo", C.c_int32), ("Co", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("nsplit", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("partial", c_void_p)]
+
+
+class MnasDwFwd(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
+                ("nparts", C.c_int32), ("in_", MnasActIn), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+                ("stats", c_void_p)]
+
+
+class MnasDwBwd(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
+                ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
+                ("wpartial", c_void_p)]
+
+
+class MnasStemFwd(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("Co", C.c_int32), ("nparts", C.c_int32), ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p),
+                ("out", c_void_p), ("stats", c_void_p)]
+
+
+class MnasStemWgrad(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("Co", C.c_int32), ("nparts", C.c_int32), ("x", c_void_p), ("dy", MnasGradIn), ("partial", c_void_p)]
+
+
+class MnasOp(C.Structure):
+    _fields_ = [("opcode", C.c_int32), ("i", C.c_int32 * 15), ("d", C.c_double * 4), ("p", c_void_p * 12)]
+
+
+OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6
+OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
+OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS = 12, 13, 14
+PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
+
+# every symbol include/mnas.h declares: (name, restype, argtypes)
+SYMBOLS = {
+    "mnas_version": (c_int, []),
+    "mnas_arch": (C.c_char_p, []),
+    "mnas_conv_gemm": (c_int, [C.POINTER(MnasConvGemm), c_void_p]),
+    "mnas_conv_wgrad": (c_int, [C.POINTER(MnasConvWgrad), c_void_p]),
+    "mnas_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mnas_dw_fwd": (c_int, [C.POINTER(MnasDwFwd), c_void_p]),
+    "mnas_dw_bwd": (c_int, [C.POINTER(MnasDwBwd), c_void_p]),
+    "mnas_dw_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mnas_stem_fwd": (c_int, [C.POINTER(MnasStemFwd), c_void_p]),
+    "mnas_stem_wgrad": (c_int, [C.POINTER(MnasStemWgrad), c_void_p]),
+    "mnas_bn_fwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "mnas_bn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_bn_bwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mnas_add_act": (c_int, [C.POINTER(MnasActIn), C.POINTER(MnasActIn), c_int64, c_int, c_void_p, c_void_p, c_int,
+                             c_void_p]),
+    "mnas_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mnas_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_packed_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "mnas_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                               c_float, c_int, c_float, c_void_p]),
+    "mnas_run_ops": (c_int, [C.POINTER(MnasOp), c_int, c_void_p, C.POINTER(c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmnas_hip.so and type every entry point.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmnas_hip.so not built (%s): run `make -C mnasnet_pytorch_amd/csrc` or __graft_entry__.build(). "
+            "There is no CPU / eager fallback for the MNASNet hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)     # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mnas_version() != 1:
+        raise RuntimeError("libmnas_hip.so ABI version %d != 1" % lib.mnas_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what="mnas call"):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+def cur_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,111 @@
+// ABI glue: version query and the batched launcher (one host->library transition per forward / backward
+// segment instead of ~450 ctypes calls per training step).
+#include "mnas_common.h"
+
+extern "C" int mnas_version(void) { return 1; }
+extern "C" const char* mnas_arch(void) { return "gfx950"; }
+
+// Field use per opcode (i = op.i, d = op.d, p = op.p):
+//  CONV_GEMM        i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw,stride,pad,nparts
+//                   p: act.data,act.scale,act.shift, grad.g,grad.y,grad.coef, w,bias,resid,out,stats
+//  CONV_WGRAD       i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw,stride,pad,nsplit   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, partial
+//  WGRAD_FINALIZE   i: nsplit,Co,Ci,taps,accumulate                  p: partial,grad
+//  DW_FWD           i: N,H,W,C,k,nparts      p: in.data,in.scale,in.shift, w,bias,out,stats
+//  DW_BWD           i: N,H,W,C,k,nparts      p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial
+//  DW_WGRAD_FINALIZE i: nparts,C,k,accumulate p: wpartial,grad
+//  STEM_FWD         i: N,H,W,Ho,Wo,Co,nparts p: x,w,bias,out,stats
+//  STEM_WGRAD       i: N,H,W,Ho,Wo,Co,nparts p: x, dy.g,dy.y,dy.coef, partial
+//  BN_FWD_FINALIZE  i: nparts,C,training  d: count,momentum,eps   p: partial,gamma,beta,rmean,rvar,nbt,bnbuf
+//  BN_BWD_REDUCE    i: C,nparts           d: rows                 p: g,y,bnbuf,partial
+//  BN_BWD_FINALIZE  i: nparts,C,accumulate d: count               p: partial,bnbuf,dgamma,dbeta
+//  ADD_ACT          i: C,HW               d: rows                 p: a.data,a.scale,a.shift, b.data,b.scale,b.shift, out_bf16,out_nchw
+//  NCHW_TO_NHWC     i: N,C,HW                                     p: src,dst
+//  PACK_WEIGHTS     i: kind,Co,Ci,kh,kw                           p: w,dst
+static int run_one(const MnasOp& o, void* stream) {
+    const int32_t* i = o.i;
+    void* const* p = o.p;
+    switch (o.opcode) {
+        case MNAS_OP_CONV_GEMM: {
+            MnasConvGemm a = {};
+            a.mode = i[0]; a.N = i[1]; a.Hi = i[2]; a.Wi = i[3]; a.Ci = i[4]; a.Ho = i[5]; a.Wo = i[6]; a.Co = i[7];
+            a.kh = i[8]; a.kw = i[9]; a.stride = i[10]; a.pad = i[11]; a.nparts = i[12];
+            a.act.data = p[0]; a.act.scale = (const float*)p[1]; a.act.shift = (const float*)p[2];
+            a.grad.g = p[3]; a.grad.y = p[4]; a.grad.coef = (const float*)p[5];
+            a.w = p[6]; a.bias = (const float*)p[7]; a.resid = p[8]; a.out = p[9]; a.stats = (float*)p[10];
+            return mnas_conv_gemm(&a, stream);
+        }
+        case MNAS_OP_CONV_WGRAD: {
+            MnasConvWgrad a = {};
+            a.N = i[0]; a.Hi = i[1]; a.Wi = i[2]; a.Ci = i[3]; a.Ho = i[4]; a.Wo = i[5]; a.Co = i[6];
+            a.kh = i[7]; a.kw = i[8]; a.stride = i[9]; a.pad = i[10]; a.nsplit = i[11];
+            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
+            a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
+            a.partial = (float*)p[6];
+            return mnas_conv_wgrad(&a, stream);
+        }
+        case MNAS_OP_WGRAD_FINALIZE:
+            return mnas_wgrad_finalize((const float*)p[0], i[0], i[1], i[2], i[3], (float*)p[1], i[4], stream);
+        case MNAS_OP_DW_FWD: {
+            MnasDwFwd a = {};
+            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.k = i[4]; a.nparts = i[5];
+            a.in.data = p[0]; a.in.scale = (const float*)p[1]; a.in.shift = (const float*)p[2];
+            a.w = (const float*)p[3]; a.bias = (const float*)p[4]; a.out = p[5]; a.stats = (float*)p[6];
+            return mnas_dw_fwd(&a, stream);
+        }
+        case MNAS_OP_DW_BWD: {
+            MnasDwBwd a = {};
+            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.k = i[4]; a.nparts = i[5];
+            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
+            a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
+            a.w = (const float*)p[6]; a.gin = p[7]; a.wpartial = (float*)p[8];
+            return mnas_dw_bwd(&a, stream);
+        }
+        case MNAS_OP_DW_WGRAD_FINALIZE:
+            return mnas_dw_wgrad_finalize((const float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], stream);
+        case MNAS_OP_STEM_FWD: {
+            MnasStemFwd a = {};
+            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.Ho = i[3]; a.Wo = i[4]; a.Co = i[5]; a.nparts = i[6];
+            a.x = (const float*)p[0]; a.w = p[1]; a.bias = (const float*)p[2]; a.out = p[3]; a.stats = (float*)p[4];
+            return mnas_stem_fwd(&a, stream);
+        }
+        case MNAS_OP_STEM_WGRAD: {
+            MnasStemWgrad a = {};
+            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.Ho = i[3]; a.Wo = i[4]; a.Co = i[5]; a.nparts = i[6];
+            a.x = (const float*)p[0];
+            a.dy.g = p[1]; a.dy.y = p[2]; a.dy.coef = (const float*)p[3];
+            a.partial = (float*)p[4];
+            return mnas_stem_wgrad(&a, stream);
+        }
+        case MNAS_OP_BN_FWD_FINALIZE:
+            return mnas_bn_fwd_finalize((const float*)p[0], i[0], i[1], o.d[0], (const float*)p[1], (const float*)p[2],
+                                        (float*)p[3], (float*)p[4], (int64_t*)p[5], (float)o.d[1], (float)o.d[2], i[2],
+                                        (float*)p[6], stream);
+        case MNAS_OP_BN_BWD_REDUCE:
+            return mnas_bn_bwd_reduce(p[0], p[1], (const float*)p[2], (int64_t)o.d[0], i[0], i[1], (float*)p[3], stream);
+        case MNAS_OP_BN_BWD_FINALIZE:
+            return mnas_bn_bwd_finalize((const float*)p[0], i[0], i[1], o.d[0], (float*)p[1], (float*)p[2], (float*)p[3],
+                                        i[2], stream);
+        case MNAS_OP_ADD_ACT: {
+            MnasActIn a = {p[0], (const float*)p[1], (const float*)p[2]};
+            MnasActIn b = {p[3], (const float*)p[4], (const float*)p[5]};
+            return mnas_add_act(&a, &b, (int64_t)o.d[0], i[0], p[6], (float*)p[7], i[1], stream);
+        }
+        case MNAS_OP_NCHW_TO_NHWC:
+            return mnas_nchw_f32_to_nhwc_bf16((const float*)p[0], p[1], i[0], i[1], i[2], stream);
+        case MNAS_OP_PACK_WEIGHTS:
+            return mnas_pack_weights((const float*)p[0], i[0], i[1], i[2], i[3], i[4], p[1], stream);
+        default:
+            return MNAS_EINVAL;
+    }
+}
+
+extern "C" int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_at) {
+    for (int k = 0; k < n; ++k) {
+        const int rc = run_one(ops[k], stream);
+        if (rc != MNAS_OK) {
+            if (failed_at) *failed_at = k;
+            return rc;
+        }
+    }
+    return MNAS_OK;
+}

@@ -1,0 +1,71 @@
+// Device-side helpers shared by the gfx950 kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mnas.h"
+
+#define MNAS_WAVE 64
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16 = 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 C/D fragment
+
+#define MNAS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf_to_f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// two fp32 -> packed bf16x2, round-to-nearest-even (v_cvt_pk_bf16_f32: lo = src0, hi = src1; verified
+// on gfx950 by tools/probe).
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ uint16_t f_to_bf(float f) { return (uint16_t)(pack_bf16(f, 0.f) & 0xffffu); }
+
+// unpack 8 bf16 (one 16-byte channel group) to fp32
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16(f[0], f[1]); v.y = pack_bf16(f[2], f[3]);
+    v.z = pack_bf16(f[4], f[5]); v.w = pack_bf16(f[6], f[7]);
+    return v;
+}
+
+// act-on-load for one channel group: relu(s*x+t)
+__device__ __forceinline__ uint4 act8(const uint4& raw, const float* s, const float* t) {
+    float f[8];
+    unpack8(raw, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], s[j], t[j]), 0.f);
+    return pack8(f);
+}
+// dy-on-load for one channel group: c1*(g*[s*y+t>0]) + c2*y + c3 ; coef rows are s,t,c1,c2,c3
+__device__ __forceinline__ void dy8(const uint4& graw, const uint4& yraw, const float* s, const float* t,
+                                    const float* c1, const float* c2, const float* c3, float* out) {
+    float g[8], y[8];
+    unpack8(graw, g);
+    unpack8(yraw, y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float dz = (fmaf(y[j], s[j], t[j]) > 0.f) ? g[j] : 0.f;
+        out[j] = fmaf(c1[j], dz, fmaf(c2[j], y[j], c3[j]));
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware remap of a 1-D block id: consecutive LOGICAL ids share an XCD (and its L2).
+// Hardware places block b on XCD b % 8 (observed, speed only).  Bijective for any n.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7u;
+    const unsigned xcd = b & 7u, slot = b >> 3;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}

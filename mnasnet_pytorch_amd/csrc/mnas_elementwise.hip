@@ -1,0 +1,379 @@
+// BatchNorm bookkeeping, residual add, layout conversions, weight packing, wgrad reductions, fused Adam.
+// All of these are HBM- or latency-bound helpers around the conv kernels; see include/mnas.h for the ABI.
+#include "mnas_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm forward finalize  (ATen native_batch_norm's statistics step; mnasnet.py:55,60)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_fwd_finalize(
+    const float* __restrict__ partial, int nparts, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+    float eps, int training, float* bnbuf) {
+    __shared__ double red[2][8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (training && c < C) {
+        for (int p = ty; p < nparts; p += 8) {
+            s1 += (double)partial[((size_t)p * 2 + 0) * C + c];
+            s2 += (double)partial[((size_t)p * 2 + 1) * C + c];
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float s, t;
+        if (training) {
+            for (int j = 1; j < 8; ++j) { s1 += red[0][j][tx]; s2 += red[1][j][tx]; }
+            const double mean = s1 / count;
+            double var = s2 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double invstd = 1.0 / sqrt(var + (double)eps);
+            s = (float)((double)gamma[c] * invstd);
+            t = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+            bnbuf[5 * C + c] = (float)mean;
+            bnbuf[6 * C + c] = (float)invstd;
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        } else {
+            const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+            s = gamma[c] * invstd;
+            t = beta[c] - running_mean[c] * s;
+        }
+        bnbuf[0 * C + c] = s;
+        bnbuf[1 * C + c] = t;
+    }
+    if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+extern "C" int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, double count, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var,
+                                    int64_t* num_batches_tracked, float momentum, float eps, int training,
+                                    float* bnbuf, void* stream) {
+    if (C <= 0 || (training && (!partial || nparts <= 0))) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training,
+                       bnbuf);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward reduce: per-channel sum(dz), sum(dz*xhat)   (native_batch_norm_backward, pass 1)
+// rows x C bf16; thread = (row lane, channel group) with the channel group fixed per thread so the
+// coefficients stay in registers across the persistent row loop.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const uint4* __restrict__ g, const uint4* __restrict__ y,
+                                                       const float* __restrict__ bnbuf, int64_t rows, int C,
+                                                       float* __restrict__ partial) {
+    extern __shared__ float red[];   // [2][C]
+    const int G = C >> 3;
+    const int R = 256 / G;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int64_t chunk = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk;
+    const int64_t r1 = min(rows, r0 + chunk);
+    if (tid < R * G) {
+        const int cg = tid % G, rl = tid / G;
+        float s[8], t[8], mu[8], is[8], a1[8], a2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s[j] = bnbuf[0 * C + cg * 8 + j];
+            t[j] = bnbuf[1 * C + cg * 8 + j];
+            is[j] = bnbuf[6 * C + cg * 8 + j];
+            mu[j] = -bnbuf[5 * C + cg * 8 + j] * is[j];
+            a1[j] = 0.f;
+            a2[j] = 0.f;
+        }
+        for (int64_t r = r0 + rl; r < r1; r += R) {
+            const uint4 gv = g[r * G + cg];
+            const uint4 yv = y[r * G + cg];
+            float gf[8], yf[8];
+            unpack8(gv, gf);
+            unpack8(yv, yf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dz = (fmaf(yf[j], s[j], t[j]) > 0.f) ? gf[j] : 0.f;
+                a1[j] += dz;
+                a2[j] = fmaf(dz, fmaf(yf[j], is[j], mu[j]), a2[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&red[cg * 8 + j], a1[j]);
+            atomicAdd(&red[C + cg * 8 + j], a2[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) partial[(size_t)blockIdx.x * 2 * C + i] = red[i];
+}
+
+extern "C" int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnbuf, int64_t rows, int C, int nparts,
+                                  float* partial, void* stream) {
+    if (C <= 0 || (C & 7) || C > 2048 || nparts <= 0) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nparts), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+                       (const uint4*)g, (const uint4*)y, bnbuf, rows, C, partial);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// dgamma, dbeta and the dy-on-load coefficients:
+//   dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) = c1*dz + c2*y + c3
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nparts, int C,
+                                                         double count, float* bnbuf, float* dgamma, float* dbeta,
+                                                         int accumulate) {
+    __shared__ double red[2][8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int p = ty; p < nparts; p += 8) {
+            s1 += (double)partial[((size_t)p * 2 + 0) * C + c];
+            s2 += (double)partial[((size_t)p * 2 + 1) * C + c];
+        }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int j = 1; j < 8; ++j) { s1 += red[0][j][tx]; s2 += red[1][j][tx]; }
+        const double s = bnbuf[0 * C + c], mean = bnbuf[5 * C + c], invstd = bnbuf[6 * C + c];
+        const double md = s1 / count, mx = s2 / count;
+        bnbuf[2 * C + c] = (float)s;
+        bnbuf[3 * C + c] = (float)(-s * invstd * mx);
+        bnbuf[4 * C + c] = (float)(s * (mean * invstd * mx - md));
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+    }
+}
+
+extern "C" int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count, float* bnbuf, float* dgamma,
+                                    float* dbeta, int accumulate, void* stream) {
+    if (C <= 0 || nparts <= 0) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+                       count, bnbuf, dgamma, dbeta, accumulate);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = act(a) + act(b): the MBConv_block residual (mnasnet.py:133) and the features-output conversion
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_add_act(MnasActIn a, MnasActIn b, int64_t rows, int C, uint4* __restrict__ out,
+                                                 float* __restrict__ out_nchw, int HW) {
+    const int G = C >> 3;
+    const int R = 256 / G;
+    const int tid = threadIdx.x;
+    if (tid >= R * G) return;
+    const int cg = tid % G, rl = tid / G;
+    float sa[8], ta[8], sb[8], tb[8];
+    const bool ha = a.scale != nullptr, hb = (b.data != nullptr) && (b.scale != nullptr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sa[j] = ha ? a.scale[cg * 8 + j] : 1.f;
+        ta[j] = ha ? a.shift[cg * 8 + j] : 0.f;
+        sb[j] = hb ? b.scale[cg * 8 + j] : 1.f;
+        tb[j] = hb ? b.shift[cg * 8 + j] : 0.f;
+    }
+    const uint4* pa = (const uint4*)a.data;
+    const uint4* pb = (const uint4*)b.data;
+    for (int64_t r = (int64_t)blockIdx.x * R + rl; r < rows; r += (int64_t)gridDim.x * R) {
+        float fa[8], fb[8];
+        unpack8(pa[r * G + cg], fa);
+        if (ha) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fa[j] = fmaxf(fmaf(fa[j], sa[j], ta[j]), 0.f);
+        }
+        if (pb) {
+            unpack8(pb[r * G + cg], fb);
+            if (hb) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fb[j] = fmaxf(fmaf(fb[j], sb[j], tb[j]), 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+        }
+        if (out) out[r * G + cg] = pack8(fa);
+        if (out_nchw) {
+            const int64_t n = r / HW, hw = r % HW;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out_nchw[(n * C + cg * 8 + j) * HW + hw] = fa[j];
+        }
+    }
+}
+
+extern "C" int mnas_add_act(const MnasActIn* a, const MnasActIn* b, int64_t rows, int C, void* out_bf16,
+                            float* out_nchw_f32, int HW, void* stream) {
+    if (!a || !a->data || C <= 0 || (C & 7) || C > 2048) return MNAS_EINVAL;
+    MnasActIn bb = {nullptr, nullptr, nullptr};
+    if (b) bb = *b;
+    const int R = 256 / (C >> 3);
+    int64_t blocks = (rows + R - 1) / R;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_add_act, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a, bb, rows, C,
+                       (uint4*)out_bf16, out_nchw_f32, HW);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ src, uint4* __restrict__ dst, int N,
+                                                      int C, int HW) {
+    const int G = C >> 3;
+    const int64_t total = (int64_t)N * HW * G;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(i % G);
+        const int64_t p = i / G;
+        const int64_t n = p / HW, hw = p % HW;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = src[(n * C + cg * 8 + j) * HW + hw];
+        dst[i] = pack8(f);
+    }
+}
+extern "C" int mnas_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int HW, void* stream) {
+    if (C <= 0 || (C & 7)) return MNAS_EINVAL;
+    int64_t total = (int64_t)N * HW * (C >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (uint4*)dst, N, C, HW);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int64_t mnas_packed_bytes(int kind, int Co, int Ci, int kh, int kw) {
+    if (kind == MNAS_PACK_FWD) return (int64_t)round_up(Co, 16) * round_up(kh * kw * Ci, 32) * 2;
+    if (kind == MNAS_PACK_DGRAD) return (int64_t)round_up(Ci, 16) * round_up(kh * kw * Co, 32) * 2;
+    if (kind == MNAS_PACK_DW) return (int64_t)kh * kw * Co * 4;
+    return -1;
+}
+
+// dst[r][k] bf16, rows = round_up(R,16), cols = round_up(T*S,32); kind FWD: r=co, (t,s)=(tap,ci); DGRAD: r=ci, s=co
+__global__ void k_pack_gemm(const float* __restrict__ w, int kind, int Co, int Ci, int taps, uint16_t* __restrict__ dst,
+                            int rows_pad, int kpad) {
+    const int total = rows_pad * kpad;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / kpad, k = i % kpad;
+        const int S = (kind == MNAS_PACK_FWD) ? Ci : Co;
+        const int R = (kind == MNAS_PACK_FWD) ? Co : Ci;
+        float v = 0.f;
+        if (r < R && k < taps * S) {
+            const int tap = k / S, s = k % S;
+            const int co = (kind == MNAS_PACK_FWD) ? r : s;
+            const int ci = (kind == MNAS_PACK_FWD) ? s : r;
+            v = w[((size_t)co * Ci + ci) * taps + tap];
+        }
+        dst[i] = f_to_bf(v);
+    }
+}
+__global__ void k_pack_dw(const float* __restrict__ w, int C, int taps, float* __restrict__ dst) {
+    const int total = C * taps;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int tap = i / C, c = i % C;
+        dst[i] = w[(size_t)c * taps + tap];
+    }
+}
+extern "C" int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int kh, int kw, void* dst, void* stream) {
+    const int taps = kh * kw;
+    if (kind == MNAS_PACK_FWD || kind == MNAS_PACK_DGRAD) {
+        const int R = (kind == MNAS_PACK_FWD) ? Co : Ci, S = (kind == MNAS_PACK_FWD) ? Ci : Co;
+        const int rows_pad = round_up(R, 16), kpad = round_up(taps * S, 32);
+        int blocks = (rows_pad * kpad + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_pack_gemm, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, kind, Co, Ci, taps,
+                           (uint16_t*)dst, rows_pad, kpad);
+    } else if (kind == MNAS_PACK_DW) {
+        int blocks = (Co * taps + 255) / 256;
+        hipLaunchKernelGGL(k_pack_dw, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Co, taps, (float*)dst);
+    } else {
+        return MNAS_EINVAL;
+    }
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad reductions (+ relayout to the reference's [Co][Ci][kh][kw])
+// ------------------------------------------------------------------------------------------------
+__global__ void k_wgrad_finalize(const float* __restrict__ partial, int nsplit, int Co, int Ci, int taps,
+                                 float* __restrict__ grad, int accumulate) {
+    const int K = taps * Ci;
+    const int total = Co * K;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float s = 0.f;
+        for (int p = 0; p < nsplit; ++p) s += partial[(size_t)p * total + i];
+        const int co = i / K, k = i % K;
+        const int tap = k / Ci, ci = k % Ci;
+        float* d = grad + ((size_t)co * Ci + ci) * taps + tap;
+        *d = (accumulate ? *d : 0.f) + s;
+    }
+}
+extern "C" int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps, float* grad,
+                                   int accumulate, void* stream) {
+    int blocks = (Co * Ci * taps + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, Co, Ci, taps,
+                       grad, accumulate);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+__global__ void k_dw_wgrad_finalize(const float* __restrict__ wpartial, int nparts, int C, int taps,
+                                    float* __restrict__ grad, int accumulate) {
+    const int total = C * taps;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float s = 0.f;
+        for (int p = 0; p < nparts; ++p) s += wpartial[(size_t)p * total + i];
+        const int tap = i / C, c = i % C;
+        float* d = grad + (size_t)c * taps + tap;
+        *d = (accumulate ? *d : 0.f) + s;
+    }
+}
+extern "C" int mnas_dw_wgrad_finalize(const float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
+                                      void* stream) {
+    int blocks = (C * k * k + 255) / 256;
+    hipLaunchKernelGGL(k_dw_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, wpartial, nparts, C, k * k,
+                       grad, accumulate);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused Adam over a flat buffer (torch.optim.Adam semantics, train.py:219-221)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                              float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+extern "C" int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (step < 1 || n < 0) return MNAS_EINVAL;
+    if (n == 0) return MNAS_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}

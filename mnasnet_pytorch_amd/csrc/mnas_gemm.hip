@@ -1,0 +1,345 @@
+// 1x1 and dense kxk convolution forward / input-gradient as an im2col-free implicit GEMM on the gfx950
+// matrix cores (v_mfma_f32_16x16x32_bf16), NHWC bf16 activations, fp32 accumulate.
+// Replaces ATen conv2d forward + dgrad for ConvBlock(groups=1) (mnasnet.py:48-54; kernel_size 1 and 3).
+//
+// Orientation: the MFMA "A" operand (D rows) is the WEIGHT tile [16 cout][32 k], the "B" operand (D cols)
+// is the ACTIVATION tile [16 pixels][32 k]; both are k-contiguous 16-byte fragments read from LDS with
+// ds_read_b128.  D[cout][pixel] then leaves every lane with 4 CONSECUTIVE output channels of ONE pixel, so
+// the epilogue (bias, BatchNorm partial statistics, residual add, bf16 pack) is lane-local and the store is
+// one 8-byte write per fragment -- no LDS transpose on the way out.
+//
+// Prologue fusion: the activation tile is staged global -> registers -> LDS, applying on the way either
+//   relu(scale*x+shift)                      (forward: the producer's BatchNorm+ReLU, "act-on-load"), or
+//   c1*(g*[s*y+t>0]) + c2*y + c3             (dgrad: BatchNorm/ReLU backward, "dy-on-load").
+// Epilogue fusion: per-workgroup partial (sum, sumsq) of the fp32 output for the NEXT BatchNorm.
+//
+// Work split: grid.x persistent workgroups stride over pixel tiles (BP = 64*PT pixels; each of the 4 waves
+// owns PT groups of 16 pixels), grid.y over blocks of NT*16 output channels.  K = taps*Ci is walked in LDS
+// chunks of <= 64.  Roofline: unfused these layers sit left of the bf16 ridge (AI 11-165 flop/B < 312), so
+// HBM bounds them; MFMA utilisation only matters for the late, small-M layers.
+#include "mnas_common.h"
+
+struct IgemmArgs {
+    int M, Hi, Wi, Ci, Ho, Wo, Co;
+    int kh, kw, stride, pad;
+    int Ktot, Kpad, kch, taps, is_pw, co_pad16;
+    MnasActIn act;
+    MnasGradIn grad;
+    const uint16_t* w;
+    const float* bias;
+    const void* resid;
+    void* out;
+    float* stats;
+};
+
+template <int MODE, int NT, int PT>
+__global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BP = 64 * PT;
+    constexpr int CROWS = (MODE == 1) ? 5 : 2;
+    const int kch = a.kch;
+    const int ldk = kch + 8;                       // LDS row stride in bf16 elements (16-byte padded)
+    const int kc8n = kch >> 3;                     // 16-byte chunks per row
+    const int ccols = (a.taps == 1) ? kch : a.Ci;  // coefficient columns kept in LDS
+    float* lds_coef = (float*)smem;                                        // [CROWS][ccols]
+    float* lds_red = lds_coef + CROWS * ccols;                             // [2][NT*16]
+    uint16_t* lds_w = (uint16_t*)(lds_red + 2 * NT * 16);                  // [NT*16][ldk]
+    uint16_t* lds_a = lds_w + NT * 16 * ldk;                               // [BP][ldk]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.y * NT * 16;
+    const int nkc = (a.Kpad + kch - 1) / kch;
+    const bool has_coef = (MODE == 1) || (MODE == 0 && a.act.scale != nullptr);
+    const float* coef_src[CROWS];
+    if (MODE != 1) { coef_src[0] = a.act.scale; coef_src[1] = a.act.shift; }
+    else {
+#pragma unroll
+        for (int r = 0; r < CROWS; ++r) coef_src[r] = a.grad.coef + (size_t)r * a.Ci;
+    }
+
+    auto load_coefs = [&](int k0) {
+        if (!has_coef) return;
+        for (int i = tid; i < CROWS * ccols; i += 256) {
+            const int r = i / ccols, c = (a.taps == 1 ? k0 : 0) + i % ccols;
+            lds_coef[i] = (c < a.Ci) ? coef_src[r][c] : 0.f;
+        }
+    };
+    auto stage_w = [&](int k0) {
+        const int chunks = NT * 16 * kc8n;
+        for (int q = tid; q < chunks; q += 256) {
+            const int r = q / kc8n, kc8 = q % kc8n;
+            const int k = k0 + kc8 * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n0 + r < a.co_pad16 && k < a.Kpad) v = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + k);
+            *(uint4*)(lds_w + r * ldk + kc8 * 8) = v;
+        }
+    };
+    auto stage_a = [&](int tile0, int k0) {
+        const int chunks = BP * kc8n;
+        for (int q = tid; q < chunks; q += 256) {
+            const int p = q / kc8n, kc8 = q % kc8n;
+            const int k = k0 + kc8 * 8;
+            const int m = tile0 + p;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (MODE == 2) {
+                // stem (mnasnet.py:179): im2col of the fp32 NCHW image, k = ci*9 + kh*3 + kw (reference
+                // weight order), 3x3 stride 2 pad 1; Hi,Wi = image dims
+                if (m < a.M) {
+                    const int hw = a.Ho * a.Wo;
+                    const int n = m / hw, rem = m - n * hw;
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    const float* x = (const float*)a.act.data;
+                    float f[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = k + j;
+                        const int ci = kk / 9, r9 = kk - ci * 9, th = r9 / 3, tw = r9 - th * 3;
+                        const int ih = oh * 2 + th - 1, iw = ow * 2 + tw - 1;
+                        const bool okj = kk < 27 && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                        f[j] = okj ? x[(((size_t)n * 3 + ci) * a.Hi + ih) * a.Wi + iw] : 0.f;
+                    }
+                    v = pack8(f);
+                }
+            } else if (m < a.M && k < a.Ktot) {
+                int ci = k;
+                size_t src;
+                bool ok = true;
+                if (a.is_pw) {
+                    src = (size_t)m * a.Ci + k;
+                } else {
+                    const int tap = k / a.Ci;
+                    ci = k - tap * a.Ci;
+                    const int th = tap / a.kw, tw = tap - th * a.kw;
+                    const int hw = a.Ho * a.Wo;
+                    const int n = m / hw, rem = m - n * hw;
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    int ih, iw;
+                    if (MODE == 0) {
+                        ih = oh * a.stride + th - a.pad;
+                        iw = ow * a.stride + tw - a.pad;
+                    } else {   // transposed geometry: dy pixel that this forward-input pixel fed through tap
+                        const int yh = oh + a.pad - th, yw = ow + a.pad - tw;
+                        ok = (yh >= 0) && (yw >= 0) && (yh % a.stride == 0) && (yw % a.stride == 0);
+                        ih = yh / a.stride;
+                        iw = yw / a.stride;
+                    }
+                    ok = ok && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + ci;
+                }
+                if (ok) {
+                    const int cc = (a.taps == 1) ? (k - k0) : ci;
+                    if (MODE != 1) {
+                        v = *(const uint4*)((const uint16_t*)a.act.data + src);
+                        if (has_coef) {
+                            float s[8], t[8];
+                            *(float4*)&s[0] = *(const float4*)(lds_coef + cc);
+                            *(float4*)&s[4] = *(const float4*)(lds_coef + cc + 4);
+                            *(float4*)&t[0] = *(const float4*)(lds_coef + ccols + cc);
+                            *(float4*)&t[4] = *(const float4*)(lds_coef + ccols + cc + 4);
+                            v = act8(v, s, t);
+                        }
+                    } else {
+                        const uint4 gv = *(const uint4*)((const uint16_t*)a.grad.g + src);
+                        const uint4 yv = *(const uint4*)((const uint16_t*)a.grad.y + src);
+                        float cf[5][8];
+#pragma unroll
+                        for (int r = 0; r < 5; ++r) {
+                            *(float4*)&cf[r][0] = *(const float4*)(lds_coef + r * ccols + cc);
+                            *(float4*)&cf[r][4] = *(const float4*)(lds_coef + r * ccols + cc + 4);
+                        }
+                        float o[8];
+                        dy8(gv, yv, cf[0], cf[1], cf[2], cf[3], cf[4], o);
+                        v = pack8(o);
+                    }
+                }
+            }
+            *(uint4*)(lds_a + p * ldk + kc8 * 8) = v;
+        }
+    };
+
+    // per-lane epilogue constants: the 4 consecutive output channels this lane owns in each cout tile
+    float bias_r[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = n0 + nt * 16 + lg * 4 + r;
+            bias_r[nt][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+        }
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+
+    if (nkc == 1) {       // weights + coefficients are tile-invariant: stage once
+        load_coefs(0);
+        stage_w(0);
+    } else if (a.taps != 1) {
+        load_coefs(0);    // all Ci channels resident
+    }
+
+    const int ntiles = (a.M + BP - 1) / BP;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tile0 = t * BP;
+        f32x4_t acc[PT][NT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int k0 = kc * kch;
+            __syncthreads();                       // previous chunk's fragments consumed
+            if (nkc > 1) {
+                if (a.taps == 1) { load_coefs(k0); __syncthreads(); }
+                stage_w(k0);
+            }
+            stage_a(tile0, k0);
+            __syncthreads();
+            const int ksteps = min(kch, a.Kpad - k0) >> 5;
+            for (int ks = 0; ks < ksteps; ++ks) {
+                bf16x8_t bfrag[PT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    bfrag[pt] = *(const bf16x8_t*)(lds_a + ((wave * PT + pt) * 16 + l15) * ldk + ks * 32 + lg * 8);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8_t afrag = *(const bf16x8_t*)(lds_w + (nt * 16 + l15) * ldk + ks * 32 + lg * 8);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[pt], acc[pt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: lane holds couts n0+nt*16+lg*4+{0..3} of pixel tile0+(wave*PT+pt)*16+l15
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = tile0 + (wave * PT + pt) * 16 + l15;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = n0 + nt * 16 + lg * 4;
+                if (co >= a.Co) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[pt][nt][r] + bias_r[nt][r];
+                const size_t o = (size_t)m * a.Co + co;
+                if (a.resid) {
+                    const uint2 rv = *(const uint2*)((const uint16_t*)a.resid + o);
+                    v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
+                }
+                if (MODE != 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s1[nt][r] += v[r]; s2[nt][r] = fmaf(v[r], v[r], s2[nt][r]); }
+                }
+                uint2 pk;
+                pk.x = pack_bf16(v[0], v[1]);
+                pk.y = pack_bf16(v[2], v[3]);
+                *(uint2*)((uint16_t*)a.out + o) = pk;
+            }
+        }
+    }
+
+    if (MODE != 1 && a.stats) {
+        __syncthreads();
+        for (int i = tid; i < 2 * NT * 16; i += 256) lds_red[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x1 = s1[nt][r], x2 = s2[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+                if (l15 == 0) {
+                    atomicAdd(&lds_red[nt * 16 + lg * 4 + r], x1);
+                    atomicAdd(&lds_red[NT * 16 + nt * 16 + lg * 4 + r], x2);
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < 2 * NT * 16; i += 256) {
+            const int r = i / (NT * 16), c = n0 + i % (NT * 16);
+            if (c < a.Co) a.stats[((size_t)blockIdx.x * 2 + r) * a.Co + c] = lds_red[i];
+        }
+    }
+}
+
+template <int MODE, int NT, int PT>
+static int launch_igemm(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
+    constexpr int CROWS = (MODE == 1) ? 5 : 2;
+    const int ccols = (a.taps == 1) ? a.kch : a.Ci;
+    const size_t lds = (size_t)(CROWS * ccols + 2 * NT * 16) * sizeof(float) +
+                       (size_t)(NT * 16 + 64 * PT) * (a.kch + 8) * 2;
+    if (lds > 160 * 1024) return MNAS_EINVAL;
+    hipLaunchKernelGGL((k_igemm<MODE, NT, PT>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
+    if (!c || (c->mode != 0 && c->mode != 1)) return MNAS_EINVAL;
+    if ((c->Ci & 7) || (c->Co & 7) || c->nparts < 1 || c->nparts > 65535) return MNAS_EINVAL;
+    IgemmArgs a;
+    a.M = c->N * c->Ho * c->Wo;
+    a.Hi = c->Hi; a.Wi = c->Wi; a.Ci = c->Ci; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co;
+    a.kh = c->kh; a.kw = c->kw; a.stride = c->stride; a.pad = c->pad;
+    a.taps = c->kh * c->kw;
+    a.Ktot = a.taps * c->Ci;
+    a.Kpad = (a.Ktot + 31) / 32 * 32;
+    a.kch = a.Kpad >= 64 ? 64 : 32;
+    a.is_pw = (a.taps == 1 && c->stride == 1 && c->pad == 0) ? 1 : 0;
+    a.co_pad16 = (c->Co + 15) / 16 * 16;
+    a.act = c->act; a.grad = c->grad;
+    a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = c->resid; a.out = c->out; a.stats = c->stats;
+    if (a.taps != 1 && c->Ci > 1024) return MNAS_EINVAL;
+    if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;   // strided / padded 1x1 does not occur in this network
+    if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
+    if (c->mode == 1 && (!c->grad.g || !c->grad.y || !c->grad.coef)) return MNAS_EINVAL;
+
+    // cout tiling: NT*16 channels per workgroup column, minimising padded tiles then blocks
+    const int tiles = (c->Co + 15) / 16;
+    static const int opts[] = {8, 6, 4, 3, 2, 1};
+    int best_nt = 1, best_waste = 1 << 30, best_blocks = 1 << 30;
+    for (int nt : opts) {
+        const int blocks = (tiles + nt - 1) / nt;
+        const int waste = blocks * nt - tiles;
+        if (waste < best_waste || (waste == best_waste && blocks < best_blocks)) {
+            best_nt = nt; best_waste = waste; best_blocks = blocks;
+        }
+    }
+    const int nblocks = best_blocks;
+    // PT=2 (128-pixel tiles) when there are enough tiles to fill the chip twice over
+    const int pt = ((int64_t)a.M * nblocks >= (int64_t)128 * 1024) ? 2 : 1;
+    hipStream_t s = (hipStream_t)stream;
+#define MNAS_IG(MODE_, NT_) \
+    if (c->mode == MODE_ && best_nt == NT_) return pt == 2 ? launch_igemm<MODE_, NT_, 2>(a, c->nparts, nblocks, s) \
+                                                           : launch_igemm<MODE_, NT_, 1>(a, c->nparts, nblocks, s);
+    MNAS_IG(0, 1) MNAS_IG(0, 2) MNAS_IG(0, 3) MNAS_IG(0, 4) MNAS_IG(0, 6) MNAS_IG(0, 8)
+    MNAS_IG(1, 1) MNAS_IG(1, 2) MNAS_IG(1, 3) MNAS_IG(1, 4) MNAS_IG(1, 6) MNAS_IG(1, 8)
+#undef MNAS_IG
+    return MNAS_EINVAL;
+}
+
+// Stem: dense 3x3 stride-2 conv on the fp32 NCHW image (mnasnet.py:179) = the same GEMM with an im2col
+// staging mode (K = 27 padded to 32, image values rounded to bf16 like every other activation).
+extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
+    if (!c || (c->Co & 7) || c->Co > 128 || c->nparts < 1) return MNAS_EINVAL;
+    IgemmArgs a;
+    a.M = c->N * c->Ho * c->Wo;
+    a.Hi = c->H; a.Wi = c->W; a.Ci = 27; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co;
+    a.kh = 3; a.kw = 3; a.stride = 2; a.pad = 1;
+    a.taps = 1; a.Ktot = 27; a.Kpad = 32; a.kch = 32; a.is_pw = 0;
+    a.co_pad16 = (c->Co + 15) / 16 * 16;
+    a.act.data = c->x; a.act.scale = nullptr; a.act.shift = nullptr;
+    a.grad.g = nullptr; a.grad.y = nullptr; a.grad.coef = nullptr;
+    a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = nullptr; a.out = c->out; a.stats = c->stats;
+    const int tiles = (c->Co + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (tiles == 1) return launch_igemm<2, 1, 2>(a, c->nparts, 1, s);
+    if (tiles == 2) return launch_igemm<2, 2, 2>(a, c->nparts, 1, s);
+    if (tiles <= 4) return launch_igemm<2, 4, 2>(a, c->nparts, 1, s);
+    return launch_igemm<2, 8, 2>(a, c->nparts, 1, s);
+}

@@ -1,0 +1,231 @@
+// Weight gradient of the 1x1 / dense kxk convolutions on the matrix cores:
+//     dW[co][tap*Ci+ci] = sum over output pixels of dy[pix][co] * act(x)[src(pix,tap)][ci]
+// Replaces ATen's conv2d weight-gradient for ConvBlock(groups=1) (autograd mirror of mnasnet.py:48-54).
+//
+// GEMM view: D[co][k] (16x16 MFMA tiles) with the reduction running over PIXELS.  Both operands are stored
+// pixel-major in HBM/LDS (NHWC), i.e. transposed with respect to what the MFMA fragments want (8 consecutive
+// reduction indices per lane), so the fragments are read with gfx950's LDS transpose-read
+// ds_read_b64_tr_b16: lane i of a 16-lane group points at row (i>>2), 4 columns starting at (i&3)*4 and
+// receives column i of 4 consecutive rows (verified by tools/probe).  Two such reads = one bf16x8 fragment.
+//
+// A workgroup owns a (<=64 cout) x (<=64 k) slab of dW and a contiguous range of pixels; its 4 waves split
+// each 128-pixel chunk (32 pixels = one MFMA k-step each) and hold the whole slab in accumulators; the
+// four copies are summed through LDS once at the end and written to partial[split][co][k] (plain stores, no
+// atomics, deterministic); mnas_wgrad_finalize reduces the splits.
+// dy-on-load and act-on-load are applied while staging, exactly as in mnas_gemm.hip.
+#include "mnas_common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s4_t;
+typedef __attribute__((address_space(3))) s4_t* lds_s4_ptr;
+
+struct WgradArgs {
+    int M, Hi, Wi, Ci, Ho, Wo, Co;
+    int kh, kw, stride, pad;
+    int Ktot, taps, is_pw, chunk;   // chunk = pixels per split (multiple of 128)
+    MnasActIn x;
+    MnasGradIn dy;
+    float* partial;
+};
+
+#define WG_BPIX 128
+#define WG_T 4            // 4x4 tiles of 16x16 per workgroup slab
+
+__device__ __forceinline__ bf16x8_t tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
+    // rows row0 + (lane>>4)*8 + {0..7}, column col0 + (lane&15)
+    const int i = lane & 15, g = lane >> 4;
+    const uint16_t* p = tile + (row0 + g * 8 + (i >> 2)) * ld + col0 + (i & 3) * 4;
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)p);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p + 4 * ld));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool STEM>
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int co0 = blockIdx.y * 64, kc0 = blockIdx.z * 64;
+    const int con = min(64, a.Co - co0);                  // valid couts in the slab (multiple of 8)
+    const int kn = min(64, a.Ktot - kc0);                 // valid k columns (multiple of 8)
+    const int ctn = (con + 15) >> 4, ktn = (kn + 15) >> 4;
+    const int ldd = 64 + 8, lda = 64 + 8;                 // LDS row strides (elements)
+    const int xcols = (a.taps == 1) ? 64 : a.Ci;
+    float* lds_cd = (float*)smem;                         // [5][64]   dy coefficients for couts co0..
+    float* lds_cx = lds_cd + 5 * 64;                      // [2][xcols] scale/shift of x
+    uint16_t* tile_d = (uint16_t*)(lds_cx + 2 * xcols);   // [128][ldd]
+    uint16_t* tile_a = tile_d + WG_BPIX * ldd;            // [128][lda]
+    float* lds_out = (float*)tile_d;                      // reused at the end: [64][65]
+
+    for (int i = tid; i < 5 * 64; i += 256) {
+        const int r = i >> 6, c = co0 + (i & 63);
+        lds_cd[i] = (c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
+    }
+    const bool hasx = !STEM && a.x.scale != nullptr;
+    if (hasx)
+        for (int i = tid; i < 2 * xcols; i += 256) {
+            const int r = i / xcols, c = (a.taps == 1 ? kc0 : 0) + i % xcols;
+            lds_cx[i] = (c < a.Ci) ? (r == 0 ? a.x.scale[c] : a.x.shift[c]) : 0.f;
+        }
+
+    f32x4_t acc[WG_T][WG_T];
+#pragma unroll
+    for (int i = 0; i < WG_T; ++i)
+#pragma unroll
+        for (int j = 0; j < WG_T; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int p_begin = blockIdx.x * a.chunk;
+    const int p_end = min(a.M, p_begin + a.chunk);
+    for (int pc = p_begin; pc < p_end; pc += WG_BPIX) {
+        __syncthreads();
+        // ---- stage dy tile: [128 pixels][64 couts]
+        for (int q = tid; q < WG_BPIX * 8; q += 256) {
+            const int p = q >> 3, c8 = q & 7;
+            const int m = pc + p, co = co0 + c8 * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < p_end && co < a.Co) {
+                const size_t off = (size_t)m * a.Co + co;
+                const uint4 gv = *(const uint4*)((const uint16_t*)a.dy.g + off);
+                const uint4 yv = *(const uint4*)((const uint16_t*)a.dy.y + off);
+                float cf[5][8];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    *(float4*)&cf[r][0] = *(const float4*)(lds_cd + r * 64 + c8 * 8);
+                    *(float4*)&cf[r][4] = *(const float4*)(lds_cd + r * 64 + c8 * 8 + 4);
+                }
+                float o[8];
+                dy8(gv, yv, cf[0], cf[1], cf[2], cf[3], cf[4], o);
+                v = pack8(o);
+            }
+            *(uint4*)(tile_d + p * ldd + c8 * 8) = v;
+        }
+        // ---- stage activation tile: [128 pixels][64 k columns], gathered per tap for kxk
+        for (int q = tid; q < WG_BPIX * 8; q += 256) {
+            const int p = q >> 3, c8 = q & 7;
+            const int m = pc + p, k = kc0 + c8 * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (STEM) {
+                // im2col of the fp32 NCHW image: k = ci*9 + kh*3 + kw (reference weight order)
+                if (m < p_end && k < 32) {
+                    const int hw = a.Ho * a.Wo;
+                    const int n = m / hw, rem = m - n * hw;
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    const float* x = (const float*)a.x.data;
+                    float f[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = k + j;
+                        const int ci = kk / 9, r9 = kk - ci * 9, th = r9 / 3, tw = r9 - th * 3;
+                        const int ih = oh * 2 + th - 1, iw = ow * 2 + tw - 1;
+                        const bool okj = kk < 27 && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                        f[j] = okj ? x[(((size_t)n * 3 + ci) * a.Hi + ih) * a.Wi + iw] : 0.f;
+                    }
+                    v = pack8(f);
+                }
+            } else if (m < p_end && k < a.Ktot) {
+                int ci = k;
+                size_t src;
+                bool ok = true;
+                if (a.is_pw) {
+                    src = (size_t)m * a.Ci + k;
+                } else {
+                    const int tap = k / a.Ci;
+                    ci = k - tap * a.Ci;
+                    const int th = tap / a.kw, tw = tap - th * a.kw;
+                    const int hw = a.Ho * a.Wo;
+                    const int n = m / hw, rem = m - n * hw;
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    const int ih = oh * a.stride + th - a.pad, iw = ow * a.stride + tw - a.pad;
+                    ok = ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + ci;
+                }
+                if (ok) {
+                    v = *(const uint4*)((const uint16_t*)a.x.data + src);
+                    if (hasx) {
+                        const int cc = (a.taps == 1) ? c8 * 8 : ci;
+                        float s[8], t[8];
+                        *(float4*)&s[0] = *(const float4*)(lds_cx + cc);
+                        *(float4*)&s[4] = *(const float4*)(lds_cx + cc + 4);
+                        *(float4*)&t[0] = *(const float4*)(lds_cx + xcols + cc);
+                        *(float4*)&t[4] = *(const float4*)(lds_cx + xcols + cc + 4);
+                        v = act8(v, s, t);
+                    }
+                }
+            }
+            *(uint4*)(tile_a + p * lda + c8 * 8) = v;
+        }
+        __syncthreads();
+        // ---- each wave: its 32 pixels, all slab tiles
+        bf16x8_t bf[WG_T];
+#pragma unroll
+        for (int kt = 0; kt < WG_T; ++kt)
+            if (kt < ktn) bf[kt] = tr_frag(tile_a, lda, wave * 32, kt * 16, lane);
+#pragma unroll
+        for (int ct = 0; ct < WG_T; ++ct) {
+            if (ct >= ctn) continue;
+            const bf16x8_t af = tr_frag(tile_d, ldd, wave * 32, ct * 16, lane);
+#pragma unroll
+            for (int kt = 0; kt < WG_T; ++kt)
+                if (kt < ktn) acc[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[kt], acc[ct][kt], 0, 0, 0);
+        }
+    }
+    // ---- sum the 4 waves' slabs through LDS, then write partial[split][co][k]
+    __syncthreads();
+    for (int i = tid; i < 64 * 65; i += 256) lds_out[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < WG_T; ++ct)
+#pragma unroll
+        for (int kt = 0; kt < WG_T; ++kt) {
+            if (ct >= ctn || kt >= ktn) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&lds_out[(ct * 16 + lg * 4 + r) * 65 + kt * 16 + l15], acc[ct][kt][r]);
+        }
+    __syncthreads();
+    float* dst = a.partial + (size_t)blockIdx.x * a.Co * a.Ktot;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (r < con && c < kn) dst[(size_t)(co0 + r) * a.Ktot + kc0 + c] = lds_out[r * 65 + c];
+    }
+}
+
+extern "C" int mnas_conv_wgrad(const MnasConvWgrad* c, void* stream) {
+    if (!c || (c->Ci & 7) || (c->Co & 7) || c->nsplit < 1) return MNAS_EINVAL;
+    WgradArgs a;
+    a.M = c->N * c->Ho * c->Wo;
+    a.Hi = c->Hi; a.Wi = c->Wi; a.Ci = c->Ci; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co;
+    a.kh = c->kh; a.kw = c->kw; a.stride = c->stride; a.pad = c->pad;
+    a.taps = c->kh * c->kw;
+    a.Ktot = a.taps * c->Ci;
+    a.is_pw = (a.taps == 1 && c->stride == 1 && c->pad == 0) ? 1 : 0;
+    if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;
+    if (a.taps != 1 && c->Ci > 1024) return MNAS_EINVAL;
+    const int per = (a.M + c->nsplit - 1) / c->nsplit;
+    a.chunk = (per + WG_BPIX - 1) / WG_BPIX * WG_BPIX;
+    a.x = c->x; a.dy = c->dy; a.partial = c->partial;
+    const int xcols = (a.taps == 1) ? 64 : a.Ci;
+    const size_t lds = (size_t)(5 * 64 + 2 * xcols) * sizeof(float) + (size_t)2 * WG_BPIX * 72 * 2;
+    dim3 grid(c->nsplit, (c->Co + 63) / 64, (a.Ktot + 63) / 64);
+    hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// Stem weight gradient: partial[split][co][27] already in the reference's [co][ci][kh][kw] order
+// (finalize with mnas_wgrad_finalize(partial, nsplit, Co, 27, 1, grad, ...)).
+extern "C" int mnas_stem_wgrad(const MnasStemWgrad* c, void* stream) {
+    if (!c || (c->Co & 7) || c->nparts < 1) return MNAS_EINVAL;
+    WgradArgs a;
+    a.M = c->N * c->Ho * c->Wo;
+    a.Hi = c->H; a.Wi = c->W; a.Ci = 27; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co;
+    a.kh = 3; a.kw = 3; a.stride = 2; a.pad = 1;
+    a.taps = 1; a.Ktot = 27; a.is_pw = 0;
+    const int per = (a.M + c->nparts - 1) / c->nparts;
+    a.chunk = (per + WG_BPIX - 1) / WG_BPIX * WG_BPIX;
+    a.x.data = c->x; a.x.scale = nullptr; a.x.shift = nullptr;
+    a.dy = c->dy; a.partial = c->partial;
+    const size_t lds = (size_t)(5 * 64 + 2 * 64) * sizeof(float) + (size_t)2 * WG_BPIX * 72 * 2;
+    dim3 grid(c->nparts, (c->Co + 63) / 64, 1);
+    hipLaunchKernelGGL(k_wgrad<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
