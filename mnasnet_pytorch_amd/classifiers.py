@@ -1,0 +1,61 @@
+"""Drop-in for the mnasnet branch of the reference's ``src/models/classifiers.py``:
+``load_model`` (classifiers.py:7-17) and ``FineTuneModelPool`` (classifiers.py:19-111).
+
+The feature extractor is the HIP engine (``Mnasnet(cut_channels_first=False).features``, exactly what
+train.py:194-207 builds); pooling + the small MLP head stay PyTorch modules (0.3-0.7 M
+parameters, negligible time; 8(f) rank 2 is the "next" row that fuses them).  The resnet branches of the
+reference need torchvision and are outside the hot path: they raise."""
+import torch.nn as nn
+
+from .mnasnet import Mnasnet
+
+
+def load_model(arch="resnet18", pretrained=True):
+    if arch.startswith("mnasnet"):
+        model = Mnasnet(cut_channels_first=False)       # classifiers.py:13 (pretrained is ignored there too)
+        print("Mnasnet initialized")
+        return model
+    raise ValueError("Finetuning not supported on this architecture yet")   # resnet*: torchvision, out of scope
+
+
+class FineTuneModelPool(nn.Module):
+    def __init__(self, original_model, arch, num_classes, classifier_config):
+        super().__init__()
+        self.num_classes = num_classes
+        if not arch.startswith("mnasnet"):
+            raise ValueError("Finetuning not supported on this architecture yet")
+        self.features = original_model.features          # classifiers.py:47 (re-parented, same object)
+        final_feature_map = 320                          # classifiers.py:48
+        self.pooling = nn.Sequential(nn.AdaptiveAvgPool2d(1))
+        self.modelName = "mnasnet"
+        if classifier_config == "256":
+            self.classifier = nn.Sequential(nn.Dropout(), nn.Linear(final_feature_map, 256), nn.ReLU(inplace=True),
+                                            nn.Dropout(), nn.Linear(256, num_classes))
+        elif classifier_config == "512_256":
+            self.classifier = nn.Sequential(nn.Dropout(), nn.Linear(final_feature_map, 512), nn.ReLU(inplace=True),
+                                            nn.Dropout(), nn.Linear(512, 256), nn.ReLU(inplace=True), nn.Dropout(),
+                                            nn.Linear(256, num_classes))
+        elif classifier_config == "320":
+            self.classifier = nn.Sequential(nn.Dropout(p=0.2, inplace=True), nn.Linear(final_feature_map, num_classes))
+        elif classifier_config == "512":
+            self.classifier = nn.Sequential(nn.Dropout(), nn.Linear(final_feature_map, 512), nn.ReLU(inplace=True),
+                                            nn.Dropout(), nn.Linear(512, num_classes))
+        else:
+            raise ValueError("Finetuning not supported on this architecture yet")
+        self.mean = (0.485, 0.456, 0.406)
+        self.std = (0.229, 0.224, 0.225)
+
+    def freeze(self):
+        print("Features frozen")
+        for p in self.features.parameters():
+            p.requires_grad = False
+
+    def unfreeze(self):
+        print("Features unfrozen")
+        for p in self.features.parameters():
+            p.requires_grad = True
+
+    def forward(self, x):
+        f = self.features(x)
+        f = self.pooling(f)
+        return self.classifier(f.view(f.size(0), -1))

@@ -1,0 +1,538 @@
+"""Execution engine: compiles a subtree of the drop-in modules (mnasnet.py) into a static PROGRAM of HIP
+kernel launches (include/mnas.h) per (batch, height, width, mode) and runs it with ONE host->library call
+per forward / per backward segment (mnas_run_ops).
+
+Mirrors, for this path, what autograd + ATen do for the reference:
+    forward   Mnasnet.features(x)                /root/reference/src/models/mnasnet.py:211-213
+    backward  loss.backward() through it          /root/reference/src/train.py:439
+but MI355X-first: NHWC bf16 activations resident in HBM (nothing is recomputed: 288 GB), BatchNorm+ReLU
+fused into the consumers' loads, BatchNorm statistics fused into the producers' epilogues, all buffers
+allocated once per shape, no Python per-layer dispatch on the step path.
+
+Autograd contract: parameters are inputs of one autograd.Function, so loss.backward() reaches
+us; weight/BN gradients are written by the kernels straight into a flat fp32 buffer whose slices ARE the
+parameters' ``.grad`` (None -> attached, already ours -> accumulated, foreign tensor -> added into it), the
+same observable behaviour as autograd's AccumulateGrad, without ~110 tiny copy kernels.  Shared blocks
+accumulate their ``layers`` contributions; ``conv.bias.grad`` is exactly zero (train-mode BatchNorm cancels
+the bias; the reference gets ~1e-5 rounding noise there).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+_STATS_PARTS = 1024          # persistent pixel-workgroups for conv kernels / rows of the stats scratch
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+class _ConvInfo:
+    """One unique ConvBlock (shared blocks appear once)."""
+
+    def __init__(self, mod, stage):
+        conv, bn = mod.conv, mod.bn
+        self.mod, self.stage = mod, stage
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.k = conv.kernel_size[0]
+        self.stride, self.pad, self.groups = conv.stride[0], conv.padding[0], conv.groups
+        if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1]:
+            raise NotImplementedError("square kernels / strides only")
+        if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+            raise NotImplementedError("BatchNorm2d(affine, track_running_stats, momentum=float) only")
+        if self.groups == 1 and self.k == 1:
+            if self.stride != 1 or self.pad != 0:
+                raise NotImplementedError("1x1 convs are stride 1 / pad 0 in this network")
+            self.kind = "pw"
+        elif self.groups == self.cin == self.cout and self.groups > 1:
+            if self.k not in (3, 5) or self.stride != 1 or self.pad != self.k // 2:
+                raise NotImplementedError("depthwise: k in {3,5}, stride 1, pad k//2 (mnasnet.py:122-125)")
+            self.kind = "dw"
+        elif self.groups == 1 and self.k == 3 and self.pad == 1 and self.cin == 3 and self.stride == 2:
+            self.kind = "stem"
+        elif self.groups == 1 and self.k == 3 and self.pad == 1:
+            self.kind = "dense"
+        else:
+            raise NotImplementedError("unsupported ConvBlock geometry")
+        if self.kind != "stem" and (self.cin % 8 or self.cout % 8):
+            raise NotImplementedError("channel counts must be multiples of 8")
+        self.params = [conv.weight, conv.bias, bn.weight, bn.bias]
+        self.gslice = {}            # name -> (offset, numel) in the flat grad buffer
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1)
+
+
+def _trace(root):
+    """Flatten a module subtree into steps: ("conv", ConvBlock, stage) / ("block", [e,d,p], stage)."""
+    steps = []
+
+    def rec(m, stage):
+        name = type(m).__name__
+        if name == "ConvBlock":
+            steps.append(("conv", m, stage))
+        elif name == "MBConv_block":
+            steps.append(("block", list(m.sequence), stage))
+        elif name in ("SepConv", "MBConv"):
+            for c in m.sequence:
+                rec(c, stage)
+        elif name == "Mnasnet":
+            rec(m.features, stage)
+        elif isinstance(m, nn.Sequential):
+            for i, c in enumerate(m):
+                rec(c, i if stage is None else stage)
+        else:
+            raise TypeError("cannot compile %s for the HIP engine" % name)
+
+    rec(root, None)
+    return [(op, m, 0 if st is None else st) for op, m, st in steps]
+
+
+class _Act:
+    """A (possibly virtual) activation: value = relu(scale*data+shift) if bn is not None else data."""
+    __slots__ = ("data", "bn", "H", "W", "C")
+
+    def __init__(self, data, bn, H, W, C_):
+        self.data, self.bn, self.H, self.W, self.C = data, bn, H, W, C_
+
+    def act_ptrs(self):
+        if self.bn is None:
+            return [self.data.data_ptr(), None, None]
+        return [self.data.data_ptr(), self.bn.data_ptr(), self.bn.data_ptr() + 4 * self.C]
+
+
+class _OpList:
+    def __init__(self):
+        self.items = []
+
+    def add(self, opcode, ints=(), dbls=(), ptrs=()):
+        self.items.append((opcode, list(ints), list(dbls), list(ptrs)))
+        return len(self.items) - 1
+
+    def build(self):
+        arr = (L.MnasOp * max(1, len(self.items)))()
+        for n, (opc, ints, dbls, ptrs) in enumerate(self.items):
+            o = arr[n]
+            o.opcode = opc
+            for j, v in enumerate(ints):
+                o.i[j] = int(v)
+            for j, v in enumerate(dbls):
+                o.d[j] = float(v)
+            for j, v in enumerate(ptrs):
+                o.p[j] = v if v else None
+        return arr, len(self.items)
+
+
+class Program:
+    """All buffers + launch lists for one (N, H, W, training, need_dx) configuration."""
+
+    def __init__(self, eng: "Engine", N, H, W, training, need_dx):
+        self.eng, self.N, self.H, self.W, self.training, self.need_dx = eng, N, H, W, training, need_dx
+        self.busy = False
+        dev = eng.device
+        self.keep = []                      # tensors owned by this program
+        lib = eng.lib
+
+        def new(shape, dtype=torch.bfloat16):
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            self.keep.append(t)
+            return t
+
+        def bnbuf(C_):
+            t = torch.zeros((L_BN_ROWS, C_), dtype=torch.float32, device=dev)
+            self.keep.append(t)
+            return t
+
+        fwd = _OpList()
+        # ---- weight packing (once per forward; weights change every optimizer step)
+        for ci in eng.convs:
+            w = ci.mod.conv.weight
+            if ci.kind in ("pw", "dense"):
+                fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_FWD, ci.cout, ci.cin, ci.k, ci.k], [], [w.data_ptr(), ci.w_fwd.data_ptr()])
+                if training:
+                    fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_DGRAD, ci.cout, ci.cin, ci.k, ci.k], [],
+                            [w.data_ptr(), ci.w_dgrad.data_ptr()])
+            elif ci.kind == "dw":
+                fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_DW, ci.cout, 1, ci.k, ci.k], [], [w.data_ptr(), ci.w_fwd.data_ptr()])
+            else:  # stem: [Co][27] viewed as a 1x1 conv over 27 "channels"
+                fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_FWD, ci.cout, 27, 1, 1], [], [w.data_ptr(), ci.w_fwd.data_ptr()])
+
+        steps = eng.steps
+        first_kind = eng.info[id(steps[0][1] if steps[0][0] == "conv" else steps[0][1][0])].kind
+        self.x_is_image = first_kind == "stem"
+        self.patch_x = []       # (op index, pointer slot) receiving the input pointer
+        records = []            # forward applications, for the backward builder
+        Hc, Wc = H, W
+        if self.x_is_image:
+            cur = None          # the stem reads the fp32 NCHW input directly
+        else:
+            Cin = eng.info[id(steps[0][1] if steps[0][0] == "conv" else steps[0][1][0])].cin
+            xb = new((N, H, W, Cin))
+            j = fwd.add(L.OP_NCHW_TO_NHWC, [N, Cin, H * W], [], [None, xb.data_ptr()])
+            self.patch_x.append((j, 0))
+            cur = _Act(xb, None, H, W, Cin)
+        self.in_channels = 3 if self.x_is_image else cur.C
+
+        def conv_fwd(ci: _ConvInfo, a_in: Optional[_Act], Hi, Wi):
+            Ho, Wo = ci.out_hw(Hi, Wi)
+            M = N * Ho * Wo
+            y = new((N, Ho, Wo, ci.cout))
+            bn = bnbuf(ci.cout)
+            conv, bnm = ci.mod.conv, ci.mod.bn
+            bias = conv.bias.data_ptr() if conv.bias is not None else None
+            nparts = max(1, min(_STATS_PARTS, _cdiv(M, 128)))
+            stats = eng.scratch_stats.data_ptr() if training else None
+            if ci.kind == "stem":
+                j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts], [],
+                            [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
+                self.patch_x.append((j, 0))
+            elif ci.kind == "dw":
+                nparts = max(1, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 4)))
+                fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nparts], [],
+                        a_in.act_ptrs() + [ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
+            else:
+                fwd.add(L.OP_CONV_GEMM, [0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
+                        a_in.act_ptrs() + [None, None, None, ci.w_fwd.data_ptr(), bias, None, y.data_ptr(), stats])
+            fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, ci.cout, 1 if training else 0], [float(M), bnm.momentum, bnm.eps],
+                    [stats, bnm.weight.data_ptr(), bnm.bias.data_ptr(), bnm.running_mean.data_ptr(),
+                     bnm.running_var.data_ptr(), bnm.num_batches_tracked.data_ptr(), bn.data_ptr()])
+            out = _Act(y, bn, Ho, Wo, ci.cout)
+            records.append(("conv", ci, a_in, out, Hi, Wi))
+            return out
+
+        step_records = []
+        for op, m, stage in steps:
+            start = len(records)
+            if op == "conv":
+                ci = eng.info[id(m)]
+                cur = conv_fwd(ci, cur, Hc, Wc)
+                Hc, Wc = cur.H, cur.W
+                step_records.append(("conv", stage, start, None, None))
+            else:
+                a_in = cur
+                h = cur
+                for cb in m:
+                    h = conv_fwd(eng.info[id(cb)], h, Hc, Wc)
+                r = new((N, Hc, Wc, a_in.C))
+                fwd.add(L.OP_ADD_ACT, [a_in.C, Hc * Wc], [float(N * Hc * Wc)],
+                        a_in.act_ptrs() + h.act_ptrs() + [r.data_ptr(), None])
+                cur = _Act(r, None, Hc, Wc, a_in.C)
+                step_records.append(("block", stage, start, a_in, cur))
+        # ---- features output: fp32 NCHW (classifiers.py:109 consumes it)
+        self.out_shape = (N, cur.C, cur.H, cur.W)
+        j = fwd.add(L.OP_ADD_ACT, [cur.C, cur.H * cur.W], [float(N * cur.H * cur.W)],
+                    cur.act_ptrs() + [None, None, None, None, None])
+        self.patch_out = (j, 7)
+        self.fwd_ops, self.fwd_n = fwd.build()
+        self.final = cur
+
+        # ---- backward ------------------------------------------------------------------------------
+        self.bwd_segments = []      # [(stage, ops, n)]
+        self.patch_gout = None
+        self.patch_dx = None
+        if not training:
+            return
+        seg_ops: Dict[int, _OpList] = {}
+        order: List[int] = []
+
+        def seg(stage):
+            if stage not in seg_ops:
+                seg_ops[stage] = _OpList()
+                order.append(stage)
+            return seg_ops[stage]
+
+        last_stage = step_records[-1][1]
+        g_final = new((N, cur.H, cur.W, cur.C))
+        j = seg(last_stage).add(L.OP_NCHW_TO_NHWC, [N, cur.C, cur.H * cur.W], [], [None, g_final.data_ptr()])
+        self.patch_gout = (last_stage, j, 0)
+
+        def conv_bwd(ops: _OpList, rec, g, resid, need_gin):
+            """Backward of one ConvBlock application.  g: bf16 grad wrt its activated output.  Returns the
+            bf16 grad wrt its (activated) input, or None."""
+            _, ci, a_in, out, Hi, Wi = rec
+            Ho, Wo, Co = out.H, out.W, ci.cout
+            M = N * Ho * Wo
+            bnm = ci.mod.bn
+            gy = [g.data_ptr(), out.data.data_ptr(), out.bn.data_ptr()]
+            nred = max(1, min(_STATS_PARTS, _cdiv(M * Co, 256 * 8 * 8)))
+            ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), eng.scratch_stats.data_ptr()])
+            ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
+                    [eng.scratch_stats.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
+            gin = None
+            if ci.kind == "stem":
+                nsp = max(1, min(512, _cdiv(M, 1024)))
+                ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()])
+                self.patch_x_bwd = (ops, len(ops.items) - 1, 0)
+                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
+            elif ci.kind == "dw":
+                nparts = max(1, min(512, _cdiv(M * Co, 256 * 16 * 8)))
+                gin = new((N, Hi, Wi, ci.cin))
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts], [],
+                        a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()])
+                ops.add(L.OP_DW_WGRAD_FINALIZE, [nparts, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
+            else:
+                K = ci.k * ci.k * ci.cin
+                slabs = _cdiv(Co, 64) * _cdiv(K, 64)
+                nsp = max(1, min(_cdiv(1024, slabs), _cdiv(M, 256)))
+                ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
+                        a_in.act_ptrs() + gy + [eng.scratch_wgrad.data_ptr()])
+                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
+                if need_gin:
+                    gin = new((N, Hi, Wi, ci.cin))
+                    Min = N * Hi * Wi
+                    nparts = max(1, min(_STATS_PARTS, _cdiv(Min, 128)))
+                    ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
+                            [None, None, None] + gy + [ci.w_dgrad.data_ptr(), None,
+                                                       resid.data_ptr() if resid is not None else None,
+                                                       gin.data_ptr(), None])
+            if ci.kind == "dw" and resid is not None:
+                raise AssertionError("residual add into a depthwise dgrad does not occur")
+            return gin
+
+        g = g_final
+        self.patch_x_bwd = None
+        for si in range(len(step_records) - 1, -1, -1):
+            kind, stage, start, a_in, a_out = step_records[si]
+            ops = seg(stage)
+            first = si == 0
+            if kind == "conv":
+                rec = records[start]
+                need = (not first) or (need_dx and not self.x_is_image)
+                g = conv_bwd(ops, rec, g, None, need)
+            else:
+                re_, rd, rp = records[start], records[start + 1], records[start + 2]
+                G = g                                   # grad wrt the block output (materialised sum)
+                g2 = conv_bwd(ops, rp, G, None, True)
+                g1 = conv_bwd(ops, rd, g2, None, True)
+                need = (not first) or need_dx
+                if need:
+                    g = conv_bwd(ops, re_, g1, G, True)   # + skip-connection gradient fused in the epilogue
+                else:
+                    conv_bwd(ops, re_, g1, None, False)
+                    g = None
+        if need_dx and not self.x_is_image:
+            Cin = self.in_channels
+            j = seg(step_records[0][1]).add(L.OP_ADD_ACT, [Cin, H * W], [float(N * H * W)],
+                                            [g.data_ptr(), None, None, None, None, None, None, None])
+            self.patch_dx = (step_records[0][1], j, 7)
+        built = {}
+        for st in order:
+            built[st] = seg_ops[st].build()
+        self.bwd_segments = [(st,) + built[st] for st in order]
+        self._seg_index = {st: n for n, st in enumerate(order)}
+        if self.patch_x_bwd is not None:
+            ops_obj, idx, slot = self.patch_x_bwd
+            st = [s for s in order if seg_ops[s] is ops_obj][0]
+            self.patch_x_bwd = (st, idx, slot)
+
+    # ------------------------------------------------------------------------------------------
+    def _run(self, arr, n, what):
+        failed = C.c_int(-1)
+        rc = self.eng.lib.mnas_run_ops(arr, n, L.cur_stream(), C.byref(failed))
+        if rc != 0:
+            raise RuntimeError("%s: mnas_run_ops failed with code %d at op %d (opcode %d)" %
+                               (what, rc, failed.value, arr[failed.value].opcode if failed.value >= 0 else -1))
+
+    def run_forward(self, x):
+        out = torch.empty(self.out_shape, dtype=torch.float32, device=x.device)
+        for j, slot in self.patch_x:
+            self.fwd_ops[j].p[slot] = x.data_ptr()
+        j, slot = self.patch_out
+        self.fwd_ops[j].p[slot] = out.data_ptr()
+        self.x_ref = x
+        self._run(self.fwd_ops, self.fwd_n, "forward")
+        return out
+
+    def run_backward(self, gout, on_stage_done: Optional[Callable[[int], None]] = None):
+        segs = {st: (arr, n) for st, arr, n in self.bwd_segments}
+        st, j, slot = self.patch_gout
+        segs[st][0][j].p[slot] = gout.data_ptr()
+        if self.patch_x_bwd is not None:
+            st, j, slot = self.patch_x_bwd
+            segs[st][0][j].p[slot] = self.x_ref.data_ptr()
+        dx = None
+        if self.patch_dx is not None:
+            dx = torch.empty((self.N, self.in_channels, self.H, self.W), dtype=torch.float32, device=gout.device)
+            st, j, slot = self.patch_dx
+            segs[st][0][j].p[slot] = dx.data_ptr()
+        for st, arr, n in self.bwd_segments:
+            self._run(arr, n, "backward[stage %d]" % st)
+            if on_stage_done is not None:
+                on_stage_done(st)
+        self.x_ref = None
+        return dx
+
+
+L_BN_ROWS = 8
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, track, x, *params):
+        need_dx = track and x.requires_grad
+        training = eng.root.training
+        prog = eng.program(x.shape[0], x.shape[2], x.shape[3], training, need_dx)
+        out = prog.run_forward(x)
+        if training and track:
+            prog.busy = True
+            ctx.prog = prog
+            ctx.eng = eng
+        else:
+            ctx.prog = None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        prog, eng = ctx.prog, ctx.eng
+        if prog is None:
+            raise RuntimeError("backward through an eval-mode / no-grad engine forward")
+        try:
+            accumulate = eng.prepare_grads()
+            dx = prog.run_backward(gout.contiguous().float(), eng.on_stage_done)
+            eng.finish_grads(accumulate)
+        finally:
+            prog.busy = False
+        return (None, None, dx) + (None,) * len(eng.params)
+
+
+class Engine:
+    """Owns the packed weights, scratch space, flat gradient buffer and per-shape programs of one module
+    subtree."""
+
+    def __init__(self, root: nn.Module):
+        self.root = root
+        self.steps = _trace(root)
+        self.lib = None
+        self.device = None
+        self.programs: Dict[tuple, List[Program]] = {}
+        self.on_stage_done: Optional[Callable[[int], None]] = None
+        # unique ConvBlocks in first-use order
+        self.info: Dict[int, _ConvInfo] = {}
+        self.convs: List[_ConvInfo] = []
+        for op, m, stage in self.steps:
+            for cb in ([m] if op == "conv" else m):
+                if id(cb) not in self.info:
+                    ci = _ConvInfo(cb, stage)
+                    self.info[id(cb)] = ci
+                    self.convs.append(ci)
+        for n, (op, m, stage) in enumerate(self.steps):
+            for cb in ([m] if op == "conv" else m):
+                if self.info[id(cb)].kind == "stem" and n != 0:
+                    raise NotImplementedError("a 3-channel stride-2 conv is only supported as the first layer")
+        # flat gradient layout: later stages first (their gradients are complete first in backward)
+        self.params: List[nn.Parameter] = []
+        off = 0
+        self.stage_ranges: Dict[int, List[int]] = {}
+        for ci in sorted(self.convs, key=lambda c: -c.stage):
+            a = off
+            for j, p in enumerate(ci.params):
+                ci.gslice[j] = (off, p.numel())
+                off += p.numel()
+                self.params.append(p)
+            r = self.stage_ranges.setdefault(ci.stage, [a, off])
+            r[0], r[1] = min(r[0], a), max(r[1], off)
+        self.grad_numel = off
+        self._sig = None
+
+    # ---- device state ---------------------------------------------------------------------------
+    def _signature(self):
+        sig = [p.data_ptr() for p in self.params]
+        for ci in self.convs:
+            bn = ci.mod.bn
+            sig += [bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()]
+        return tuple(sig)
+
+    def _setup(self, device):
+        self.lib = L.load()
+        self.device = device
+        self.programs.clear()
+        nbytes = self.lib.mnas_packed_bytes
+        smax, wmax = 0, 0
+        for ci in self.convs:
+            if ci.kind in ("pw", "dense"):
+                ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
+                ci.w_dgrad = torch.empty(nbytes(L.PACK_DGRAD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
+                K = ci.k * ci.k * ci.cin
+                slabs = _cdiv(ci.cout, 64) * _cdiv(K, 64)
+                wmax = max(wmax, max(1, _cdiv(1024, slabs)) * ci.cout * K)
+            elif ci.kind == "dw":
+                ci.w_fwd = torch.empty(nbytes(L.PACK_DW, ci.cout, 1, ci.k, ci.k), dtype=torch.uint8, device=device)
+                wmax = max(wmax, 512 * ci.k * ci.k * ci.cout)
+            else:
+                ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, 27, 1, 1), dtype=torch.uint8, device=device)
+                wmax = max(wmax, 512 * ci.cout * 27)
+            smax = max(smax, ci.cout)
+        self.scratch_stats = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)
+        self.scratch_wgrad = torch.empty(wmax, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(self.grad_numel, dtype=torch.float32, device=device)
+        self.grad_views = []
+        for ci in sorted(self.convs, key=lambda c: -c.stage):
+            for j, p in enumerate(ci.params):
+                o, n = ci.gslice[j]
+                self.grad_views.append(self.flat_grad[o:o + n].view(p.shape))
+
+    def gptr(self, ci: _ConvInfo, j: int):
+        return self.flat_grad.data_ptr() + 4 * ci.gslice[j][0]
+
+    def program(self, N, H, W, training, need_dx) -> Program:
+        key = (N, H, W, training, need_dx)
+        lst = self.programs.setdefault(key, [])
+        for p in lst:
+            if not p.busy:
+                return p
+        p = Program(self, N, H, W, training, need_dx)
+        lst.append(p)
+        return p
+
+    # ---- .grad bookkeeping (AccumulateGrad semantics on a flat buffer) -----------------------------
+    def prepare_grads(self):
+        """Returns True if every live .grad is already one of our views (accumulate in place)."""
+        ours, other = 0, 0
+        for p, v in zip(self.params, self.grad_views):
+            if not p.requires_grad:
+                continue
+            if p.grad is not None and p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape:
+                ours += 1
+            else:
+                other += 1
+        if ours and other:       # mixed: zero the slices that are not live accumulators, then accumulate
+            for p, v in zip(self.params, self.grad_views):
+                if not (p.grad is not None and p.grad.data_ptr() == v.data_ptr()):
+                    v.zero_()
+            return True
+        if ours:
+            return True
+        self.flat_grad.zero_()
+        return False
+
+    def finish_grads(self, accumulate):
+        for p, v in zip(self.params, self.grad_views):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                p.grad.add_(v)          # a foreign .grad tensor: add into it, like AccumulateGrad
+
+    # ---- entry point ------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("mnasnet_pytorch_amd runs on MI355X only: got a %s tensor; there is no CPU/eager "
+                               "fallback (use oracle/ in tests for a CPU reference)" % x.device)
+        if x.dim() != 4:
+            raise ValueError("expected NCHW input")
+        if any(p.device != x.device for p in self.params):
+            raise RuntimeError("module parameters and input are on different devices")
+        x = x.float().contiguous()          # train.py:427 input.float()
+        sig = self._signature()
+        if self.lib is None or self.device != x.device or sig != self._sig:
+            self._setup(x.device)
+            self._sig = sig
+        track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params))
+        return _EngineFn.apply(self, track, x, *self.params)

@@ -112,9 +112,9 @@ def gen_stages():
 
 def gen_nets():
     out = {}
-    for name, (ccf, N, H, W, train) in C.NETS.items():
+    for name, (ccf, N, H, W, train, pg) in C.NETS.items():
         m = R.Mnasnet(cut_channels_first=ccf)
-        m.load_state_dict(O.init_state(ccf, C.STATE_SEED))
+        m.load_state_dict(O.init_state(ccf, C.STATE_SEED, proj_gamma=pg))
         m.train(train)
         x = C.det_input((N, 3, H, W))
         if train:

@@ -1,0 +1,252 @@
+"""-m gpu: the drop-in modules (mnasnet_pytorch_amd, HIP engine) against
+  (a) oracle/bf16_mirror.py -- the reference's arithmetic with bf16 rounding at the HIP path's storage points:
+      TIGHT bound: relative L2 <= 2e-3 per tensor for one ConvBlock (measured <= 2e-4: the engine is
+      bit-for-bit the mirror up to fp32 summation order), <= 3e-2 for blocks/stages (a 1-ulp bf16 difference
+      in y moves the heavily cancelling sum dgamma = sum dz*xhat by ~2 %), whole networks: outputs <= 3e-2,
+      gradients by cosine similarity (min >= 0.8, median >= 0.95) because the 57-layer backward amplifies
+      those 1-ulp differences (measured median relative L2 0.18) -- this pins the engine's wiring;
+  (b) the golden fixtures captured from the fp32 reference: LOOSE bound, because bf16 storage legitimately
+      costs a few % at these tiny batch sizes (ReLU-mask flips; see tests/test_bf16_mirror.py, which holds
+      the mirror itself to the same goldens on CPU):
+         one ConvBlock   y <= 1e-2, gradients <= 8e-2         MBConv_block / stage   y <= 4e-2, gradients <= 0.2
+         whole network, well-conditioned state (gain ~5)      y <= 8e-2
+         whole network, default state (gain ~110, measured)   y <= 0.7  (sanity only; any bf16 pipeline is here)
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+from cases import O
+from oracle import bf16_mirror as M
+from test_oracle_golden import block_state, prim_state
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-3      # one ConvBlock
+TIGHT_BLK = 3e-2  # blocks / stages
+
+
+def rl2(a, b):
+    a = torch.as_tensor(np.asarray(a)).double().flatten()
+    b = torch.as_tensor(np.asarray(b)).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load(name):
+    return np.load("%s/%s.npz" % (C.GOLDEN_DIR, name))
+
+
+def fill(module, prefix, seed=C.STATE_SEED):
+    """Same closed-form fill as the golden generator (first alias names the value)."""
+    sd = module.state_dict()
+    new, first = {}, {}
+    for k, v in sd.items():
+        src = first.setdefault(v.data_ptr(), k) if v.dim() > 0 else k
+        new[k] = O.det_param(prefix + "." + src, tuple(v.shape), seed).to(v.dtype)
+    module.load_state_dict(new)
+
+
+def check_grads(module, mirror_grads, prefix_map, tol, gold=None, gold_prefix=None, gold_tol=None):
+    worst = 0.0
+    for kk, p in module.named_parameters():
+        ref = mirror_grads[prefix_map(kk)]
+        if kk.endswith("conv.bias"):
+            assert p.grad is not None and float(p.grad.abs().max()) < 1e-4
+            continue
+        e = rl2(p.grad.cpu(), ref)
+        worst = max(worst, e)
+        # dgamma = sum dz*xhat cancels heavily: a 1-ulp bf16 difference in one y moves it by a few %
+        assert e < (max(tol, 0.1) if kk.endswith("bn.weight") and tol > TIGHT else tol), (kk, e)
+        if gold is not None:
+            assert rl2(p.grad.cpu(), gold[gold_prefix + kk]) < gold_tol, kk
+    return worst
+
+
+@pytest.mark.parametrize("name", sorted(C.PRIMITIVES))
+@pytest.mark.parametrize("train", [True, False])
+def test_convblock(name, train):
+    from mnasnet_pytorch_amd import ConvBlock
+    g = load("primitives")
+    cin, cout, k, s, p, grp, N, H, W = C.PRIMITIVES[name]
+    m = ConvBlock(cin, cout, kernel_size=k, stride=s, padding=p, groups=grp)
+    fill(m, name)
+    m = m.cuda().train(train)
+    x0 = C.det_input((N, cin, H, W))
+    x = x0.cuda().requires_grad_(cin != 3)
+    y = m(x)
+    tag = name + ("/train" if train else "/eval")
+    assert y.shape == g[tag + "/y"].shape and y.dtype == torch.float32
+    spec = O.ConvSpec("cb", cin, cout, k, s, p, grp)
+    st = prim_state(name, spec)
+    cot = C.cotangent(tuple(y.shape))
+    r = M.run([("conv", spec)], st, x0, train=train, cot=cot if train else None, need_dx=True)
+    assert rl2(y.detach().cpu(), r["y"]) < TIGHT
+    assert rl2(y.detach().cpu(), g[tag + "/y"]) < 1e-2
+    if not train:
+        return
+    (y * cot.cuda()).sum().backward()
+    if cin != 3:
+        assert rl2(x.grad.cpu(), r["dx"]) < TIGHT
+        assert rl2(x.grad.cpu(), g[tag + "/dx"]) < 8e-2
+    check_grads(m, r["grads"], lambda kk: "cb." + kk, TIGHT, g, tag + "/d_", 8e-2)
+    assert rl2(m.bn.running_mean.cpu(), g[tag + "/bn.running_mean"]) < 1e-2
+    assert rl2(m.bn.running_var.cpu(), g[tag + "/bn.running_var"]) < 1e-2
+    assert int(m.bn.num_batches_tracked) == int(g[tag + "/bn.num_batches_tracked"])
+
+
+@pytest.mark.parametrize("name", sorted(C.BLOCKS))
+def test_block(name):
+    from mnasnet_pytorch_amd import MBConv_block
+    g = load("blocks")
+    c, t, k, N, H, W = C.BLOCKS[name]
+    m = MBConv_block(c, t, k)
+    fill(m, name)
+    m = m.cuda().train()
+    x0 = C.det_input((N, c, H, W))
+    x = x0.cuda().requires_grad_(True)
+    y = m(x)
+    cot = C.cotangent(tuple(y.shape))
+    (y * cot.cuda()).sum().backward()
+    specs = O._block_specs("blk", c, t, k)
+    st = block_state(name, specs)
+    r = M.run([("block", specs)], st, x0, True, cot, need_dx=True)
+    assert rl2(y.detach().cpu(), r["y"]) < TIGHT_BLK
+    assert rl2(x.grad.cpu(), r["dx"]) < TIGHT_BLK
+    assert rl2(y.detach().cpu(), g[name + "/y"]) < 4e-2
+    assert rl2(x.grad.cpu(), g[name + "/dx"]) < 0.3
+    check_grads(m, r["grads"], lambda kk: "blk." + kk, TIGHT_BLK, g, name + "/d_", 0.3)
+    for kk, v in m.state_dict().items():
+        if "running" in kk:
+            assert rl2(v.cpu(), g[name + "/" + kk]) < 2e-2, kk
+
+
+@pytest.mark.parametrize("name", sorted(C.STAGES))
+def test_stage(name):
+    from mnasnet_pytorch_amd import MBConv
+    g = load("stages")
+    cin, cout, t, layers, k, reduce, ccf, N, H, W = C.STAGES[name]
+    m = MBConv(cin, cout, t, layers, kernel_size=k, reduce=reduce, cut_channels_first=ccf)
+    fill(m, name)
+    m = m.cuda().train()
+    x0 = C.det_input((N, cin, H, W))
+    x = x0.cuda().requires_grad_(True)
+    y = m(x)
+    cot = C.cotangent(tuple(y.shape))
+    (y * cot.cuda()).sum().backward()
+    # mirror program for the stand-alone stage (mnasnet.py:139-173)
+    stride = 2 if reduce else 1
+    bc = cout if ccf else cin
+    conv = O.ConvSpec("sequence.%d" % (0 if ccf else layers), cin, cout, 3, stride, 1, 1)
+    blk = O._block_specs("sequence.%d" % (1 if ccf else 0), bc, t, k)
+    st = {}
+    for s_ in [conv] + blk:
+        for suf, shp in (("conv.weight", s_.weight_shape()), ("conv.bias", (s_.cout,)), ("bn.weight", (s_.cout,)),
+                         ("bn.bias", (s_.cout,)), ("bn.running_mean", (s_.cout,)), ("bn.running_var", (s_.cout,))):
+            st[s_.prefix + "." + suf] = O.det_param("%s.%s.%s" % (name, s_.prefix, suf), shp, C.STATE_SEED)
+        st[s_.prefix + ".bn.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    prog = ([("conv", conv)] if ccf else []) + [("block", blk)] * layers + ([] if ccf else [("conv", conv)])
+    r = M.run(prog, st, x0, True, cot, need_dx=True)
+    assert rl2(y.detach().cpu(), r["y"]) < TIGHT_BLK
+    assert rl2(x.grad.cpu(), r["dx"]) < TIGHT_BLK
+    assert rl2(y.detach().cpu(), g[name + "/y"]) < 4e-2
+    assert rl2(x.grad.cpu(), g[name + "/dx"]) < 0.3
+    # shared block: grads are the SUM over its `layers` applications
+    check_grads(m, r["grads"], lambda kk: kk, TIGHT_BLK, g, name + "/d_", 0.3)
+    sd = m.state_dict()
+    for kk in g.files:
+        if kk.startswith(name + "/") and "tracked" in kk:
+            assert int(sd[kk[len(name) + 1:]]) == int(g[kk]), kk       # 3 updates per forward for the shared block
+        if kk.startswith(name + "/") and "running" in kk:
+            assert rl2(sd[kk[len(name) + 1:]].cpu(), g[kk]) < 4e-2, kk
+
+
+@pytest.mark.parametrize("name", sorted(C.NETS))
+def test_net(name):
+    from mnasnet_pytorch_amd import Mnasnet
+    g = load("nets")
+    ccf, N, H, W, train, pg = C.NETS[name]
+    m = Mnasnet(cut_channels_first=ccf)
+    assert list(m.state_dict().keys()) == O.state_keys(ccf)
+    m.load_state_dict(O.init_state(ccf, C.STATE_SEED, proj_gamma=pg))
+    m = m.cuda().train(train)
+    x0 = C.det_input((N, 3, H, W))
+    x = x0.cuda()
+    prog, _ = O.build_program(ccf)
+    st = O.init_state(ccf, C.STATE_SEED, proj_gamma=pg)
+    gold_tol = 8e-2 if pg != 1.0 else 0.7
+    if not train:
+        with torch.no_grad():
+            y = m(x)
+        r = M.run(prog, st, x0, False)
+        assert rl2(y.cpu(), r["y"]) < 2e-2
+        assert rl2(y.cpu(), g[name + "/y"]) < 0.1        # eval mode: running statistics, no batch-stat feedback
+        return
+    y = m(x)
+    cot = C.cotangent(tuple(y.shape))
+    (y * cot.cuda()).sum().backward()
+    r = M.run(prog, st, x0, True, cot)
+    e_m, e_g = rl2(y.detach().cpu(), r["y"]), rl2(y.detach().cpu(), g[name + "/y"])
+    print(name, "y vs mirror", e_m, "vs fp32 golden", e_g)
+    assert e_g < gold_tol
+    if pg == 1.0:
+        return              # default state: gain ~110, only the sanity bound above is meaningful
+    assert e_m < 3e-2
+    coss = []
+    for kk, p in m.named_parameters():
+        if kk.endswith("conv.bias"):
+            assert p.grad is not None
+            continue
+        a, b = p.grad.double().flatten().cpu(), r["grads"][kk].double().flatten()
+        coss.append(float((a @ b) / (a.norm() * b.norm() + 1e-30)))
+        assert 0.5 < float(a.norm() / b.norm()) < 2.0, kk
+    print(name, "grad cosine vs mirror: min %.4f median %.4f" % (min(coss), float(np.median(coss))))
+    assert min(coss) > 0.8 and np.median(coss) > 0.95
+    cg = []
+    for kk, p in m.named_parameters():
+        if (name + "/g/" + kk) in g.files and not kk.endswith("conv.bias"):
+            a, b = p.grad.double().flatten().cpu(), torch.as_tensor(g[name + "/g/" + kk]).double().flatten()
+            cg.append(float((a @ b) / (a.norm() * b.norm() + 1e-30)))
+    print(name, "grad cosine vs fp32 golden: min %.4f median %.4f" % (min(cg), float(np.median(cg))))
+    assert np.median(cg) > 0.9
+    sd = m.state_dict()
+    for kk in g.files:
+        if kk.startswith(name + "/") and "tracked" in kk:
+            assert int(sd[kk[len(name) + 1:]]) == int(g[kk])
+        if kk.startswith(name + "/ssum/") and pg != 1.0:
+            v = sd[kk[len(name) + 6:]].double()
+            assert abs(float(v.abs().sum()) - g[kk][1]) <= 5e-2 * g[kk][1], kk
+
+
+def test_no_cpu_fallback():
+    from mnasnet_pytorch_amd import Mnasnet
+    m = Mnasnet()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+def test_grad_accumulation_semantics():
+    """.grad behaves like autograd's: None -> set, existing -> accumulated, zero_grad() honoured."""
+    from mnasnet_pytorch_amd import MBConv_block
+    m = MBConv_block(16, 3, 3)
+    fill(m, "block_16_3_3")
+    m = m.cuda().train()
+    x = C.det_input((2, 16, 14, 14)).cuda()
+    m(x).sum().backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m(x).sum().backward()                       # second backward without zero_grad: accumulates
+    for p, a in zip(m.parameters(), g1):
+        if a.abs().max() > 0:
+            assert rl2(p.grad.cpu(), (2 * a).cpu()) < 5e-2
+    m.zero_grad(set_to_none=True)
+    m(x).sum().backward()
+    for p, a in zip(m.parameters(), g1):
+        if a.abs().max() > 0:
+            assert rl2(p.grad.cpu(), a.cpu()) < 5e-2
+    # foreign .grad tensors are added into, like AccumulateGrad does
+    m.zero_grad(set_to_none=True)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    m(x).sum().backward()
+    for p, a in zip(m.parameters(), g1):
+        if a.abs().max() > 0:
+            assert rl2((p.grad - 1).cpu(), a.cpu()) < 5e-2

@@ -158,8 +158,8 @@ def test_stage(name):
 @pytest.mark.parametrize("name", sorted(C.NETS))
 def test_net(name):
     g = load("nets")
-    ccf, N, H, W, train = C.NETS[name]
-    st = O.init_state(ccf, C.STATE_SEED)
+    ccf, N, H, W, train, pg = C.NETS[name]
+    st = O.init_state(ccf, C.STATE_SEED, proj_gamma=pg)
     x = C.det_input((N, 3, H, W))
     if not train:
         with torch.no_grad():
