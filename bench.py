@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the MNASNet train step (src/train.py:423-440 of the reference) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]/[2]): MNASNet-1.0 = Mnasnet(cut_channels_first=False) + FineTuneModelPool
+head '512', num_classes 1000, bs=256 per GPU, synthetic 3x224x224 fp32 batches resident in HBM,
+CrossEntropyLoss, Adam(lr=1e-3), model.train(); one step = forward + backward + gradient all-reduce (N>1) +
+optimizer.  Weak scaling: global batch = 256*N.  Prints ONE JSON line on rank 0.
+
+Extra objects in the JSON line:
+  roofline     -- for the kernel class that takes the most time in the step: algorithmic bytes it must move
+                  (its input and output tensors once, bf16 NHWC) / its launch time measured with
+                  HIP events recorded around every launch of that class inside the timed region.
+  cpu_baseline -- the CPU oracle (oracle/mnasnet_oracle.py, a port of the reference's eager path; the
+                  reference sources do not travel to the GPU box) running the same step at bs=32 on the host
+                  cores, rank 0, N=1 only.  A reported baseline, not the optimisation target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def conv_table(engine, N, H, W):
+    """Per ConvBlock application: (kind, E_in, E_out, macs) at batch N -- the algorithmic accounting of
+    SURVEY 8(d) / Appendix A, derived from the module geometry."""
+    rows = []
+    Hc, Wc = H, W
+    for op, m, stage in engine.steps:
+        for cb in ([m] if op == "conv" else m):
+            ci = engine.info[id(cb)]
+            Ho, Wo = ci.out_hw(Hc, Wc)
+            e_in = N * Hc * Wc * ci.cin
+            e_out = N * Ho * Wo * ci.cout
+            macs = N * Ho * Wo * ci.cout * (ci.cin // ci.groups) * ci.k * ci.k
+            rows.append((ci.kind, ci, (Hc, Wc), e_in, e_out, macs))
+            Hc, Wc = Ho, Wo
+    return rows
+
+
+def cpu_baseline(seconds):
+    """The oracle's train step on the host cores (fp32, bs=32, head '512', Adam) -- kind 'port'."""
+    from oracle import mnasnet_oracle as O
+    threads = os.cpu_count() or 1
+    threads = min(threads, 64)          # oneDNN stops scaling on these tiny convs well before 64 threads
+    torch.set_num_threads(threads)
+    net = O.OracleNet(ccf=False, head="512", num_classes=1000, seed=1).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    bs = 32
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(bs, 3, 224, 224, generator=g)
+    t = torch.randint(0, 1000, (bs,), generator=g)
+    O.train_step(net, opt, x, t)       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(net, opt, x, t)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 20:
+            break
+    return {"value": round(bs * n / el, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d train steps of bs=%d fp32 (same model/head/optimizer, oracle/mnasnet_oracle.py) in %.1f s"
+                      % (n, bs, el)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mnasnet_pytorch_amd import FineTuneModelPool, load_model, _lib as L
+    from mnasnet_pytorch_amd.train_step import Trainer
+
+    torch.manual_seed(0)                       # identical init on every rank (and rank-0 broadcast in Trainer)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        base = load_model("mnasnet")
+    model = FineTuneModelPool(base, "mnasnet", 1000, "512").to(dev).train()
+    trainer = Trainer(model, lr=1e-3, distributed=distributed)
+    eng = trainer.engine
+    profile = (not args.no_roofline) and rank == 0
+    if profile:
+        eng.profile_opcodes = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE,
+                               L.OP_STEM_FWD, L.OP_STEM_WGRAD, L.OP_ADD_ACT}
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    B, S = args.batch, args.size
+    x = torch.randn(B, 3, S, S, device=dev, generator=g)
+    target = torch.randint(0, 1000, (B,), device=dev, generator=g)
+
+    def barrier():
+        if distributed:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x, target)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, target)
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    lossv = float(loss)
+    if rank != 0:
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    res = {
+        "metric": "images/sec MNASNet-1.0 224^2 bf16 train step",
+        "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes) fwd+bwd+Adam, "
+                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (B, S, S),
+                   "global_batch": B * world, "parallelism": "dp%d" % world, "loss": round(lossv, 4)},
+    }
+    # ---- roofline of the dominant kernel class ---------------------------------------------------
+    if profile:
+        names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_fwd", L.OP_DW_BWD: "k_dw_bwd",
+                 L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
+                 L.OP_ADD_ACT: "k_add_act"}
+        agg = {}
+        for (tag, opc, ints), msv in eng.read_profile():
+            key = names[opc] + ("" if opc != L.OP_CONV_GEMM else ("<dgrad>" if ints[0] == 1 else "<fwd>"))
+            if opc == L.OP_CONV_GEMM:       # i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,...
+                _, N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:8]
+                e_in, e_out = N_ * Hi * Wi * Ci, N_ * Ho * Wo * Co
+                nbytes = 2 * ((2 * e_in + e_out) if ints[0] == 1 else (e_in + e_out))     # dgrad reads g AND y
+                flops = 2.0 * N_ * Ho * Wo * Co * Ci * ints[8] * ints[9] if ints[0] == 0 else \
+                    2.0 * N_ * Hi * Wi * Ci * Co * ints[8] * ints[9]
+            elif opc == L.OP_CONV_WGRAD:    # i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw
+                N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:7]
+                nbytes = 2 * (N_ * Hi * Wi * Ci + 2 * N_ * Ho * Wo * Co)
+                flops = 2.0 * N_ * Ho * Wo * Co * Ci * ints[7] * ints[8]
+            elif opc in (L.OP_DW_FWD, L.OP_DW_BWD):
+                N_, H_, W_, C_, k_ = ints[:5]
+                e = N_ * H_ * W_ * C_
+                nbytes = 2 * (2 * e if opc == L.OP_DW_FWD else 4 * e)
+                flops = 2.0 * e * k_ * k_ * (1 if opc == L.OP_DW_FWD else 2)
+            elif opc == L.OP_BN_BWD_REDUCE:
+                nbytes, flops = 0, 0.0     # pure overhead in SURVEY 8(d)'s accounting (reads g and y again)
+            elif opc == L.OP_ADD_ACT:
+                nbytes, flops = 0, 0.0
+            else:                           # stem fwd / wgrad: fp32 image + bf16 output
+                N_, H_, W_, Ho, Wo, Co = ints[:6]
+                nbytes = N_ * 3 * H_ * W_ * 4 + 2 * N_ * Ho * Wo * Co * (1 if opc == L.OP_STEM_FWD else 2)
+                flops = 2.0 * N_ * Ho * Wo * Co * 27
+            a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
+            a[0] += msv; a[1] += nbytes; a[2] += flops; a[3] += 1
+        # every step re-records the same event pairs, so what is read here is the LAST timed step
+        tot = sum(a[0] for a in agg.values())
+        name, (tms, nb, fl, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+        gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+        res["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                           "launches_per_step": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
+                           "ms_per_step": round(tms, 3), "share_of_bracketed_time": round(tms / tot, 3),
+                           "note": "HIP events around every launch of this kernel class, last timed step"}
+        res["kernel_classes"] = {k: {"ms_per_step": round(v[0], 3), "algorithmic_GB": round(v[1] / 1e9, 3),
+                                     "GBps": round(v[1] / max(v[0], 1e-9) / 1e6, 1), "TFLOP": round(v[2] / 1e12, 4),
+                                     "TFLOPps": round(v[2] / max(v[0], 1e-9) / 1e9, 1), "launches": v[3]}
+                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        res["bracketed_ms_per_step"] = round(tot, 3)
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    print(json.dumps(res))
+    if distributed:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

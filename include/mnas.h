@@ -205,6 +205,7 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_ADD_ACT 12
 #define MNAS_OP_NCHW_TO_NHWC 13
 #define MNAS_OP_PACK_WEIGHTS 14
+#define MNAS_OP_EVENT_RECORD 15    /* p[0] = event handle from mnas_event_create: hipEventRecord on `stream` */
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];
@@ -214,6 +215,13 @@ typedef struct MnasOp {
 /* Field use per opcode is documented next to mnas_run_ops in csrc/mnas_abi.hip. Stops at the first error
  * and returns it (index of the failing op in *failed_at if non-NULL). */
 int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_at);
+
+/* ---- HIP events on the launch stream (measurement only: bench.py brackets single kernel launches inside
+ * the timed region; torch.cuda.Event cannot be recorded from inside mnas_run_ops) ------------------------ */
+int mnas_event_create(void** event);
+int mnas_event_destroy(void* event);
+int mnas_event_record(void* event, void* stream);
+int mnas_event_elapsed_ms(void* start, void* stop, float* ms);   /* non-zero if either is not complete */
 
 #ifdef __cplusplus
 }

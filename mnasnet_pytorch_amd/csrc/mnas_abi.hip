@@ -94,6 +94,8 @@ static int run_one(const MnasOp& o, void* stream) {
             return mnas_nchw_f32_to_nhwc_bf16((const float*)p[0], p[1], i[0], i[1], i[2], stream);
         case MNAS_OP_PACK_WEIGHTS:
             return mnas_pack_weights((const float*)p[0], i[0], i[1], i[2], i[3], i[4], p[1], stream);
+        case MNAS_OP_EVENT_RECORD:
+            return (int)hipEventRecord((hipEvent_t)p[0], (hipStream_t)stream);
         default:
             return MNAS_EINVAL;
     }
@@ -108,4 +110,18 @@ extern "C" int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_
         }
     }
     return MNAS_OK;
+}
+
+extern "C" int mnas_event_create(void** event) {
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc == hipSuccess) *event = (void*)e;
+    return (int)rc;
+}
+extern "C" int mnas_event_destroy(void* event) { return (int)hipEventDestroy((hipEvent_t)event); }
+extern "C" int mnas_event_record(void* event, void* stream) {
+    return (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+}
+extern "C" int mnas_event_elapsed_ms(void* start, void* stop, float* ms) {
+    return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
 }

@@ -108,12 +108,21 @@ class _Act:
 
 
 class _OpList:
-    def __init__(self):
+    def __init__(self, eng=None, tag=""):
         self.items = []
+        self.eng, self.tag = eng, tag
 
     def add(self, opcode, ints=(), dbls=(), ptrs=()):
+        prof = self.eng is not None and self.eng.profile_opcodes and opcode in self.eng.profile_opcodes
+        if prof:
+            ev0, ev1 = self.eng.new_event(), self.eng.new_event()
+            self.items.append((L.OP_EVENT_RECORD, [], [], [ev0]))
         self.items.append((opcode, list(ints), list(dbls), list(ptrs)))
-        return len(self.items) - 1
+        idx = len(self.items) - 1
+        if prof:
+            self.items.append((L.OP_EVENT_RECORD, [], [], [ev1]))
+            self.eng.profile_events.append(((self.tag, opcode, tuple(ints)), ev0, ev1))
+        return idx
 
     def build(self):
         arr = (L.MnasOp * max(1, len(self.items)))()
@@ -149,7 +158,7 @@ class Program:
             self.keep.append(t)
             return t
 
-        fwd = _OpList()
+        fwd = _OpList(eng, "fwd")
         # ---- weight packing (once per forward; weights change every optimizer step)
         for ci in eng.convs:
             w = ci.mod.conv.weight
@@ -243,7 +252,7 @@ class Program:
 
         def seg(stage):
             if stage not in seg_ops:
-                seg_ops[stage] = _OpList()
+                seg_ops[stage] = _OpList(eng, "bwd")
                 order.append(stage)
             return seg_ops[stage]
 
@@ -267,8 +276,8 @@ class Program:
             gin = None
             if ci.kind == "stem":
                 nsp = max(1, min(512, _cdiv(M, 1024)))
-                ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()])
-                self.patch_x_bwd = (ops, len(ops.items) - 1, 0)
+                jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()])
+                self.patch_x_bwd = (ops, jx, 0)
                 ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
             elif ci.kind == "dw":
                 nparts = max(1, min(512, _cdiv(M * Co, 256 * 16 * 8)))
@@ -439,6 +448,9 @@ class Engine:
             r[0], r[1] = min(r[0], a), max(r[1], off)
         self.grad_numel = off
         self._sig = None
+        self._ext_grad: Optional[torch.Tensor] = None
+        self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
+        self.profile_events = []         # [(tag, start_handle, stop_handle)]
 
     # ---- device state ---------------------------------------------------------------------------
     def _signature(self):
@@ -470,12 +482,44 @@ class Engine:
             smax = max(smax, ci.cout)
         self.scratch_stats = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)
         self.scratch_wgrad = torch.empty(wmax, dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros(self.grad_numel, dtype=torch.float32, device=device)
+        if self._ext_grad is not None:
+            self.flat_grad = self._ext_grad
+        else:
+            self.flat_grad = torch.zeros(self.grad_numel, dtype=torch.float32, device=device)
         self.grad_views = []
         for ci in sorted(self.convs, key=lambda c: -c.stage):
             for j, p in enumerate(ci.params):
                 o, n = ci.gslice[j]
                 self.grad_views.append(self.flat_grad[o:o + n].view(p.shape))
+
+    def bind_grad_buffer(self, buf: Optional[torch.Tensor]):
+        """Make the kernels write gradients into ``buf`` (fp32, ``grad_numel`` elements, engine layout: later
+        stages first) instead of an engine-owned buffer -- used by train_step.Trainer so that ONE flat buffer
+        feeds the RCCL all-reduce buckets and the fused Adam."""
+        if buf is not None and (buf.numel() != self.grad_numel or buf.dtype != torch.float32 or not buf.is_contiguous()):
+            raise ValueError("grad buffer must be contiguous fp32 with %d elements" % self.grad_numel)
+        self._ext_grad = buf
+        self._sig = None           # forces _setup (programs hold gradient pointers)
+
+    def ensure_setup(self, device):
+        sig = self._signature()
+        if self.lib is None or self.device != device or sig != self._sig:
+            self._setup(device)
+            self._sig = sig
+
+    def new_event(self):
+        h = C.c_void_p()
+        L.check(self.lib.mnas_event_create(C.byref(h)), "event_create")
+        return h.value
+
+    def read_profile(self):
+        """[(tag, ms)] for every bracketed op launch since the programs were built (call after a sync)."""
+        out = []
+        for tag, e0, e1 in self.profile_events:
+            ms = C.c_float()
+            if self.lib.mnas_event_elapsed_ms(e0, e1, C.byref(ms)) == 0:
+                out.append((tag, ms.value))
+        return out
 
     def gptr(self, ci: _ConvInfo, j: int):
         return self.flat_grad.data_ptr() + 4 * ci.gslice[j][0]
@@ -530,9 +574,6 @@ class Engine:
         if any(p.device != x.device for p in self.params):
             raise RuntimeError("module parameters and input are on different devices")
         x = x.float().contiguous()          # train.py:427 input.float()
-        sig = self._signature()
-        if self.lib is None or self.device != x.device or sig != self._sig:
-            self._setup(x.device)
-            self._sig = sig
+        self.ensure_setup(x.device)
         track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params))
         return _EngineFn.apply(self, track, x, *self.params)
