@@ -66,8 +66,9 @@ const char* mnas_arch(void);            /* "gfx950" */
  *                    in  = dy (N,Hi,Wi,Ci) read through `grad` (Hi,Wi,Ci are the FORWARD OUTPUT dims and
  *                    channels), out = (N,Ho,Wo,Co) are the FORWARD INPUT dims/channels.
  * w: packed bf16 [Co_pad16][Kpad32], K = kh*kw*Ci ordered (tap, ci) -- see mnas_pack_weights.
- * stats (optional, forward): float[nparts][2][Co] partial (sum, sumsq) of the fp32 output, one row per
- * pixel-workgroup; rows are fully overwritten (no memset needed). */
+ * stats (optional, forward): float[2][Co][nparts] partial (sum, sumsq) of the fp32 output, one column per
+ * pixel-workgroup (channel-major so the finalize kernel reads one channel contiguously); fully overwritten
+ * (no memset needed). */
 typedef struct MnasConvGemm {
     int32_t mode;
     int32_t N, Hi, Wi, Ci;
@@ -108,12 +109,12 @@ int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int ta
  * Replaces ATen conv2d fwd/bwd for ConvBlock's groups==C convs (mnasnet.py:122-125, 76-81). */
 typedef struct MnasDwFwd {
     int32_t N, H, W, C, k;
-    int32_t nparts;          /* persistent workgroups per channel block; rows of `stats` */
+    int32_t nparts;          /* workgroups launched = columns of `stats`; must be >= C/64 (channel blocks) */
     MnasActIn in;
     const float* w;          /* fp32 [k*k][C] (tap-major) */
     const float* bias;       /* [C] or NULL */
     void*  out;              /* bf16 (N,H,W,C) raw output */
-    float* stats;            /* float[nparts][2][C] or NULL */
+    float* stats;            /* float[2][C][nparts] or NULL */
 } MnasDwFwd;
 int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
 
@@ -140,7 +141,7 @@ typedef struct MnasStemFwd {
                                 the reference [Co][3][3][3] tensor viewed as [Co][27] (k = ci*9+kh*3+kw) */
     const float* bias;
     void*  out;              /* bf16 (N,Ho,Wo,Co) */
-    float* stats;            /* float[nparts][2][Co] */
+    float* stats;            /* float[2][Co][nparts] */
 } MnasStemFwd;
 int mnas_stem_fwd(const MnasStemFwd* a, void* stream);
 typedef struct MnasStemWgrad {
@@ -153,7 +154,7 @@ typedef struct MnasStemWgrad {
 int mnas_stem_wgrad(const MnasStemWgrad* a, void* stream);
 
 /* ---- BatchNorm2d bookkeeping (replaces ATen native_batch_norm / native_batch_norm_backward) ---------- */
-/* partial: float[nparts][2][C] (sum, sumsq over `count` elements per channel).
+/* partial: float[2][C][nparts] (sum, sumsq over `count` elements per channel).
  * training=1: batch stats -> bnbuf rows 0,1,5,6; running_mean/var momentum update (unbiased var),
  *             num_batches_tracked (int64 device scalar, may be NULL) += 1.
  * training=0: bnbuf rows 0,1 from the running stats; nothing else is touched (partial may be NULL). */
@@ -161,7 +162,7 @@ int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, double count,
                          const float* gamma, const float* beta,
                          float* running_mean, float* running_var, int64_t* num_batches_tracked,
                          float momentum, float eps, int training, float* bnbuf, void* stream);
-/* partial[p][0][c] = sum dz, partial[p][1][c] = sum dz*xhat over the rows of workgroup p, where
+/* partial[0][c][p] = sum dz, partial[1][c][p] = sum dz*xhat over the rows of workgroup p, where
  * dz = g*[s*y+t>0], xhat = (y-mean)*invstd.  g,y: bf16 [rows][C]. */
 int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnbuf, int64_t rows, int C,
                        int nparts, float* partial, void* stream);

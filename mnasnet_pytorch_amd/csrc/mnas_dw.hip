@@ -1,405 +1,411 @@
 // Depthwise kxk convolution (k in {3,5}, stride 1, pad k/2) forward and backward, NHWC bf16, fp32 math.
 // Replaces ATen's grouped conv2d fwd/bwd for ConvBlock(groups=C) (mnasnet.py:76-81,122-125).
 //
-// Mapping ("lanes = channel pairs"): a thread owns one channel PAIR (one dword of the NHWC row) and a
-// BH x BW block of output pixels; consecutive lanes own consecutive channel pairs, so LDS reads are
-// consecutive dwords and global stores are contiguous runs of 4*CPW bytes per pixel.  The k*k*2 filter
-// taps of the thread's channel pair live in VGPRs for the whole (persistent) kernel.  The input tile with
-// its halo is staged through registers (act-on-load / dy-on-load applied once per element) into LDS in the
-// same [y][x][c] order as global memory, so staging is plain 16-byte copies.
-// Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5); the fp32 FMA work is ~half the HBM time at peak.
+// Structure ("vertical sweep over an LDS row ring"):
+//   * a workgroup owns ONE image, a column strip of TW = 4*sx output columns and a block of 2*cpw channels
+//     (all channels of the pixel when C <= 144, otherwise >= 64 channels = 128-byte runs), and sweeps the
+//     strip top to bottom G = 4 output rows at a time;
+//   * the input rows it needs live in an 8-row ring in LDS, in the same [row][x][c] order as HBM, so every
+//     input element is fetched from HBM ONCE per strip (halo only horizontally: (TW+k-1)/TW) and staged with
+//     plain 16-byte loads/stores; BatchNorm+ReLU of the producer ("act-on-load") or BatchNorm/ReLU backward
+//     ("dy-on-load") is applied once per element on the way into LDS;
+//   * staging is division-free in steady state: each thread's (row, x, channel-group) slots are computed once
+//     per kernel, its channel group never changes, so the per-channel coefficients sit in registers, and the
+//     <= 6 loads of a step are issued back to back before any of them is consumed (bytes in flight);
+//   * compute: thread = (channel pair, 4-column strip), consecutive lanes = consecutive channel pairs
+//     (conflict-free dword LDS reads, contiguous global stores); the k*k*2 taps of its channel pair are in VGPRs;
+//     rows are STREAMED: each input row is read from LDS once (k+3 dwords) and scattered into a register ring of
+//     k partial output rows; the oldest ring entry is complete after every input row and is emitted;
+//   * BatchNorm partial statistics (forward) and the k*k weight-gradient sums (backward) are accumulated in
+//     registers over the whole sweep and written once per workgroup (no atomics in HBM, deterministic);
+//   * backward = two launches of this structure: dgrad (the forward kernel with dy-on-load staging and the
+//     flipped filter) and wgrad.  Fusing them needs 2 x k*k*2 persistent VGPRs per thread (filter + gradient
+//     sums) and halves occupancy; measured trade-off recorded in DESIGN.md.
+// Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5 forward; backward moves 4 tensors for 2x the FMAs).
 #include "mnas_common.h"
 
-#define DW_BH 4
-#define DW_BW 4
+#define DW_G 4          // output rows per sweep step
+#define DW_BW 4         // output columns per thread
+#define DW_RR 8         // ring rows (>= G + k - 1)
+#define DW_MAXCOL 2     // column positions (x, channel group) a thread stages per row
 
-struct DwCfg {
-    int cpw;        // channel pairs per workgroup (multiple of 4)
-    int ni, sy, sx; // strips: images x rows x cols of BHxBW blocks
-    int tiles_y, tiles_x, groups;
-    int ih, iw;     // LDS tile dims (with halo)
-    int cblocks;
-    size_t lds_tile_bytes;
-};
-
-static bool dw_pick_config(int N, int H, int W, int C, int k, int ntiles_lds, DwCfg* out) {
-    const int cps = C / 2;
-    double best = -1.0;
-    for (int cpw = 4; cpw <= 128 && cpw <= ((cps + 3) / 4) * 4; cpw += 4) {
-        const int S = 256 / cpw;
-        if (S < 1) break;
-        const int cblocks = (cps + cpw - 1) / cpw;
-        const int maxsy = (H + DW_BH - 1) / DW_BH, maxsx = (W + DW_BW - 1) / DW_BW;
-        for (int sy = 1; sy <= maxsy && sy <= S; ++sy) {
-            for (int sx = 1; sx <= maxsx && sy * sx <= S; ++sx) {
-                int ni = 1;
-                if (sy == maxsy && sx == maxsx) ni = S / (sy * sx);
-                if (ni > N) ni = N;
-                if (ni < 1) ni = 1;
-                const int th = sy * DW_BH, tw = sx * DW_BW;
-                const int ih = th + k - 1, iw = tw + k - 1;
-                const size_t lds = (size_t)ni * ih * iw * cpw * 2 * 2;
-                if (lds * ntiles_lds + 8192 > 64 * 1024) continue;
-                const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw, groups = (N + ni - 1) / ni;
-                const double work = (double)ty * tx * groups * cblocks * 256.0 * DW_BH * DW_BW;
-                const double useful = (double)N * H * W * cps;
-                const double halo = (double)(ih * iw) / (double)(th * tw);
-                const double score = useful / work / (0.75 + 0.25 * halo);
-                if (score > best) {
-                    best = score;
-                    out->cpw = cpw; out->ni = ni; out->sy = sy; out->sx = sx;
-                    out->tiles_y = ty; out->tiles_x = tx; out->groups = groups;
-                    out->ih = ih; out->iw = iw; out->cblocks = cblocks; out->lds_tile_bytes = lds;
-                }
-            }
-        }
-    }
-    return best > 0.0;
-}
-
-struct DwGeom {
+struct DwArgs {
     int N, H, W, C;
-    int cpw, ni, sy, sx, tiles_y, tiles_x, groups, ih, iw;
+    int cpw, sx, nthreads, cgn, iw, ps;     // ps: LDS pixel stride (dwords), multiple of 4
+    int strips_x, cblocks, items, geff;     // geff: workgroups that take items (multiple of cblocks)
+    int rc, ncol, tcol, rpp;                // staging: chunks per row, columns per thread, threads per column pass, rows per pass
 };
 
-// ---- staging -------------------------------------------------------------------------------------
-// tile layout in LDS: [ni][ih][iw][cblk] bf16, cblk = 2*cpw channels (cblk % 8 == 0)
-template <int KS>
-__device__ __forceinline__ void dw_stage_act(const DwGeom& g, const MnasActIn& in, const float* lds_coef /*[2][cblk]*/,
-                                             uint4* tile, int n0, int y0, int x0, int c0) {
-    constexpr int PAD = KS / 2;
-    const int cg_n = g.cpw >> 2;
-    const int chunks = g.ni * g.ih * g.iw * cg_n;
-    const uint4* src = (const uint4*)in.data;
-    const bool has = in.scale != nullptr;
-    for (int q = threadIdx.x; q < chunks; q += 256) {
-        const int cgl = q % cg_n;
-        int pix = q / cg_n;
-        const int ix = pix % g.iw; pix /= g.iw;
-        const int iy = pix % g.ih;
-        const int ni = pix / g.ih;
-        const int gy = y0 + iy - PAD, gx = x0 + ix - PAD, n = n0 + ni, c = c0 + cgl * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (n < g.N && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && c < g.C) {
-            v = src[(((size_t)n * g.H + gy) * g.W + gx) * (g.C >> 3) + (c >> 3)];
-            if (has) {
-                const float4* cf = (const float4*)(lds_coef + cgl * 8);
-                const float4* ct = (const float4*)(lds_coef + 2 * g.cpw + cgl * 8);
-                float s[8], t[8];
-                *(float4*)&s[0] = cf[0]; *(float4*)&s[4] = cf[1];
-                *(float4*)&t[0] = ct[0]; *(float4*)&t[4] = ct[1];
-                v = act8(v, s, t);
-            }
-        }
-        tile[q] = v;
+static bool dw_pick(int N, int H, int W, int C, int k, int nrings, DwArgs* a) {
+    const int cps = C / 2;
+    // channel block: whole pixel if it fits a workgroup sensibly, else >= 32 pairs (128 B runs)
+    int cpw;
+    if (cps <= 72) cpw = cps;
+    else {
+        cpw = 32;
+        for (int c = 32; c <= 64; c += 4)           // prefer an exact divisor of C/2
+            if (cps % c == 0) { cpw = c; break; }
     }
+    const int cgn = cpw / 4;
+    const int ps = (cpw % 32 == 0) ? cpw : cpw + 4;
+    int best_sx = 0; double best = -1.0;
+    const int maxsx = (W + DW_BW - 1) / DW_BW;
+    for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
+        const int tw = sx * DW_BW, iw = tw + k - 1;
+        const size_t lds = (size_t)nrings * DW_RR * iw * ps * 4;
+        if (lds > 56 * 1024) continue;
+        const int nth = ((sx * cpw + 63) / 64) * 64;
+        const int rc = iw * cgn;
+        const int tcol = (nth / cgn) * cgn;
+        if (rc > DW_MAXCOL * tcol) continue;
+        const int strips = (W + tw - 1) / tw;
+        const double util = (double)W / (strips * tw) * (double)(sx * cpw) / nth;
+        const double halo = (double)iw / tw;
+        const double score = util / (0.6 + 0.4 * halo);
+        if (score > best) { best = score; best_sx = sx; }
+    }
+    if (best_sx == 0) return false;
+    a->N = N; a->H = H; a->W = W; a->C = C;
+    a->cpw = cpw; a->sx = best_sx; a->cgn = cgn; a->ps = ps;
+    a->nthreads = ((best_sx * cpw + 63) / 64) * 64;
+    a->iw = best_sx * DW_BW + k - 1;
+    a->strips_x = (W + best_sx * DW_BW - 1) / (best_sx * DW_BW);
+    a->cblocks = (cps + cpw - 1) / cpw;
+    a->items = N * a->strips_x * a->cblocks;
+    a->rc = a->iw * cgn;
+    if (a->rc <= a->nthreads) {          // several rows per pass, one column position per thread
+        a->ncol = 1; a->tcol = a->rc; a->rpp = a->nthreads / a->rc;
+        if (a->rpp > DW_G) a->rpp = DW_G;
+    } else {                             // one row per pass, up to DW_MAXCOL column positions per thread
+        a->tcol = (a->nthreads / cgn) * cgn; a->ncol = (a->rc + a->tcol - 1) / a->tcol; a->rpp = 1;
+    }
+    return true;
 }
 
-template <int KS>
-__device__ __forceinline__ void dw_stage_dy(const DwGeom& g, const MnasGradIn& d, const float* lds_coef /*[5][cblk]*/,
-                                            uint4* tile, int n0, int y0, int x0, int c0) {
-    constexpr int PAD = KS / 2;
-    const int cg_n = g.cpw >> 2;
-    const int cblk = 2 * g.cpw;
-    const int chunks = g.ni * g.ih * g.iw * cg_n;
-    const uint4* gs = (const uint4*)d.g;
-    const uint4* ys = (const uint4*)d.y;
-    for (int q = threadIdx.x; q < chunks; q += 256) {
-        const int cgl = q % cg_n;
-        int pix = q / cg_n;
-        const int ix = pix % g.iw; pix /= g.iw;
-        const int iy = pix % g.ih;
-        const int ni = pix / g.ih;
-        const int gy = y0 + iy - PAD, gx = x0 + ix - PAD, n = n0 + ni, c = c0 + cgl * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (n < g.N && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && c < g.C) {
-            const size_t off = (((size_t)n * g.H + gy) * g.W + gx) * (g.C >> 3) + (c >> 3);
-            const uint4 gv = gs[off], yv = ys[off];
-            float cf[5][8];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const float4* p = (const float4*)(lds_coef + r * cblk + cgl * 8);
-                *(float4*)&cf[r][0] = p[0];
-                *(float4*)&cf[r][4] = p[1];
-            }
-            float o[8];
-            dy8(gv, yv, cf[0], cf[1], cf[2], cf[3], cf[4], o);
-            v = pack8(o);
-        }
-        tile[q] = v;
-    }
-}
+__device__ __forceinline__ int dw_slot(int image_row) { return (image_row + DW_RR) & (DW_RR - 1); }   // rows >= -RR
 
-__device__ __forceinline__ void dw_load_coefs(float* lds_coef, const float* src, int rows, int C, int c0, int cblk) {
-    for (int i = threadIdx.x; i < rows * cblk; i += 256) {
-        const int r = i / cblk, c = c0 + i % cblk;
-        lds_coef[i] = (src && c < C) ? src[(size_t)r * C + c] : 0.f;
-    }
-}
+// per-thread staging plan (tile-invariant): its column position(s) and row lane
+struct DwStagePlan {
+    int goff[DW_MAXCOL];     // element offset (uint4 units) of the chunk inside an image row, relative to x0-PAD: ix*C8 + c8
+    int loff[DW_MAXCOL];     // dword offset inside a ring row: ix*ps + cgl*4
+    int ix[DW_MAXCOL];
+    int rl;                  // row lane (0..rpp-1), or -1 if the thread does not stage
+    int cgl;
+};
 
-// ---- forward ---------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(256) void k_dw_fwd(DwGeom g, MnasActIn in, const float* __restrict__ w,
-                                                const float* __restrict__ bias, uint32_t* __restrict__ out,
-                                                float* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WIN_W = DW_BW + KS - 1, WIN_H = DW_BH + KS - 1;
-    const int cblk = 2 * g.cpw;
-    float* lds_coef = (float*)smem;                                   // [2][cblk] scale/shift
-    float* lds_red = lds_coef + 2 * cblk;                              // [2][cblk] stats
-    uint4* tile = (uint4*)(smem + 4 * cblk * sizeof(float));
-    const uint32_t* tile32 = (const uint32_t*)tile;
-
-    const int c0 = blockIdx.y * cblk;
+__device__ __forceinline__ void dw_make_plan(const DwArgs& a, DwStagePlan& p) {
     const int tid = threadIdx.x;
-    const int cp = tid % g.cpw;
-    const int strip = tid / g.cpw;
-    const int nstrips = g.ni * g.sy * g.sx;
-    const bool active = strip < nstrips;
-    const int sx = strip % g.sx, sy = (strip / g.sx) % g.sy, sni = strip / (g.sx * g.sy);
-    const int ch = c0 + 2 * cp;
-    const bool ch_ok = ch < g.C;
-
-    // scale/shift for the staging pass (rows [scale | shift])
-    if (in.scale) {
-        dw_load_coefs(lds_coef, in.scale, 1, g.C, c0, cblk);
-        dw_load_coefs(lds_coef + cblk, in.shift, 1, g.C, c0, cblk);
-    }
-    for (int i = tid; i < 2 * cblk; i += 256) lds_red[i] = 0.f;
-
-    float wt[KS * KS][2];
+    int col0;
+    if (a.ncol == 1) { p.rl = tid / a.rc; col0 = tid - p.rl * a.rc; if (p.rl >= a.rpp) p.rl = -1; }
+    else { p.rl = (tid < a.tcol) ? 0 : -1; col0 = tid; }
+    p.cgl = col0 % a.cgn;
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) {
-        wt[t][0] = ch_ok ? w[(size_t)t * g.C + ch] : 0.f;
-        wt[t][1] = ch_ok ? w[(size_t)t * g.C + ch + 1] : 0.f;
+    for (int j = 0; j < DW_MAXCOL; ++j) {
+        const int col = col0 + j * a.tcol;
+        const int ix = (col < a.rc && j < a.ncol) ? col / a.cgn : -1;
+        p.ix[j] = ix;
+        p.goff[j] = ix * (a.C >> 3);
+        p.loff[j] = ix * a.ps + p.cgl * 4;
     }
-    const float b0 = (bias && ch_ok) ? bias[ch] : 0.f, b1 = (bias && ch_ok) ? bias[ch + 1] : 0.f;
+}
+
+// Stage `nrows` (<= G) image rows starting at image row `row0` (may be negative / beyond H: zero rows) into
+// the ring.  MODE 0: act-on-load, coefficients lds_c = [2][cblk] (scale, shift).  MODE 1: dy-on-load,
+// lds_c = [5][cblk] (s,t,c1,c2,c3).  Slots t = 0..G*ncol-1 -> (row group t/ncol, column t%ncol) are processed
+// in batches of 4: the batch's loads are issued back to back, then transformed and written to LDS.
+template <int KS, int MODE>
+__device__ __forceinline__ void dw_stage(const DwArgs& a, const DwStagePlan& p, uint32_t* ring, const uint4* __restrict__ src0,
+                                         const uint4* __restrict__ src1, const float* lds_c, bool has_coef, int n, int row0,
+                                         int nrows, int x0, int c0) {
+    constexpr int PAD = KS / 2;
+    if (p.rl < 0) return;
+    const int cblk = 2 * a.cpw;
+    const int c = c0 + p.cgl * 8;
+    const bool c_ok = c < a.C;
+    const int C8 = a.C >> 3;
+    const int rowstride = a.W * C8;
+    const int xbase = (x0 - PAD) * C8 + (c >> 3);
+    const int nslots = DW_G * a.ncol;
+    const int jshift = a.ncol - 1;           // ncol in {1,2}
+#pragma unroll
+    for (int tb = 0; tb < DW_G * DW_MAXCOL; tb += 4) {
+        if (tb >= nslots) break;
+        uint4 v0[4], v1[4];
+        bool inb[4], st[4];
+        int lofs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tb + u;
+            const int q = t >> jshift, j = t & jshift;
+            const int row = q * a.rpp + p.rl;
+            const int gy = row0 + row;
+            const int ixj = j ? p.ix[1] : p.ix[0];
+            const int gx = x0 - PAD + ixj;
+            st[u] = (q * a.rpp < nrows) && (row < nrows) && ixj >= 0;
+            inb[u] = st[u] && c_ok && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+            lofs[u] = (dw_slot(gy) * a.iw + ixj) * a.ps + p.cgl * 4;
+            v0[u] = make_uint4(0, 0, 0, 0);
+            if (MODE == 1) v1[u] = make_uint4(0, 0, 0, 0);
+            if (inb[u]) {
+                const size_t off = ((size_t)n * a.H + gy) * rowstride + xbase + ixj * C8;
+                v0[u] = src0[off];
+                if (MODE == 1) v1[u] = src1[off];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!st[u]) continue;
+            uint4 v = v0[u];
+            if (MODE == 0) {
+                if (has_coef && inb[u]) {
+                    float cs[8], ct[8];
+                    *(float4*)&cs[0] = *(const float4*)(lds_c + p.cgl * 8);
+                    *(float4*)&cs[4] = *(const float4*)(lds_c + p.cgl * 8 + 4);
+                    *(float4*)&ct[0] = *(const float4*)(lds_c + cblk + p.cgl * 8);
+                    *(float4*)&ct[4] = *(const float4*)(lds_c + cblk + p.cgl * 8 + 4);
+                    v = act8(v, cs, ct);
+                }
+            } else if (inb[u]) {
+                float cf[5][8];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    *(float4*)&cf[r][0] = *(const float4*)(lds_c + r * cblk + p.cgl * 8);
+                    *(float4*)&cf[r][4] = *(const float4*)(lds_c + r * cblk + p.cgl * 8 + 4);
+                }
+                float o[8];
+                dy8(v, v1[u], cf[0], cf[1], cf[2], cf[3], cf[4], o);
+                v = pack8(o);
+            }
+            *(uint4*)(ring + lofs[u]) = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void dw_item(const DwArgs& a, int item, int& n, int& x0, int& c0) {
+    const int cb = item % a.cblocks;
+    const int r = item / a.cblocks;
+    const int sxi = r % a.strips_x;
+    n = r / a.strips_x;
+    x0 = sxi * a.sx * DW_BW;
+    c0 = cb * 2 * a.cpw;
+}
+
+__device__ __forceinline__ void dw_load_coefs(float* lds_c, const float* r0, const float* r1, const float* rows5, int nrows,
+                                              int C, int c0, int cblk) {
+    for (int i = threadIdx.x; i < nrows * cblk; i += blockDim.x) {
+        const int r = i / cblk, c = c0 + i % cblk;
+        float v = 0.f;
+        if (c < C) v = rows5 ? rows5[(size_t)r * C + c] : (r == 0 ? (r0 ? r0[c] : 1.f) : (r1 ? r1[c] : 0.f));
+        lds_c[i] = v;
+    }
+}
+
+// ---- forward (MODE 0) and input gradient (MODE 1: dy-on-load staging, flipped filter, no bias/stats) --------
+template <int KS, int MODE>
+__global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_conv(DwArgs a, MnasActIn in, MnasGradIn d,
+                                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                                    uint32_t* __restrict__ out, float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1, CROWS = (MODE == 0) ? 2 : 5;
+    const int cblk = 2 * a.cpw;
+    float* lds_c = (float*)smem;                         // [CROWS][cblk] staging coefficients
+    float* lds_red = lds_c + CROWS * cblk;               // [2][cblk]
+    uint32_t* ring = (uint32_t*)(lds_red + 2 * cblk);    // [RR][iw][ps]
+    const int tid = threadIdx.x;
+    const int cp = tid % a.cpw, sxi = tid / a.cpw;
+    const bool active = sxi < a.sx;
+    DwStagePlan plan;
+    dw_make_plan(a, plan);
+    const bool has_coef = (MODE == 1) || in.scale != nullptr;
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    int cur_c0 = -1;
+    float wt[KS * KS][2], b0 = 0.f, b1 = 0.f;
+    const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
+    const uint4* src0 = (const uint4*)(MODE == 0 ? in.data : d.g);
+    const uint4* src1 = (const uint4*)(MODE == 0 ? nullptr : d.y);
 
-    const int th = g.sy * DW_BH, tw = g.sx * DW_BW;
-    const int ntiles = g.groups * g.tiles_y * g.tiles_x;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, grp = t / (g.tiles_x * g.tiles_y);
-        const int n0 = grp * g.ni, y0 = ty * th, x0 = tx * tw;
-        __syncthreads();   // previous tile fully consumed (also orders the coef/red init on the first pass)
-        dw_stage_act<KS>(g, in, lds_coef, tile, n0, y0, x0, c0);
-        __syncthreads();
-        if (active) {
-            float acc[DW_BH][DW_BW][2];
+    for (int item = blockIdx.x; item < a.items && (int)blockIdx.x < a.geff; item += a.geff) {
+        int n, x0, c0;
+        dw_item(a, item, n, x0, c0);
+        const int ch = c0 + 2 * cp;
+        const bool ch_ok = ch < a.C;
+        if (c0 != cur_c0) {       // first item: a workgroup only ever sees ONE channel block (see dw_setup)
+            cur_c0 = c0;
 #pragma unroll
-            for (int i = 0; i < DW_BH; ++i)
+            for (int t = 0; t < KS * KS; ++t) {
+                // MODE 1: gin[p] = sum_k dy[p + PAD - k] * w[k]  ==  a forward conv with the filter flipped in y and x
+                const int ts = (MODE == 0) ? t : (KS * KS - 1 - t);
+                wt[t][0] = ch_ok ? w[(size_t)ts * a.C + ch] : 0.f;
+                wt[t][1] = ch_ok ? w[(size_t)ts * a.C + ch + 1] : 0.f;
+            }
+            b0 = (MODE == 0 && bias && ch_ok) ? bias[ch] : 0.f;
+            b1 = (MODE == 0 && bias && ch_ok) ? bias[ch + 1] : 0.f;
+            __syncthreads();
+            if (MODE == 0) dw_load_coefs(lds_c, in.scale, in.shift, nullptr, 2, a.C, c0, cblk);
+            else dw_load_coefs(lds_c, nullptr, nullptr, d.coef, 5, a.C, c0, cblk);
+        }
+        // register ring of KS partial output rows: A[i] = output row (iy - PAD + i) while input row iy is processed
+        float A[KS][DW_BW][2];
 #pragma unroll
-                for (int j = 0; j < DW_BW; ++j) { acc[i][j][0] = b0; acc[i][j][1] = b1; }
-            const int base = ((sni * g.ih + sy * DW_BH) * g.iw + sx * DW_BW) * g.cpw + cp;
+        for (int i = 0; i < KS; ++i)
 #pragma unroll
-            for (int r = 0; r < WIN_H; ++r) {
+            for (int j = 0; j < DW_BW; ++j) { A[i][j][0] = b0; A[i][j][1] = b1; }
+        const int gx0 = x0 + sxi * DW_BW;
+        uint32_t* outp = out + (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
+        const uint32_t* colp = ring + (size_t)sxi * DW_BW * a.ps + cp;
+
+        for (int s = 0; s < nsteps; ++s) {
+            const int r0 = -PAD + s * DW_G;
+            __syncthreads();                         // previous group fully consumed (and coefficients visible)
+            dw_stage<KS, MODE>(a, plan, ring, src0, src1, lds_c, has_coef, n, r0, DW_G, x0, c0);
+            __syncthreads();
+            if (!active) continue;
+#pragma unroll 1
+            for (int j = 0; j < DW_G; ++j) {
+                const int iy = r0 + j;
+                if (iy >= a.H + PAD) break;
+                const uint32_t* rowp = colp + (size_t)dw_slot(iy) * a.iw * a.ps;
                 float xr[WIN_W][2];
 #pragma unroll
                 for (int x = 0; x < WIN_W; ++x) {
-                    const uint32_t u = tile32[base + (r * g.iw + x) * g.cpw];
+                    const uint32_t u = rowp[x * a.ps];
                     xr[x][0] = bf_lo(u);
                     xr[x][1] = bf_hi(u);
                 }
 #pragma unroll
-                for (int oy = 0; oy < DW_BH; ++oy) {
-                    const int ky = r - oy;
-                    if (ky < 0 || ky >= KS) continue;
+                for (int i = 0; i < KS; ++i)
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
                         for (int kx = 0; kx < KS; ++kx) {
-                            acc[oy][ox][0] = fmaf(wt[ky * KS + kx][0], xr[ox + kx][0], acc[oy][ox][0]);
-                            acc[oy][ox][1] = fmaf(wt[ky * KS + kx][1], xr[ox + kx][1], acc[oy][ox][1]);
+                            A[i][ox][0] = fmaf(wt[(KS - 1 - i) * KS + kx][0], xr[ox + kx][0], A[i][ox][0]);
+                            A[i][ox][1] = fmaf(wt[(KS - 1 - i) * KS + kx][1], xr[ox + kx][1], A[i][ox][1]);
                         }
-                }
-            }
-            const int n = n0 + sni;
-            if (ch_ok && n < g.N) {
-#pragma unroll
-                for (int oy = 0; oy < DW_BH; ++oy) {
-                    const int gy = y0 + sy * DW_BH + oy;
-                    if (gy >= g.H) continue;
+                const int oy = iy - PAD;             // A[0] is complete
+                if (oy >= 0 && ch_ok) {
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) {
-                        const int gx = x0 + sx * DW_BW + ox;
-                        if (gx >= g.W) continue;
-                        const float v0 = acc[oy][ox][0], v1 = acc[oy][ox][1];
-                        s1[0] += v0; s2[0] = fmaf(v0, v0, s2[0]);
-                        s1[1] += v1; s2[1] = fmaf(v1, v1, s2[1]);
-                        out[((((size_t)n * g.H + gy) * g.W + gx) * g.C + ch) >> 1] = pack_bf16(v0, v1);
+                        if (gx0 + ox < a.W) {
+                            const float v0 = A[0][ox][0], v1 = A[0][ox][1];
+                            if (MODE == 0) {
+                                s1[0] += v0; s2[0] = fmaf(v0, v0, s2[0]);
+                                s1[1] += v1; s2[1] = fmaf(v1, v1, s2[1]);
+                            }
+                            outp[((size_t)oy * a.W + ox) * a.C / 2] = pack_bf16(v0, v1);
+                        }
                     }
                 }
+#pragma unroll
+                for (int i = 0; i + 1 < KS; ++i)
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) { A[i][ox][0] = A[i + 1][ox][0]; A[i][ox][1] = A[i + 1][ox][1]; }
+#pragma unroll
+                for (int ox = 0; ox < DW_BW; ++ox) { A[KS - 1][ox][0] = b0; A[KS - 1][ox][1] = b1; }
             }
         }
     }
-    if (stats) {
+    if (MODE == 0 && stats) {
+        // every workgroup writes its WHOLE column of the [2][C][nparts] table: its own channel block's sums,
+        // zeros elsewhere (idle workgroups: all zeros), so no memset is needed and the finalize sum is exact
         __syncthreads();
-        if (active && ch_ok) {
-            atomicAdd(&lds_red[2 * cp], s1[0]);
-            atomicAdd(&lds_red[2 * cp + 1], s1[1]);
-            atomicAdd(&lds_red[cblk + 2 * cp], s2[0]);
-            atomicAdd(&lds_red[cblk + 2 * cp + 1], s2[1]);
+        for (int i = tid; i < 2 * cblk; i += blockDim.x) lds_red[i] = 0.f;
+        __syncthreads();
+        if (active && cur_c0 >= 0 && cur_c0 + 2 * cp < a.C) {
+            atomicAdd(&lds_red[2 * cp], s1[0]); atomicAdd(&lds_red[2 * cp + 1], s1[1]);
+            atomicAdd(&lds_red[cblk + 2 * cp], s2[0]); atomicAdd(&lds_red[cblk + 2 * cp + 1], s2[1]);
         }
         __syncthreads();
-        for (int i = tid; i < 2 * cblk; i += 256) {
-            const int r = i / cblk, c = c0 + i % cblk;
-            if (c < g.C) stats[((size_t)blockIdx.x * 2 + r) * g.C + c] = lds_red[i];
+        for (int i = tid; i < 2 * a.C; i += blockDim.x) {
+            const int r = i / a.C, c = i - r * a.C;
+            const bool own = cur_c0 >= 0 && c >= cur_c0 && c < cur_c0 + cblk;
+            stats[(size_t)i * gridDim.x + blockIdx.x] = own ? lds_red[r * cblk + (c - cur_c0)] : 0.f;
         }
     }
 }
 
-extern "C" int mnas_dw_fwd(const MnasDwFwd* a, void* stream) {
-    if (!a || (a->k != 3 && a->k != 5) || (a->C & 7) || a->nparts < 1) return MNAS_EINVAL;
-    DwCfg cfg;
-    if (!dw_pick_config(a->N, a->H, a->W, a->C, a->k, 1, &cfg)) return MNAS_EINVAL;
-    DwGeom g = {a->N, a->H, a->W, a->C, cfg.cpw, cfg.ni, cfg.sy, cfg.sx, cfg.tiles_y, cfg.tiles_x, cfg.groups, cfg.ih, cfg.iw};
-    const size_t lds = 4 * 2 * cfg.cpw * sizeof(float) + cfg.lds_tile_bytes;
-    dim3 grid(a->nparts, cfg.cblocks);
-    if (a->k == 3)
-        hipLaunchKernelGGL(k_dw_fwd<3>, grid, dim3(256), lds, (hipStream_t)stream, g, a->in, a->w, a->bias, (uint32_t*)a->out, a->stats);
-    else
-        hipLaunchKernelGGL(k_dw_fwd<5>, grid, dim3(256), lds, (hipStream_t)stream, g, a->in, a->w, a->bias, (uint32_t*)a->out, a->stats);
-    MNAS_CHECK_LAUNCH();
-    return MNAS_OK;
-}
-
-// ---- backward: dgrad (flipped filter over dy) + wgrad (per-channel k*k reduction) in one pass -----------
+// ---- weight gradient: dW[ky][kx][c] = sum_p dy[p][c] * act(x)[p + (ky-PAD, kx-PAD)][c] --------------------------
+// At image row iy: dy row o = iy - PAD (centre columns) x activation rows o-PAD..o+PAD = iy-2PAD..iy (all in the ring).
 template <int KS>
-__global__ __launch_bounds__(256) void k_dw_bwd(DwGeom g, MnasActIn x, MnasGradIn d, const float* __restrict__ w,
-                                                uint32_t* __restrict__ gin, float* __restrict__ wpartial) {
+__global__ __launch_bounds__(256, 2) void k_dw_wgrad(DwArgs a, MnasActIn x, MnasGradIn d,
+                                                                     float* __restrict__ wpartial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WIN_W = DW_BW + KS - 1, WIN_H = DW_BH + KS - 1, PAD = KS / 2;
-    const int cblk = 2 * g.cpw;
-    float* lds_cx = (float*)smem;                 // [2][cblk] scale/shift of x
-    float* lds_cd = lds_cx + 2 * cblk;            // [5][cblk] dy coefficients
-    float* lds_red = lds_cd + 5 * cblk;           // [KS*KS][cblk]
-    const size_t hdr = (size_t)(7 + KS * KS) * cblk * sizeof(float);
-    const size_t tile_bytes = (size_t)g.ni * g.ih * g.iw * cblk * 2;
-    uint4* tile_d = (uint4*)(smem + hdr);
-    uint4* tile_x = (uint4*)(smem + hdr + tile_bytes);
-    const uint32_t* td32 = (const uint32_t*)tile_d;
-    const uint32_t* tx32 = (const uint32_t*)tile_x;
-
-    const int c0 = blockIdx.y * cblk;
+    constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
+    const int cblk = 2 * a.cpw;
+    float* lds_cx = (float*)smem;                            // [2][cblk]
+    float* lds_cd = lds_cx + 2 * cblk;                       // [5][cblk]
+    float* lds_red = lds_cd + 5 * cblk;                      // [KS*KS][cblk]
+    uint32_t* ring_d = (uint32_t*)(lds_red + KS * KS * cblk);
+    uint32_t* ring_x = ring_d + (size_t)DW_RR * a.iw * a.ps;
     const int tid = threadIdx.x;
-    const int cp = tid % g.cpw;
-    const int strip = tid / g.cpw;
-    const int nstrips = g.ni * g.sy * g.sx;
-    const bool active = strip < nstrips;
-    const int sx = strip % g.sx, sy = (strip / g.sx) % g.sy, sni = strip / (g.sx * g.sy);
-    const int ch = c0 + 2 * cp;
-    const bool ch_ok = ch < g.C;
-
-    if (x.scale) {
-        dw_load_coefs(lds_cx, x.scale, 1, g.C, c0, cblk);
-        dw_load_coefs(lds_cx + cblk, x.shift, 1, g.C, c0, cblk);
-    }
-    dw_load_coefs(lds_cd, d.coef, 5, g.C, c0, cblk);
-    for (int i = tid; i < KS * KS * cblk; i += 256) lds_red[i] = 0.f;
-
+    const int cp = tid % a.cpw, sxi = tid / a.cpw;
+    const bool active = sxi < a.sx;
+    DwStagePlan plan;
+    dw_make_plan(a, plan);
+    const bool has_coef = x.scale != nullptr;
+    int cur_c0 = -1;
     float wacc[KS * KS][2];
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t) { wacc[t][0] = 0.f; wacc[t][1] = 0.f; }
+    const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
 
-    const int th = g.sy * DW_BH, tw = g.sx * DW_BW;
-    const int ntiles = g.groups * g.tiles_y * g.tiles_x;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, grp = t / (g.tiles_x * g.tiles_y);
-        const int n0 = grp * g.ni, y0 = ty * th, x0 = tx * tw;
-        __syncthreads();
-        dw_stage_dy<KS>(g, d, lds_cd, tile_d, n0, y0, x0, c0);
-        dw_stage_act<KS>(g, x, lds_cx, tile_x, n0, y0, x0, c0);
-        __syncthreads();
-        if (!active) continue;
-        const int base = ((sni * g.ih + sy * DW_BH) * g.iw + sx * DW_BW) * g.cpw + cp;
-        // ---- phase 1: dgrad.  gin[p] = sum_j dy_win[p + j] * w[KS-1-j]
-        {
-            float wt[KS * KS][2];
-#pragma unroll
-            for (int k = 0; k < KS * KS; ++k) {
-                wt[k][0] = ch_ok ? w[(size_t)k * g.C + ch] : 0.f;
-                wt[k][1] = ch_ok ? w[(size_t)k * g.C + ch + 1] : 0.f;
-            }
-            float acc[DW_BH][DW_BW][2];
-#pragma unroll
-            for (int i = 0; i < DW_BH; ++i)
-#pragma unroll
-                for (int j = 0; j < DW_BW; ++j) { acc[i][j][0] = 0.f; acc[i][j][1] = 0.f; }
-#pragma unroll
-            for (int r = 0; r < WIN_H; ++r) {
-                float xr[WIN_W][2];
-#pragma unroll
-                for (int xx = 0; xx < WIN_W; ++xx) {
-                    const uint32_t u = td32[base + (r * g.iw + xx) * g.cpw];
-                    xr[xx][0] = bf_lo(u);
-                    xr[xx][1] = bf_hi(u);
-                }
-#pragma unroll
-                for (int oy = 0; oy < DW_BH; ++oy) {
-                    const int jy = r - oy;
-                    if (jy < 0 || jy >= KS) continue;
-#pragma unroll
-                    for (int ox = 0; ox < DW_BW; ++ox)
-#pragma unroll
-                        for (int jx = 0; jx < KS; ++jx) {
-                            const int k = (KS - 1 - jy) * KS + (KS - 1 - jx);
-                            acc[oy][ox][0] = fmaf(wt[k][0], xr[ox + jx][0], acc[oy][ox][0]);
-                            acc[oy][ox][1] = fmaf(wt[k][1], xr[ox + jx][1], acc[oy][ox][1]);
-                        }
-                }
-            }
-            const int n = n0 + sni;
-            if (ch_ok && n < g.N) {
-#pragma unroll
-                for (int oy = 0; oy < DW_BH; ++oy) {
-                    const int gy = y0 + sy * DW_BH + oy;
-                    if (gy >= g.H) continue;
+    for (int item = blockIdx.x; item < a.items && (int)blockIdx.x < a.geff; item += a.geff) {
+        int n, x0, c0;
+        dw_item(a, item, n, x0, c0);
+        if (c0 != cur_c0) {
+            cur_c0 = c0;
+            __syncthreads();
+            dw_load_coefs(lds_cx, x.scale, x.shift, nullptr, 2, a.C, c0, cblk);
+            dw_load_coefs(lds_cd, nullptr, nullptr, d.coef, 5, a.C, c0, cblk);
+        }
+        const size_t coloff = (size_t)sxi * DW_BW * a.ps + cp;
+        for (int s = 0; s < nsteps; ++s) {
+            const int r0 = -PAD + s * DW_G;
+            __syncthreads();
+            dw_stage<KS, 1>(a, plan, ring_d, (const uint4*)d.g, (const uint4*)d.y, lds_cd, true, n, r0, DW_G, x0, c0);
+            dw_stage<KS, 0>(a, plan, ring_x, (const uint4*)x.data, nullptr, lds_cx, has_coef, n, r0, DW_G, x0, c0);
+            __syncthreads();
+            if (!active) continue;
+#pragma unroll 1
+            for (int j = 0; j < DW_G; ++j) {
+                const int oy = r0 + j - PAD;
+                if (oy < 0) continue;
+                if (oy >= a.H) break;
+                float dyc[DW_BW][2];
+                {
+                    const uint32_t* rowp = ring_d + (size_t)dw_slot(oy) * a.iw * a.ps + coloff;
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) {
-                        const int gx = x0 + sx * DW_BW + ox;
-                        if (gx >= g.W) continue;
-                        gin[((((size_t)n * g.H + gy) * g.W + gx) * g.C + ch) >> 1] = pack_bf16(acc[oy][ox][0], acc[oy][ox][1]);
+                        const uint32_t u = rowp[(ox + PAD) * a.ps];    // columns beyond W were staged as zeros
+                        dyc[ox][0] = bf_lo(u);
+                        dyc[ox][1] = bf_hi(u);
                     }
                 }
-            }
-        }
-        // ---- phase 2: wgrad.  dW[ky][kx] += sum_p dy[p] * a_win[p + (ky,kx)]
-        {
-            float dyc[DW_BH][DW_BW][2];
 #pragma unroll
-            for (int oy = 0; oy < DW_BH; ++oy)
+                for (int ky = 0; ky < KS; ++ky) {
+                    const uint32_t* rowp = ring_x + (size_t)dw_slot(oy + ky - PAD) * a.iw * a.ps + coloff;
+                    float xr[WIN_W][2];
 #pragma unroll
-                for (int ox = 0; ox < DW_BW; ++ox) {
-                    const uint32_t u = td32[base + ((oy + PAD) * g.iw + ox + PAD) * g.cpw];
-                    dyc[oy][ox][0] = bf_lo(u);
-                    dyc[oy][ox][1] = bf_hi(u);
-                }
-#pragma unroll
-            for (int r = 0; r < WIN_H; ++r) {
-                float xr[WIN_W][2];
-#pragma unroll
-                for (int xx = 0; xx < WIN_W; ++xx) {
-                    const uint32_t u = tx32[base + (r * g.iw + xx) * g.cpw];
-                    xr[xx][0] = bf_lo(u);
-                    xr[xx][1] = bf_hi(u);
-                }
-#pragma unroll
-                for (int oy = 0; oy < DW_BH; ++oy) {
-                    const int ky = r - oy;
-                    if (ky < 0 || ky >= KS) continue;
+                    for (int xx = 0; xx < WIN_W; ++xx) {
+                        const uint32_t u = rowp[xx * a.ps];
+                        xr[xx][0] = bf_lo(u);
+                        xr[xx][1] = bf_hi(u);
+                    }
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
                         for (int kx = 0; kx < KS; ++kx) {
-                            wacc[ky * KS + kx][0] = fmaf(dyc[oy][ox][0], xr[ox + kx][0], wacc[ky * KS + kx][0]);
-                            wacc[ky * KS + kx][1] = fmaf(dyc[oy][ox][1], xr[ox + kx][1], wacc[ky * KS + kx][1]);
+                            wacc[ky * KS + kx][0] = fmaf(dyc[ox][0], xr[ox + kx][0], wacc[ky * KS + kx][0]);
+                            wacc[ky * KS + kx][1] = fmaf(dyc[ox][1], xr[ox + kx][1], wacc[ky * KS + kx][1]);
                         }
                 }
             }
         }
     }
+    // every workgroup writes its WHOLE row of wpartial[nparts][k*k][C] (zeros outside its channel block)
     __syncthreads();
-    if (active && ch_ok) {
+    for (int i = tid; i < KS * KS * cblk; i += blockDim.x) lds_red[i] = 0.f;
+    __syncthreads();
+    if (active && cur_c0 >= 0 && cur_c0 + 2 * cp < a.C) {
 #pragma unroll
         for (int k = 0; k < KS * KS; ++k) {
             atomicAdd(&lds_red[k * cblk + 2 * cp], wacc[k][0]);
@@ -407,23 +413,59 @@ __global__ __launch_bounds__(256) void k_dw_bwd(DwGeom g, MnasActIn x, MnasGradI
         }
     }
     __syncthreads();
-    for (int i = tid; i < KS * KS * cblk; i += 256) {
-        const int k = i / cblk, c = c0 + i % cblk;
-        if (c < g.C) wpartial[((size_t)blockIdx.x * KS * KS + k) * g.C + c] = lds_red[i];
+    for (int i = tid; i < KS * KS * a.C; i += blockDim.x) {
+        const int k = i / a.C, c = i - k * a.C;
+        const bool own = cur_c0 >= 0 && c >= cur_c0 && c < cur_c0 + cblk;
+        wpartial[(size_t)blockIdx.x * KS * KS * a.C + i] = own ? lds_red[k * cblk + (c - cur_c0)] : 0.f;
     }
 }
 
-extern "C" int mnas_dw_bwd(const MnasDwBwd* a, void* stream) {
-    if (!a || (a->k != 3 && a->k != 5) || (a->C & 7) || a->nparts < 1) return MNAS_EINVAL;
-    DwCfg cfg;
-    if (!dw_pick_config(a->N, a->H, a->W, a->C, a->k, 2, &cfg)) return MNAS_EINVAL;
-    DwGeom g = {a->N, a->H, a->W, a->C, cfg.cpw, cfg.ni, cfg.sy, cfg.sx, cfg.tiles_y, cfg.tiles_x, cfg.groups, cfg.ih, cfg.iw};
-    const size_t lds = (size_t)(7 + a->k * a->k) * 2 * cfg.cpw * sizeof(float) + 2 * cfg.lds_tile_bytes;
-    dim3 grid(a->nparts, cfg.cblocks);
-    if (a->k == 3)
-        hipLaunchKernelGGL(k_dw_bwd<3>, grid, dim3(256), lds, (hipStream_t)stream, g, a->x, a->dy, a->w, (uint32_t*)a->gin, a->wpartial);
+static bool dw_setup(DwArgs* a, int N, int H, int W, int C, int k, int nrings, int nparts) {
+    if (!dw_pick(N, H, W, C, k, nrings, a)) return false;
+    if (nparts < a->cblocks) return false;
+    int g = nparts < a->items ? nparts : a->items;
+    a->geff = g / a->cblocks * a->cblocks;          // multiple of cblocks: item % cblocks is constant per workgroup
+    return a->geff >= a->cblocks;
+}
+
+extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
+    if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
+    DwArgs a;
+    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;
+    const size_t lds = (size_t)4 * 2 * a.cpw * sizeof(float) + (size_t)DW_RR * a.iw * a.ps * 4;
+    hipStream_t s = (hipStream_t)stream;
+    MnasGradIn nod = {nullptr, nullptr, nullptr};
+    if (c->k == 3)
+        hipLaunchKernelGGL((k_dw_conv<3, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats);
     else
-        hipLaunchKernelGGL(k_dw_bwd<5>, grid, dim3(256), lds, (hipStream_t)stream, g, a->x, a->dy, a->w, (uint32_t*)a->gin, a->wpartial);
+        hipLaunchKernelGGL((k_dw_conv<5, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats);
     MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
+    if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    MnasActIn noa = {nullptr, nullptr, nullptr};
+    {   // input gradient
+        DwArgs a;
+        if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;
+        const size_t lds = (size_t)7 * 2 * a.cpw * sizeof(float) + (size_t)DW_RR * a.iw * a.ps * 4;
+        if (c->k == 3)
+            hipLaunchKernelGGL((k_dw_conv<3, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, nullptr);
+        else
+            hipLaunchKernelGGL((k_dw_conv<5, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, nullptr);
+        MNAS_CHECK_LAUNCH();
+    }
+    {   // weight gradient
+        DwArgs a;
+        if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 2, c->nparts)) return MNAS_EINVAL;
+        const size_t lds = (size_t)(7 + c->k * c->k) * 2 * a.cpw * sizeof(float) + (size_t)2 * DW_RR * a.iw * a.ps * 4;
+        if (c->k == 3)
+            hipLaunchKernelGGL(k_dw_wgrad<3>, dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->wpartial);
+        else
+            hipLaunchKernelGGL(k_dw_wgrad<5>, dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->wpartial);
+        MNAS_CHECK_LAUNCH();
+    }
     return MNAS_OK;
 }

@@ -4,46 +4,51 @@
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm forward finalize  (ATen native_batch_norm's statistics step; mnasnet.py:55,60)
+// partial layout: float[2][C][nparts] (channel-major: one wave reads one channel's partials contiguously)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(
     const float* __restrict__ partial, int nparts, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
     float eps, int training, float* bnbuf) {
-    __shared__ double red[2][8][32];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx;
-    double s1 = 0.0, s2 = 0.0;
-    if (training && c < C) {
-        for (int p = ty; p < nparts; p += 8) {
-            s1 += (double)partial[((size_t)p * 2 + 0) * C + c];
-            s2 += (double)partial[((size_t)p * 2 + 1) * C + c];
-        }
-    }
-    red[0][ty][tx] = s1;
-    red[1][ty][tx] = s2;
-    __syncthreads();
-    if (ty == 0 && c < C) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c < C) {
         float s, t;
         if (training) {
-            for (int j = 1; j < 8; ++j) { s1 += red[0][j][tx]; s2 += red[1][j][tx]; }
+            double s1 = 0.0, s2 = 0.0;
+            const float* p1 = partial + (size_t)c * nparts;
+            const float* p2 = partial + ((size_t)C + c) * nparts;
+            for (int p = lane; p < nparts; p += 64) { s1 += (double)p1[p]; s2 += (double)p2[p]; }
+            s1 = wave_sum_d(s1);
+            s2 = wave_sum_d(s2);
             const double mean = s1 / count;
             double var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
             const double invstd = 1.0 / sqrt(var + (double)eps);
             s = (float)((double)gamma[c] * invstd);
             t = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
-            bnbuf[5 * C + c] = (float)mean;
-            bnbuf[6 * C + c] = (float)invstd;
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+            if (lane == 0) {
+                bnbuf[5 * C + c] = (float)mean;
+                bnbuf[6 * C + c] = (float)invstd;
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+            }
         } else {
             const float invstd = 1.0f / sqrtf(running_var[c] + eps);
             s = gamma[c] * invstd;
             t = beta[c] - running_mean[c] * s;
         }
-        bnbuf[0 * C + c] = s;
-        bnbuf[1 * C + c] = t;
+        if (lane == 0) {
+            bnbuf[0 * C + c] = s;
+            bnbuf[1 * C + c] = t;
+        }
     }
     if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
@@ -53,7 +58,7 @@ extern "C" int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, dou
                                     int64_t* num_batches_tracked, float momentum, float eps, int training,
                                     float* bnbuf, void* stream) {
     if (C <= 0 || (training && (!partial || nparts <= 0))) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
                        count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training,
                        bnbuf);
     MNAS_CHECK_LAUNCH();
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const uint4* __restrict__
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * C; i += 256) partial[(size_t)blockIdx.x * 2 * C + i] = red[i];
+    for (int i = tid; i < 2 * C; i += 256) partial[(size_t)i * gridDim.x + blockIdx.x] = red[i];   // [2][C][P]
 }
 
 extern "C" int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnbuf, int64_t rows, int C, int nparts,
@@ -126,20 +131,16 @@ extern "C" int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnb
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nparts, int C,
                                                          double count, float* bnbuf, float* dgamma, float* dbeta,
                                                          int accumulate) {
-    __shared__ double red[2][8][32];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int p = ty; p < nparts; p += 8) {
-            s1 += (double)partial[((size_t)p * 2 + 0) * C + c];
-            s2 += (double)partial[((size_t)p * 2 + 1) * C + c];
-        }
-    red[0][ty][tx] = s1;
-    red[1][ty][tx] = s2;
-    __syncthreads();
-    if (ty == 0 && c < C) {
-        for (int j = 1; j < 8; ++j) { s1 += red[0][j][tx]; s2 += red[1][j][tx]; }
+    const float* p1 = partial + (size_t)c * nparts;
+    const float* p2 = partial + ((size_t)C + c) * nparts;
+    for (int p = lane; p < nparts; p += 64) { s1 += (double)p1[p]; s2 += (double)p2[p]; }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane == 0) {
         const double s = bnbuf[0 * C + c], mean = bnbuf[5 * C + c], invstd = bnbuf[6 * C + c];
         const double md = s1 / count, mx = s2 / count;
         bnbuf[2 * C + c] = (float)s;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
 extern "C" int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count, float* bnbuf, float* dgamma,
                                     float* dbeta, int accumulate, void* stream) {
     if (C <= 0 || nparts <= 0) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
                        count, bnbuf, dgamma, dbeta, accumulate);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
@@ -304,13 +305,21 @@ extern "C" int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int k
 // ------------------------------------------------------------------------------------------------
 // wgrad reductions (+ relayout to the reference's [Co][Ci][kh][kw])
 // ------------------------------------------------------------------------------------------------
-__global__ void k_wgrad_finalize(const float* __restrict__ partial, int nsplit, int Co, int Ci, int taps,
-                                 float* __restrict__ grad, int accumulate) {
+__global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict__ partial, int nsplit, int Co, int Ci,
+                                                         int taps, float* __restrict__ grad, int accumulate) {
+    __shared__ float red[8][33];
     const int K = taps * Ci;
     const int total = Co * K;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        float s = 0.f;
-        for (int p = 0; p < nsplit; ++p) s += partial[(size_t)p * total + i];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    float s = 0.f;
+    if (i < total)
+        for (int p = ty; p < nsplit; p += 8) s += partial[(size_t)p * total + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < total) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += red[j][tx];
         const int co = i / K, k = i % K;
         const int tap = k / Ci, ci = k % Ci;
         float* d = grad + ((size_t)co * Ci + ci) * taps + tap;
@@ -319,19 +328,26 @@ __global__ void k_wgrad_finalize(const float* __restrict__ partial, int nsplit, 
 }
 extern "C" int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps, float* grad,
                                    int accumulate, void* stream) {
-    int blocks = (Co * Ci * taps + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = (Co * Ci * taps + 31) / 32;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, Co, Ci, taps,
                        grad, accumulate);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
-__global__ void k_dw_wgrad_finalize(const float* __restrict__ wpartial, int nparts, int C, int taps,
-                                    float* __restrict__ grad, int accumulate) {
+__global__ __launch_bounds__(256) void k_dw_wgrad_finalize(const float* __restrict__ wpartial, int nparts, int C,
+                                                            int taps, float* __restrict__ grad, int accumulate) {
+    __shared__ float red[8][33];
     const int total = C * taps;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        float s = 0.f;
-        for (int p = 0; p < nparts; ++p) s += wpartial[(size_t)p * total + i];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    float s = 0.f;
+    if (i < total)
+        for (int p = ty; p < nparts; p += 8) s += wpartial[(size_t)p * total + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < total) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += red[j][tx];
         const int tap = i / C, c = i % C;
         float* d = grad + (size_t)c * taps + tap;
         *d = (accumulate ? *d : 0.f) + s;
@@ -339,7 +355,7 @@ __global__ void k_dw_wgrad_finalize(const float* __restrict__ wpartial, int npar
 }
 extern "C" int mnas_dw_wgrad_finalize(const float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
                                       void* stream) {
-    int blocks = (C * k * k + 255) / 256;
+    const int blocks = (C * k * k + 31) / 32;
     hipLaunchKernelGGL(k_dw_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, wpartial, nparts, C, k * k,
                        grad, accumulate);
     MNAS_CHECK_LAUNCH();

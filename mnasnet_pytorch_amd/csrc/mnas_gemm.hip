@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         __syncthreads();
         for (int i = tid; i < 2 * NT * 16; i += 256) {
             const int r = i / (NT * 16), c = n0 + i % (NT * 16);
-            if (c < a.Co) a.stats[((size_t)blockIdx.x * 2 + r) * a.Co + c] = lds_red[i];
+            if (c < a.Co) a.stats[((size_t)r * a.Co + c) * gridDim.x + blockIdx.x] = lds_red[i];   // [2][Co][P]
         }
     }
 }

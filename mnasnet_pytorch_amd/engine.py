@@ -202,7 +202,7 @@ class Program:
                             [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
                 self.patch_x.append((j, 0))
             elif ci.kind == "dw":
-                nparts = max(1, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 4)))
+                nparts = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 4)))
                 fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nparts], [],
                         a_in.act_ptrs() + [ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
             else:
@@ -280,7 +280,7 @@ class Program:
                 self.patch_x_bwd = (ops, jx, 0)
                 ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
             elif ci.kind == "dw":
-                nparts = max(1, min(512, _cdiv(M * Co, 256 * 16 * 8)))
+                nparts = max(64, min(512, _cdiv(M * Co, 256 * 16 * 8)))
                 gin = new((N, Hi, Wi, ci.cin))
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts], [],
                         a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()])

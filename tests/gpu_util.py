@@ -49,7 +49,7 @@ def conv_gemm(mode, N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, w, bias=None, act
               nparts=64, stats=False):
     lib = L.load()
     out = torch.empty((N, Ho, Wo, Co), dtype=torch.bfloat16, device="cuda")
-    st = torch.full((nparts, 2, Co), float("nan"), device="cuda") if stats else None
+    st = torch.full((2, Co, nparts), float("nan"), device="cuda") if stats else None
     a = L.MnasConvGemm()
     a.mode, a.N, a.Hi, a.Wi, a.Ci, a.Ho, a.Wo, a.Co = mode, N, Hi, Wi, Ci, Ho, Wo, Co
     a.kh = a.kw = k

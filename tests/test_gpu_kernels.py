@@ -24,12 +24,12 @@ def _x(shape, seed):
 @pytest.mark.parametrize("C_,nparts,count", [(16, 7, 100.0), (48, 64, 3211264.0), (1152, 33, 12544.0)])
 def test_bn_fwd_finalize(C_, nparts, count):
     lib = L.load()
-    u = O.det_uniform((nparts, 2, C_), 3)
+    u = O.det_uniform((2, C_, nparts), 3)
     per = count / nparts
-    partial = torch.empty(nparts, 2, C_)
-    mean_p = 0.3 * u[:, 0]
-    partial[:, 0] = per * mean_p
-    partial[:, 1] = per * (mean_p ** 2 + 0.5 + 0.4 * u[:, 1].abs())
+    partial = torch.empty(2, C_, nparts)          # channel-major partial layout
+    mean_p = 0.3 * u[0]
+    partial[0] = per * mean_p
+    partial[1] = per * (mean_p ** 2 + 0.5 + 0.4 * u[1].abs())
     gamma, beta = 1 + 0.2 * O.det_uniform((C_,), 4), 0.1 * O.det_uniform((C_,), 5)
     rm, rv = 0.1 * O.det_uniform((C_,), 6), 1 + 0.3 * O.det_uniform((C_,), 7).abs()
     d = lambda t: t.clone().cuda()
@@ -38,7 +38,7 @@ def test_bn_fwd_finalize(C_, nparts, count):
     bn = torch.zeros(8, C_, device="cuda")
     L.check(lib.mnas_bn_fwd_finalize(dp.data_ptr(), nparts, C_, count, dg.data_ptr(), db.data_ptr(), drm.data_ptr(),
                                      drv.data_ptr(), nbt.data_ptr(), 0.1, 1e-5, 1, bn.data_ptr(), L.cur_stream()))
-    S1, S2 = partial[:, 0].double().sum(0), partial[:, 1].double().sum(0)
+    S1, S2 = partial[0].double().sum(-1), partial[1].double().sum(-1)
     mean = S1 / count
     var = S2 / count - mean * mean
     invstd = 1 / torch.sqrt(var + 1e-5)
@@ -80,7 +80,7 @@ def test_pw_fwd(shape, virt):
     out, st = conv_gemm(0, N, H, W, Ci, H, W, Co, 1, 1, 0, pack(w, L.PACK_FWD), bias.cuda(),
                         act=act_in(xd, dsc if virt else None, dsh if virt else None), nparts=13, stats=True)
     assert relerr(from_nhwc(out), ref) < TOL_BF16
-    st = st.cpu().double().sum(0)
+    st = st.cpu().double().sum(-1)
     assert relerr(st[0], ref.double().sum((0, 2, 3))) < TOL_F32
     assert relerr(st[1], (ref.double() ** 2).sum((0, 2, 3))) < TOL_F32
 
@@ -105,7 +105,7 @@ def test_dense_fwd(shape):
     out, st = conv_gemm(0, N, H, W, Ci, Ho, Wo, Co, 3, s, 1, pack(w, L.PACK_FWD), bias.cuda(),
                         act=act_in(xd, dsc, dsh), nparts=5, stats=True)
     assert relerr(from_nhwc(out), ref) < TOL_BF16
-    st = st.cpu().double().sum(0)
+    st = st.cpu().double().sum(-1)
     assert relerr(st[0], ref.double().sum((0, 2, 3))) < TOL_F32
     assert relerr(st[1], (ref.double() ** 2).sum((0, 2, 3))) < TOL_F32
 
@@ -209,16 +209,16 @@ def test_dw_fwd(shape):
     ref = F.conv2d(a, w, bias, padding=k // 2, groups=C_)
     xd, dsc, dsh, db = nhwc(x), sc.cuda(), sh.cuda(), bias.cuda()
     wp = pack(w, L.PACK_DW)
-    nparts = 6
+    nparts = 40         # >= number of channel blocks (C/64)
     out = torch.empty((N, H, W, C_), dtype=torch.bfloat16, device="cuda")
-    st = torch.full((nparts, 2, C_), float("nan"), device="cuda")
+    st = torch.full((2, C_, nparts), float("nan"), device="cuda")
     a_ = L.MnasDwFwd()
     a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts = N, H, W, C_, k, nparts
     a_.in_ = act_in(xd, dsc, dsh)
     a_.w, a_.bias, a_.out, a_.stats = wp.data_ptr(), db.data_ptr(), out.data_ptr(), st.data_ptr()
     L.check(lib.mnas_dw_fwd(C.byref(a_), L.cur_stream()), "dw_fwd")
     assert relerr(from_nhwc(out), ref) < TOL_BF16
-    st = st.cpu().double().sum(0)
+    st = st.cpu().double().sum(-1)
     assert relerr(st[0], ref.double().sum((0, 2, 3))) < TOL_F32
     assert relerr(st[1], (ref.double() ** 2).sum((0, 2, 3))) < TOL_F32
 
@@ -238,7 +238,7 @@ def test_dw_bwd(shape):
     ref_dw = torch.nn.grad.conv2d_weight(a, (C_, 1, k, k), dy, padding=k // 2, groups=C_)
     xd, gd, yd, bd, dsc, dsh = nhwc(x), nhwc(g), nhwc(y), b.cuda(), sc.cuda(), sh.cuda()
     wp = pack(w, L.PACK_DW)
-    nparts = 5
+    nparts = 37
     gin = torch.empty((N, H, W, C_), dtype=torch.bfloat16, device="cuda")
     wpart = torch.full((nparts, k * k, C_), float("nan"), device="cuda")
     a_ = L.MnasDwBwd()
@@ -267,14 +267,14 @@ def test_stem(shape):
     wp = pack(w.view(Co, 27, 1, 1), L.PACK_FWD)
     nparts = 9
     out = torch.empty((N, Ho, Wo, Co), dtype=torch.bfloat16, device="cuda")
-    st = torch.full((nparts, 2, Co), float("nan"), device="cuda")
+    st = torch.full((2, Co, nparts), float("nan"), device="cuda")
     a = L.MnasStemFwd()
     a.N, a.H, a.W, a.Ho, a.Wo, a.Co, a.nparts = N, H, W, Ho, Wo, Co, nparts
     db = bias.cuda()
     a.x, a.w, a.bias, a.out, a.stats = xd.data_ptr(), wp.data_ptr(), db.data_ptr(), out.data_ptr(), st.data_ptr()
     L.check(lib.mnas_stem_fwd(C.byref(a), L.cur_stream()), "stem_fwd")
     assert relerr(from_nhwc(out), ref) < TOL_BF16
-    st = st.cpu().double().sum(0)
+    st = st.cpu().double().sum(-1)
     assert relerr(st[0], ref.double().sum((0, 2, 3))) < TOL_F32
     # wgrad
     g, y = _x((N, Co, Ho, Wo), 6), _x((N, Co, Ho, Wo), 7)
@@ -300,14 +300,14 @@ def test_bn_bwd(C_, rows):
     b = rand_bn_coefs(C_, 9, O)
     gd, yd, bd = g.to(torch.bfloat16).cuda(), y.to(torch.bfloat16).cuda(), b.clone().cuda()
     nparts = 7
-    partial = torch.full((nparts, 2, C_), float("nan"), device="cuda")
+    partial = torch.full((2, C_, nparts), float("nan"), device="cuda")
     L.check(lib.mnas_bn_bwd_reduce(gd.data_ptr(), yd.data_ptr(), bd.data_ptr(), rows, C_, nparts, partial.data_ptr(),
                                    L.cur_stream()))
     s, t, mean, invstd = b[0], b[1], b[5], b[6]
     dz = (g * ((s * y + t) > 0)).double()
     xhat = ((y - mean) * invstd).double()
     S1, S2 = dz.sum(0), (dz * xhat).sum(0)
-    p = partial.cpu().double().sum(0)
+    p = partial.cpu().double().sum(-1)
     assert relerr(p[0], S1) < 1e-4 and relerr(p[1], S2) < 1e-4
     dgamma = torch.full((C_,), 2.0, device="cuda")
     dbeta = torch.full((C_,), 3.0, device="cuda")
@@ -380,7 +380,7 @@ def test_run_ops_batch():
     wp = torch.empty(lib.mnas_packed_bytes(L.PACK_FWD, Co, Ci, 1, 1), dtype=torch.uint8, device="cuda")
     out = torch.empty((N, H, W, Co), dtype=torch.bfloat16, device="cuda")
     nparts = 4
-    st = torch.empty((nparts, 2, Co), device="cuda")
+    st = torch.empty((2, Co, nparts), device="cuda")
     gamma, beta = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
     rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
     bn = torch.zeros(8, Co, device="cuda")

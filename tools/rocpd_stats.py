@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / %.
+usage: rocpd_stats.py results.db [steps] > profiles/<name>.txt      (steps: divide totals to get per-step)"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    rows = cur.execute("select s.display_name, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
+                       "max(s.arch_vgpr_count), max(d.group_segment_size) from `%s` d join `%s` s on d.kernel_id=s.id "
+                       "group by s.display_name order by 3 desc" % (kd, ks)).fetchall()
+    t0, t1 = cur.execute("select min(start), max(end) from `%s`" % kd).fetchone()
+    tot = sum(r[2] for r in rows)
+    print("# rocprofv3 --kernel-trace summary of %s" % sys.argv[1])
+    print("# kernels busy %.3f ms total over a %.3f ms span; divided by %g steps below" % (tot / 1e6, (t1 - t0) / 1e6, steps))
+    print("%-86s %8s %12s %10s %10s %10s %6s %5s %7s" % ("kernel", "calls", "ms/step", "avg_us", "min_us", "max_us", "%", "vgpr", "lds"))
+    for name, n, s, mn, mx, vg, lds in rows:
+        nm = name if len(name) <= 86 else name[:83] + "..."
+        print("%-86s %8.1f %12.3f %10.2f %10.2f %10.2f %6.2f %5s %7s" % (nm, n / steps, s / 1e6 / steps, s / n / 1e3, mn / 1e3, mx / 1e3,
+                                                                    100.0 * s / tot, vg, lds))
+
+
+if __name__ == "__main__":
+    main()
