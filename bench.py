@@ -165,6 +165,7 @@ def main():
                  L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
                  L.OP_ADD_ACT: "k_add_act"}
         agg = {}
+        detail = []
         for (tag, opc, ints), msv in eng.read_profile():
             key = names[opc] + ("" if opc != L.OP_CONV_GEMM else ("<dgrad>" if ints[0] == 1 else "<fwd>"))
             if opc == L.OP_CONV_GEMM:       # i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,...
@@ -192,6 +193,7 @@ def main():
                 flops = 2.0 * N_ * Ho * Wo * Co * 27
             a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
             a[0] += msv; a[1] += nbytes; a[2] += flops; a[3] += 1
+            detail.append((key, ints[:10], msv, nbytes))
         # every step re-records the same event pairs, so what is read here is the LAST timed step
         tot = sum(a[0] for a in agg.values())
         name, (tms, nb, fl, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
@@ -206,6 +208,10 @@ def main():
                                      "TFLOPps": round(v[2] / max(v[0], 1e-9) / 1e9, 1), "launches": v[3]}
                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         res["bracketed_ms_per_step"] = round(tot, 3)
+        if os.environ.get("MNAS_BENCH_DETAIL"):
+            for key, ints, msv, nb in detail:
+                sys.stderr.write("%-18s %-48s %8.1f us %8.1f GB/s\n" % (key, ",".join(map(str, ints)), msv * 1e3,
+                                                                      nb / max(msv, 1e-9) / 1e6))
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(res))

@@ -38,35 +38,36 @@ struct DwArgs {
 
 static bool dw_pick(int N, int H, int W, int C, int k, int nrings, DwArgs* a) {
     const int cps = C / 2;
-    // channel block: whole pixel if it fits a workgroup sensibly, else >= 32 pairs (128 B runs)
-    int cpw;
-    if (cps <= 72) cpw = cps;
-    else {
-        cpw = 32;
-        for (int c = 32; c <= 64; c += 4)           // prefer an exact divisor of C/2
-            if (cps % c == 0) { cpw = c; break; }
-    }
-    const int cgn = cpw / 4;
-    const int ps = (cpw % 32 == 0) ? cpw : cpw + 4;
-    int best_sx = 0; double best = -1.0;
+    // Search (channel pairs per workgroup, column strips).  Whole pixel when it fits (cps <= 72), otherwise channel
+    // blocks of >= 32 pairs (>= 128-byte runs per pixel).  Score = lane utilisation x occupancy / halo.
+    int best_sx = 0, best_cpw = 0; double best = -1.0;
     const int maxsx = (W + DW_BW - 1) / DW_BW;
-    for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
-        const int tw = sx * DW_BW, iw = tw + k - 1;
-        const size_t lds = (size_t)nrings * DW_RR * iw * ps * 4;
-        if (lds > 56 * 1024) continue;
-        const int nth = ((sx * cpw + 63) / 64) * 64;
-        const int rc = iw * cgn;
-        const int tcol = (nth / cgn) * cgn;
-        if (rc > DW_MAXCOL * tcol) continue;
-        const int strips = (W + tw - 1) / tw;
-        const double util = (double)W / (strips * tw) * (double)(sx * cpw) / nth;
-        const double halo = (double)iw / tw;
-        const double score = util / (0.6 + 0.4 * halo);
-        if (score > best) { best = score; best_sx = sx; }
+    for (int cpw = 4; cpw <= 128 && cpw <= cps; cpw += 4) {
+        if (cps <= 72) { if (cpw != cps) continue; }
+        else if (cpw < 32) continue;
+        const int cblocks = (cps + cpw - 1) / cpw;
+        const int cgn = cpw / 4;
+        const int ps = (cpw % 32 == 0) ? cpw : cpw + 4;
+        for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
+            const int tw = sx * DW_BW, iw = tw + k - 1;
+            const size_t lds = (size_t)nrings * DW_RR * iw * ps * 4;
+            if (lds > 56 * 1024) continue;
+            const int nth = ((sx * cpw + 63) / 64) * 64;
+            const int rc = iw * cgn;
+            const int tcol = (nth / cgn) * cgn;
+            if (rc > DW_MAXCOL * tcol) continue;
+            const int strips = (W + tw - 1) / tw;
+            const double util = (double)W / (strips * tw) * (double)(sx * cpw) / nth * (double)cps / (cblocks * cpw);
+            const double halo = (double)iw / tw;
+            const double occ = 0.55 + 0.45 * nth / 256.0;        // tiny workgroups starve the CU of waves
+            const double score = util * occ / (0.6 + 0.4 * halo);
+            if (score > best) { best = score; best_sx = sx; best_cpw = cpw; }
+        }
     }
     if (best_sx == 0) return false;
+    const int cpw = best_cpw, cgn = cpw / 4;
     a->N = N; a->H = H; a->W = W; a->C = C;
-    a->cpw = cpw; a->sx = best_sx; a->cgn = cgn; a->ps = ps;
+    a->cpw = cpw; a->sx = best_sx; a->cgn = cgn; a->ps = (cpw % 32 == 0) ? cpw : cpw + 4;
     a->nthreads = ((best_sx * cpw + 63) / 64) * 64;
     a->iw = best_sx * DW_BW + k - 1;
     a->strips_x = (W + best_sx * DW_BW - 1) / (best_sx * DW_BW);

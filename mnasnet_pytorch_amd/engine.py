@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_STATS_PARTS = 1024          # persistent pixel-workgroups for conv kernels / rows of the stats scratch
+_STATS_PARTS = 2048          # persistent pixel-workgroups for conv kernels / rows of the stats scratch
 
 
 def _cdiv(a, b):
@@ -195,14 +195,14 @@ class Program:
             bn = bnbuf(ci.cout)
             conv, bnm = ci.mod.conv, ci.mod.bn
             bias = conv.bias.data_ptr() if conv.bias is not None else None
-            nparts = max(1, min(_STATS_PARTS, _cdiv(M, 128)))
+            nparts = max(1, min(1024, _cdiv(M, 128)))
             stats = eng.scratch_stats.data_ptr() if training else None
             if ci.kind == "stem":
                 j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts], [],
                             [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
                 self.patch_x.append((j, 0))
             elif ci.kind == "dw":
-                nparts = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 4)))
+                nparts = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 2)))
                 fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nparts], [],
                         a_in.act_ptrs() + [ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
             else:
@@ -269,7 +269,7 @@ class Program:
             M = N * Ho * Wo
             bnm = ci.mod.bn
             gy = [g.data_ptr(), out.data.data_ptr(), out.bn.data_ptr()]
-            nred = max(1, min(_STATS_PARTS, _cdiv(M * Co, 256 * 8 * 8)))
+            nred = max(1, min(1024, _cdiv(M * Co, 256 * 8 * 8)))
             ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), eng.scratch_stats.data_ptr()])
             ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
                     [eng.scratch_stats.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
@@ -280,7 +280,7 @@ class Program:
                 self.patch_x_bwd = (ops, jx, 0)
                 ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
             elif ci.kind == "dw":
-                nparts = max(64, min(512, _cdiv(M * Co, 256 * 16 * 8)))
+                nparts = max(64, min(1024, _cdiv(M * Co, 256 * 16 * 2)))
                 gin = new((N, Hi, Wi, ci.cin))
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts], [],
                         a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()])
@@ -295,7 +295,7 @@ class Program:
                 if need_gin:
                     gin = new((N, Hi, Wi, ci.cin))
                     Min = N * Hi * Wi
-                    nparts = max(1, min(_STATS_PARTS, _cdiv(Min, 128)))
+                    nparts = max(1, min(1024, _cdiv(Min, 128)))
                     ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
                             [None, None, None] + gy + [ci.w_dgrad.data_ptr(), None,
                                                        resid.data_ptr() if resid is not None else None,
@@ -475,7 +475,7 @@ class Engine:
                 wmax = max(wmax, max(1, _cdiv(1024, slabs)) * ci.cout * K)
             elif ci.kind == "dw":
                 ci.w_fwd = torch.empty(nbytes(L.PACK_DW, ci.cout, 1, ci.k, ci.k), dtype=torch.uint8, device=device)
-                wmax = max(wmax, 512 * ci.k * ci.k * ci.cout)
+                wmax = max(wmax, 1024 * ci.k * ci.k * ci.cout)
             else:
                 ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, 27, 1, 1), dtype=torch.uint8, device=device)
                 wmax = max(wmax, 512 * ci.cout * 27)
