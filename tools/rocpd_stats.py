@@ -26,5 +26,35 @@ def main():
                                                                     100.0 * s / tot, vg, lds))
 
 
+
+
+def pmc_main(path, steps):
+    """Per-kernel sum of every collected PMC counter: rocpd_stats.py --pmc results.db [steps]"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    pe = [t for t in tabs if "pmc_event" in t][0]
+    pi = [t for t in tabs if "info_pmc" in t][0]
+    cols_pe = [r[1] for r in cur.execute("pragma table_info(`%s`)" % pe)]
+    cols_pi = [r[1] for r in cur.execute("pragma table_info(`%s`)" % pi)]
+    print("# pmc_event columns:", cols_pe)
+    print("# info_pmc columns:", cols_pi)
+    namecol = "name" if "name" in cols_pi else cols_pi[-1]
+    q = ("select s.display_name, p.%s, count(*), sum(e.value) from `%s` e join `%s` p on e.pmc_id=p.id "
+         "join `%s` d on e.event_id=d.event_id join `%s` s on d.kernel_id=s.id group by s.display_name, p.%s order by 4 desc"
+         % (namecol, pe, pi, kd, ks, namecol))
+    print("# per-kernel PMC sums, divided by %g steps" % steps)
+    print("%-86s %-14s %8s %16s" % ("kernel", "counter", "calls", "sum/step"))
+    for name, cname, n, v in cur.execute(q):
+        nm = name if len(name) <= 86 else name[:83] + "..."
+        print("%-86s %-14s %8.1f %16.1f" % (nm, cname, n / steps, (v or 0) / steps))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--pmc":
+    pmc_main(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
+    sys.exit(0)
+
 if __name__ == "__main__":
     main()
