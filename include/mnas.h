@@ -83,6 +83,12 @@ typedef struct MnasConvGemm {
     const void*  resid;      /* bf16 (N,Ho,Wo,Co) or NULL */
     void*        out;        /* bf16 (N,Ho,Wo,Co) */
     float*       stats;      /* or NULL */
+    /* mode 1 only, optional: fuse the NEXT BatchNorm-backward reduction into this kernel's epilogue.  `out` is the
+     * gradient g of some ConvBlock's activated output; red_y is that ConvBlock's saved raw output (same shape as
+     * out), red_bn its bnbuf.  stats then receives float[2][Co][nparts] partial (sum dz, sum dz*xhat), exactly what
+     * mnas_bn_bwd_reduce would produce from (out, red_y, red_bn). */
+    const void*  red_y;
+    const float* red_bn;
 } MnasConvGemm;
 int mnas_conv_gemm(const MnasConvGemm* a, void* stream);
 
@@ -126,6 +132,10 @@ typedef struct MnasDwBwd {
     const float* w;          /* fp32 [k*k][C] */
     void*  gin;              /* bf16 (N,H,W,C): dL/d act(x) */
     float* wpartial;         /* float[nparts][k*k][C], fully overwritten */
+    /* optional fused BatchNorm-backward reduction for the producer of x (x.data = its raw output, red_bn = its
+     * bnbuf): red_partial receives float[2][C][nparts] (sum dz, sum dz*xhat) of (gin, x.data) */
+    const float* red_bn;
+    float* red_partial;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
 /* grad[c][0][kh][kw] (+)= sum_p wpartial[p][tap][c] */
@@ -211,7 +221,7 @@ typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];
     double  d[4];
-    void*   p[12];
+    void*   p[16];
 } MnasOp;
 /* Field use per opcode is documented next to mnas_run_ops in csrc/mnas_abi.hip. Stops at the first error
  * and returns it (index of the failing op in *failed_at if non-NULL). */

@@ -26,7 +26,7 @@ class MnasConvGemm(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("stride", C.c_int32), ("pad", C.c_int32), ("nparts", C.c_int32), ("reserved", C.c_int32),
                 ("act", MnasActIn), ("grad", MnasGradIn), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p),
-                ("out", c_void_p), ("stats", c_void_p)]
+                ("out", c_void_p), ("stats", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p)]
 
 
 class MnasConvWgrad(C.Structure):
@@ -44,7 +44,7 @@ class MnasDwFwd(C.Structure):
 class MnasDwBwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
-                ("wpartial", c_void_p)]
+                ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p)]
 
 
 class MnasStemFwd(C.Structure):
@@ -59,7 +59,7 @@ class MnasStemWgrad(C.Structure):
 
 
 class MnasOp(C.Structure):
-    _fields_ = [("opcode", C.c_int32), ("i", C.c_int32 * 15), ("d", C.c_double * 4), ("p", c_void_p * 12)]
+    _fields_ = [("opcode", C.c_int32), ("i", C.c_int32 * 15), ("d", C.c_double * 4), ("p", c_void_p * 16)]
 
 
 OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6

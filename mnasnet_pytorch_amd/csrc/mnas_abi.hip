@@ -7,11 +7,11 @@ extern "C" const char* mnas_arch(void) { return "gfx950"; }
 
 // Field use per opcode (i = op.i, d = op.d, p = op.p):
 //  CONV_GEMM        i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw,stride,pad,nparts
-//                   p: act.data,act.scale,act.shift, grad.g,grad.y,grad.coef, w,bias,resid,out,stats
+//                   p: act.data,act.scale,act.shift, grad.g,grad.y,grad.coef, w,bias,resid,out,stats, red_y,red_bn
 //  CONV_WGRAD       i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw,stride,pad,nsplit   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, partial
 //  WGRAD_FINALIZE   i: nsplit,Co,Ci,taps,accumulate                  p: partial,grad
 //  DW_FWD           i: N,H,W,C,k,nparts      p: in.data,in.scale,in.shift, w,bias,out,stats
-//  DW_BWD           i: N,H,W,C,k,nparts      p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial
+//  DW_BWD           i: N,H,W,C,k,nparts      p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial, red_bn,red_partial
 //  DW_WGRAD_FINALIZE i: nparts,C,k,accumulate p: wpartial,grad
 //  STEM_FWD         i: N,H,W,Ho,Wo,Co,nparts p: x,w,bias,out,stats
 //  STEM_WGRAD       i: N,H,W,Ho,Wo,Co,nparts p: x, dy.g,dy.y,dy.coef, partial
@@ -32,6 +32,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.act.data = p[0]; a.act.scale = (const float*)p[1]; a.act.shift = (const float*)p[2];
             a.grad.g = p[3]; a.grad.y = p[4]; a.grad.coef = (const float*)p[5];
             a.w = p[6]; a.bias = (const float*)p[7]; a.resid = p[8]; a.out = p[9]; a.stats = (float*)p[10];
+            a.red_y = p[11]; a.red_bn = (const float*)p[12];
             return mnas_conv_gemm(&a, stream);
         }
         case MNAS_OP_CONV_WGRAD: {
@@ -58,6 +59,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = (const float*)p[6]; a.gin = p[7]; a.wpartial = (float*)p[8];
+            a.red_bn = (const float*)p[9]; a.red_partial = (float*)p[10];
             return mnas_dw_bwd(&a, stream);
         }
         case MNAS_OP_DW_WGRAD_FINALIZE:

@@ -205,7 +205,8 @@ __device__ __forceinline__ void dw_load_coefs(float* lds_c, const float* r0, con
 template <int KS, int MODE>
 __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_conv(DwArgs a, MnasActIn in, MnasGradIn d,
                                                                     const float* __restrict__ w, const float* __restrict__ bias,
-                                                                    uint32_t* __restrict__ out, float* __restrict__ stats) {
+                                                                    uint32_t* __restrict__ out, float* __restrict__ stats,
+                                                                    const uint32_t* __restrict__ red_y, const float* __restrict__ red_bn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1, CROWS = (MODE == 0) ? 2 : 5;
     const int cblk = 2 * a.cpw;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     int cur_c0 = -1;
     float wt[KS * KS][2], b0 = 0.f, b1 = 0.f;
+    float rs[2] = {0.f, 0.f}, rt[2] = {0.f, 0.f}, ris[2] = {0.f, 0.f}, rmu[2] = {0.f, 0.f};   // fused BN-bwd reduce coefs
     const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
     const uint4* src0 = (const uint4*)(MODE == 0 ? in.data : d.g);
     const uint4* src1 = (const uint4*)(MODE == 0 ? nullptr : d.y);
@@ -241,6 +243,15 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
             }
             b0 = (MODE == 0 && bias && ch_ok) ? bias[ch] : 0.f;
             b1 = (MODE == 0 && bias && ch_ok) ? bias[ch + 1] : 0.f;
+            if (MODE == 1 && red_y && ch_ok) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    rs[e] = red_bn[0 * a.C + ch + e];
+                    rt[e] = red_bn[1 * a.C + ch + e];
+                    ris[e] = red_bn[6 * a.C + ch + e];
+                    rmu[e] = -red_bn[5 * a.C + ch + e] * ris[e];
+                }
+            }
             __syncthreads();
             if (MODE == 0) dw_load_coefs(lds_c, in.scale, in.shift, nullptr, 2, a.C, c0, cblk);
             else dw_load_coefs(lds_c, nullptr, nullptr, d.coef, 5, a.C, c0, cblk);
@@ -266,6 +277,14 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
                 const int iy = r0 + j;
                 if (iy >= a.H + PAD) break;
                 const uint32_t* rowp = colp + (size_t)dw_slot(iy) * a.iw * a.ps;
+                const int oy = iy - PAD;             // A[0] is complete after this row
+                // fused reduce: fetch the target's raw outputs for the row we are about to emit; lands under the FMAs
+                uint32_t ypre[DW_BW];
+                if (MODE == 1 && red_y && oy >= 0 && ch_ok) {
+                    const uint32_t* yp = red_y + (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2 + (size_t)oy * a.W * a.C / 2;
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) ypre[ox] = (gx0 + ox < a.W) ? yp[(size_t)ox * a.C / 2] : 0u;
+                }
                 float xr[WIN_W][2];
 #pragma unroll
                 for (int x = 0; x < WIN_W; ++x) {
@@ -282,7 +301,6 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
                             A[i][ox][0] = fmaf(wt[(KS - 1 - i) * KS + kx][0], xr[ox + kx][0], A[i][ox][0]);
                             A[i][ox][1] = fmaf(wt[(KS - 1 - i) * KS + kx][1], xr[ox + kx][1], A[i][ox][1]);
                         }
-                const int oy = iy - PAD;             // A[0] is complete
                 if (oy >= 0 && ch_ok) {
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) {
@@ -292,7 +310,16 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
                                 s1[0] += v0; s2[0] = fmaf(v0, v0, s2[0]);
                                 s1[1] += v1; s2[1] = fmaf(v1, v1, s2[1]);
                             }
-                            outp[((size_t)oy * a.W + ox) * a.C / 2] = pack_bf16(v0, v1);
+                            const uint32_t pk = pack_bf16(v0, v1);
+                            outp[((size_t)oy * a.W + ox) * a.C / 2] = pk;
+                            if (MODE == 1 && red_y) {      // fused BN-backward reduce for the producer of x
+                                const uint32_t yv = ypre[ox];
+                                const float g0 = bf_lo(pk), g1 = bf_hi(pk), y0 = bf_lo(yv), y1 = bf_hi(yv);
+                                const float dz0 = (fmaf(y0, rs[0], rt[0]) > 0.f) ? g0 : 0.f;
+                                const float dz1 = (fmaf(y1, rs[1], rt[1]) > 0.f) ? g1 : 0.f;
+                                s1[0] += dz0; s2[0] = fmaf(dz0, fmaf(y0, ris[0], rmu[0]), s2[0]);
+                                s1[1] += dz1; s2[1] = fmaf(dz1, fmaf(y1, ris[1], rmu[1]), s2[1]);
+                            }
                         }
                     }
                 }
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
             }
         }
     }
-    if (MODE == 0 && stats) {
+    if ((MODE == 0 || red_y) && stats) {
         // every workgroup writes its WHOLE column of the [2][C][nparts] table: its own channel block's sums,
         // zeros elsewhere (idle workgroups: all zeros), so no memset is needed and the finalize sum is exact
         __syncthreads();
@@ -437,9 +464,9 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MnasGradIn nod = {nullptr, nullptr, nullptr};
     if (c->k == 3)
-        hipLaunchKernelGGL((k_dw_conv<3, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats);
+        hipLaunchKernelGGL((k_dw_conv<3, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((k_dw_conv<5, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats);
+        hipLaunchKernelGGL((k_dw_conv<5, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats, nullptr, nullptr);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -448,14 +475,15 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     MnasActIn noa = {nullptr, nullptr, nullptr};
+    const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
     {   // input gradient
         DwArgs a;
         if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;
         const size_t lds = (size_t)7 * 2 * a.cpw * sizeof(float) + (size_t)DW_RR * a.iw * a.ps * 4;
         if (c->k == 3)
-            hipLaunchKernelGGL((k_dw_conv<3, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, nullptr);
+            hipLaunchKernelGGL((k_dw_conv<3, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, red ? c->red_partial : nullptr, red ? (const uint32_t*)c->x.data : nullptr, c->red_bn);
         else
-            hipLaunchKernelGGL((k_dw_conv<5, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, nullptr);
+            hipLaunchKernelGGL((k_dw_conv<5, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, red ? c->red_partial : nullptr, red ? (const uint32_t*)c->x.data : nullptr, c->red_bn);
         MNAS_CHECK_LAUNCH();
     }
     {   // weight gradient

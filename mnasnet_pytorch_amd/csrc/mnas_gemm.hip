@@ -30,6 +30,8 @@ struct IgemmArgs {
     const void* resid;
     void* out;
     float* stats;
+    const void* red_y;       // MODE 1: fused BN-backward reduce target (raw output of the ConvBlock whose g we produce)
+    const float* red_bn;
 };
 
 template <int MODE, int NT, int PT>
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     const int ccols = (a.taps == 1) ? kch : a.Ci;  // coefficient columns kept in LDS
     float* lds_coef = (float*)smem;                                        // [CROWS][ccols]
     float* lds_red = lds_coef + CROWS * ccols;                             // [2][NT*16]
-    uint16_t* lds_w = (uint16_t*)(lds_red + 2 * NT * 16);                  // [NT*16][ldk]
+    float* lds_redc = lds_red + 2 * NT * 16;                               // [4][NT*16] fused-reduce coefficients
+    uint16_t* lds_w = (uint16_t*)(lds_redc + 4 * NT * 16);                 // [NT*16][ldk]
     uint16_t* lds_a = lds_w + NT * 16 * ldk;                               // [BP][ldk]
 
     const int tid = threadIdx.x;
@@ -173,6 +176,21 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    // fused BN-backward reduce (MODE 1): per-channel (s, t, invstd, -mean*invstd) of the target layer in LDS
+    const bool do_red = (MODE == 1) && a.red_y != nullptr;
+    if (do_red) {
+        for (int i = tid; i < 4 * NT * 16; i += 256) {
+            const int r = i / (NT * 16), co = n0 + i % (NT * 16);
+            float v = 0.f;
+            if (co < a.Co) {
+                if (r == 0) v = a.red_bn[0 * a.Co + co];
+                else if (r == 1) v = a.red_bn[1 * a.Co + co];
+                else if (r == 2) v = a.red_bn[6 * a.Co + co];
+                else v = -a.red_bn[5 * a.Co + co] * a.red_bn[6 * a.Co + co];
+            }
+            lds_redc[i] = v;
+        }
+    }
 
     if (nkc == 1) {       // weights + coefficients are tile-invariant: stage once
         load_coefs(0);
@@ -190,6 +208,20 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+        // fused reduce: fetch the target layer's raw outputs for this tile's fragments now; they land under the K loop
+        uint2 ypre[PT][NT];
+        if (do_red) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int m = tile0 + (wave * PT + pt) * 16 + l15;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = n0 + nt * 16 + lg * 4;
+                    ypre[pt][nt] = make_uint2(0, 0);
+                    if (m < a.M && co < a.Co) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + (size_t)m * a.Co + co);
+                }
+            }
+        }
         for (int kc = 0; kc < nkc; ++kc) {
             const int k0 = kc * kch;
             __syncthreads();                       // previous chunk's fragments consumed
@@ -239,11 +271,29 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                 pk.x = pack_bf16(v[0], v[1]);
                 pk.y = pack_bf16(v[2], v[3]);
                 *(uint2*)((uint16_t*)a.out + o) = pk;
+                if (do_red) {
+                    // fused BN-backward reduce for the layer whose activated output this gradient belongs to:
+                    // dz = g*[s*y+t>0] (g as stored, i.e. bf16-rounded), xhat = y*invstd - mean*invstd
+                    const uint2 yv = ypre[pt][nt];
+                    const float gq[4] = {bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y)};
+                    const float yq[4] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y)};
+                    const int cl = nt * 16 + lg * 4;
+                    const float4 cs = *(const float4*)(lds_redc + cl), ct = *(const float4*)(lds_redc + NT * 16 + cl);
+                    const float4 ci = *(const float4*)(lds_redc + 2 * NT * 16 + cl), cm = *(const float4*)(lds_redc + 3 * NT * 16 + cl);
+                    const float rs_[4] = {cs.x, cs.y, cs.z, cs.w}, rt_[4] = {ct.x, ct.y, ct.z, ct.w};
+                    const float ri_[4] = {ci.x, ci.y, ci.z, ci.w}, rm_[4] = {cm.x, cm.y, cm.z, cm.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dz = (fmaf(yq[r], rs_[r], rt_[r]) > 0.f) ? gq[r] : 0.f;
+                        s1[nt][r] += dz;
+                        s2[nt][r] = fmaf(dz, fmaf(yq[r], ri_[r], rm_[r]), s2[nt][r]);
+                    }
+                }
             }
         }
     }
 
-    if (MODE != 1 && a.stats) {
+    if ((MODE != 1 || do_red) && a.stats) {
         __syncthreads();
         for (int i = tid; i < 2 * NT * 16; i += 256) lds_red[i] = 0.f;
         __syncthreads();
@@ -271,7 +321,7 @@ template <int MODE, int NT, int PT>
 static int launch_igemm(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
     constexpr int CROWS = (MODE == 1) ? 5 : 2;
     const int ccols = (a.taps == 1) ? a.kch : a.Ci;
-    const size_t lds = (size_t)(CROWS * ccols + 2 * NT * 16) * sizeof(float) +
+    const size_t lds = (size_t)(CROWS * ccols + 6 * NT * 16) * sizeof(float) +
                        (size_t)(NT * 16 + 64 * PT) * (a.kch + 8) * 2;
     if (lds > 160 * 1024) return MNAS_EINVAL;
     hipLaunchKernelGGL((k_igemm<MODE, NT, PT>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
@@ -294,6 +344,8 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     a.co_pad16 = (c->Co + 15) / 16 * 16;
     a.act = c->act; a.grad = c->grad;
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = c->resid; a.out = c->out; a.stats = c->stats;
+    a.red_y = (c->mode == 1) ? c->red_y : nullptr; a.red_bn = c->red_bn;
+    if (a.red_y && (!a.red_bn || !a.stats)) return MNAS_EINVAL;
     if (a.taps != 1 && c->Ci > 1024) return MNAS_EINVAL;
     if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;   // strided / padded 1x1 does not occur in this network
     if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
@@ -336,6 +388,7 @@ extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     a.act.data = c->x; a.act.scale = nullptr; a.act.shift = nullptr;
     a.grad.g = nullptr; a.grad.y = nullptr; a.grad.coef = nullptr;
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = nullptr; a.out = c->out; a.stats = c->stats;
+    a.red_y = nullptr; a.red_bn = nullptr;
     const int tiles = (c->Co + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     if (tiles == 1) return launch_igemm<2, 1, 2>(a, c->nparts, 1, s);

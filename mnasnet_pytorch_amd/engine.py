@@ -261,19 +261,28 @@ class Program:
         j = seg(last_stage).add(L.OP_NCHW_TO_NHWC, [N, cur.C, cur.H * cur.W], [], [None, g_final.data_ptr()])
         self.patch_gout = (last_stage, j, 0)
 
-        def conv_bwd(ops: _OpList, rec, g, resid, need_gin):
-            """Backward of one ConvBlock application.  g: bf16 grad wrt its activated output.  Returns the
-            bf16 grad wrt its (activated) input, or None."""
+        def conv_bwd(ops: _OpList, rec, g, resid, need_gin, g_reduced=False, red_target=None):
+            """Backward of one ConvBlock application.  g: bf16 grad wrt its activated output.
+            g_reduced: the producer of g already wrote this layer's BN-backward partial sums into
+            eng.scratch_red (fused epilogue) with `g_reduced` columns.  red_target: (y, bn, C) of the ConvBlock
+            whose activated output is THIS layer's input -- the dgrad epilogue then does that reduce.
+            Returns (gin, ncols) : bf16 grad wrt the (activated) input or None, and the number of partial
+            columns written for red_target (0 if not fused)."""
             _, ci, a_in, out, Hi, Wi = rec
             Ho, Wo, Co = out.H, out.W, ci.cout
             M = N * Ho * Wo
-            bnm = ci.mod.bn
             gy = [g.data_ptr(), out.data.data_ptr(), out.bn.data_ptr()]
-            nred = max(1, min(1024, _cdiv(M * Co, 256 * 8 * 8)))
-            ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), eng.scratch_stats.data_ptr()])
+            if g_reduced:
+                nred = g_reduced
+                red_buf = eng.scratch_red
+            else:
+                nred = max(1, min(1024, _cdiv(M * Co, 256 * 8 * 8)))
+                red_buf = eng.scratch_stats
+                ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), red_buf.data_ptr()])
             ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
-                    [eng.scratch_stats.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
-            gin = None
+                    [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
+            gin, ncols = None, 0
+            rt = red_target if (red_target is not None and need_gin) else None
             if ci.kind == "stem":
                 nsp = max(1, min(512, _cdiv(M, 1024)))
                 jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()])
@@ -282,8 +291,12 @@ class Program:
             elif ci.kind == "dw":
                 nparts = max(64, min(1024, _cdiv(M * Co, 256 * 16 * 2)))
                 gin = new((N, Hi, Wi, ci.cin))
+                red = [None, None]
+                if rt is not None:
+                    red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
+                    ncols = nparts
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts], [],
-                        a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()])
+                        a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()] + red)
                 ops.add(L.OP_DW_WGRAD_FINALIZE, [nparts, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
             else:
                 K = ci.k * ci.k * ci.cin
@@ -296,35 +309,62 @@ class Program:
                     gin = new((N, Hi, Wi, ci.cin))
                     Min = N * Hi * Wi
                     nparts = max(1, min(1024, _cdiv(Min, 128)))
+                    red = [None, None, None]
+                    if rt is not None:
+                        red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
+                        ncols = nparts
                     ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
                             [None, None, None] + gy + [ci.w_dgrad.data_ptr(), None,
                                                        resid.data_ptr() if resid is not None else None,
-                                                       gin.data_ptr(), None])
+                                                       gin.data_ptr(), red[0], red[1], red[2]])
             if ci.kind == "dw" and resid is not None:
                 raise AssertionError("residual add into a depthwise dgrad does not occur")
-            return gin
+            return gin, ncols
+
+        def target_of(act: Optional[_Act]):
+            """(raw y tensor, bnbuf) of the ConvBlock that produced a VIRTUAL activation, else None."""
+            if act is None or act.bn is None:
+                return None
+            return (act.data, act.bn)
 
         g = g_final
+        g_red = 0            # number of fused-reduce partial columns already written for the layer g belongs to
         self.patch_x_bwd = None
         for si in range(len(step_records) - 1, -1, -1):
             kind, stage, start, a_in, a_out = step_records[si]
             ops = seg(stage)
             first = si == 0
+            # what produced the step's INPUT: a ConvBlock (virtual act) or a block's residual sum / the network input
             if kind == "conv":
                 rec = records[start]
                 need = (not first) or (need_dx and not self.x_is_image)
-                g = conv_bwd(ops, rec, g, None, need)
+                if rec[2] is not None and rec[2].bn is None and si > 0 and step_records[si - 1][0] == "block":
+                    # input is the previous block's materialised sum r: its gradient G feeds that block's project conv
+                    prev_p = records[step_records[si - 1][2] + 2]
+                    tgt = (prev_p[3].data, prev_p[3].bn)
+                else:
+                    tgt = target_of(rec[2])
+                g, g_red = conv_bwd(ops, rec, g, None, need, g_red, tgt)
             else:
                 re_, rd, rp = records[start], records[start + 1], records[start + 2]
                 G = g                                   # grad wrt the block output (materialised sum)
-                g2 = conv_bwd(ops, rp, G, None, True)
-                g1 = conv_bwd(ops, rd, g2, None, True)
+                g2, c2 = conv_bwd(ops, rp, G, None, True, g_red, target_of(rp[2]))
+                g1, c1 = conv_bwd(ops, rd, g2, None, True, c2, target_of(rd[2]))
                 need = (not first) or need_dx
                 if need:
-                    g = conv_bwd(ops, re_, g1, G, True)   # + skip-connection gradient fused in the epilogue
+                    # expand dgrad (+ skip gradient fused in its epilogue) produces the gradient of the block INPUT:
+                    # either a virtual activation (producer conv) or the previous block's sum (-> its project conv)
+                    if a_in.bn is not None:
+                        tgt = target_of(a_in)
+                    elif si > 0 and step_records[si - 1][0] == "block":
+                        prev_p = records[step_records[si - 1][2] + 2]
+                        tgt = (prev_p[3].data, prev_p[3].bn)
+                    else:
+                        tgt = None
+                    g, g_red = conv_bwd(ops, re_, g1, G, True, c1, tgt)
                 else:
-                    conv_bwd(ops, re_, g1, None, False)
-                    g = None
+                    conv_bwd(ops, re_, g1, None, False, c1, None)
+                    g, g_red = None, 0
         if need_dx and not self.x_is_image:
             Cin = self.in_channels
             j = seg(step_records[0][1]).add(L.OP_ADD_ACT, [Cin, H * W], [float(N * H * W)],
@@ -482,6 +522,7 @@ class Engine:
             smax = max(smax, ci.cout)
         self.scratch_stats = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)
         self.scratch_wgrad = torch.empty(wmax, dtype=torch.float32, device=device)
+        self.scratch_red = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)   # fused BN-bwd partials
         if self._ext_grad is not None:
             self.flat_grad = self._ext_grad
         else:

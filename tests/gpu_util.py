@@ -46,7 +46,7 @@ def pack(w, kind):
 
 
 def conv_gemm(mode, N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, w, bias=None, act=None, grad=None, resid=None,
-              nparts=64, stats=False):
+              nparts=64, stats=False, red_y=None, red_bn=None):
     lib = L.load()
     out = torch.empty((N, Ho, Wo, Co), dtype=torch.bfloat16, device="cuda")
     st = torch.full((2, Co, nparts), float("nan"), device="cuda") if stats else None
@@ -59,6 +59,7 @@ def conv_gemm(mode, N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, w, bias=None, act
     if grad is not None:
         a.grad = grad
     a.w, a.bias, a.resid, a.out, a.stats = L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(out), L.ptr(st)
+    a.red_y, a.red_bn = L.ptr(red_y), L.ptr(red_bn)
     L.check(lib.mnas_conv_gemm(C.byref(a), L.cur_stream()), "conv_gemm")
     return out, st
 

@@ -123,9 +123,20 @@ def test_pw_dgrad(shape, with_resid):
     if with_resid:
         ref = ref + resid
     gd, yd, bd, rd = nhwc(g), nhwc(y), b.cuda(), nhwc(resid)
-    out, _ = conv_gemm(1, N, H, W, Co, H, W, Ci, 1, 1, 0, pack(w, L.PACK_DGRAD), None, grad=grad_in(gd, yd, bd),
-                       resid=rd if with_resid else None, nparts=11)
+    # fused BN-backward reduce for the producer of the conv's input: (sum dz, sum dz*xhat) of (out, y_in, bn_in)
+    y_in = _x((N, Ci, H, W), 21)
+    b_in = rand_bn_coefs(Ci, 22, O)
+    yid, bid = nhwc(y_in), b_in.cuda()
+    out, st = conv_gemm(1, N, H, W, Co, H, W, Ci, 1, 1, 0, pack(w, L.PACK_DGRAD), None, grad=grad_in(gd, yd, bd),
+                        resid=rd if with_resid else None, nparts=11, stats=True, red_y=yid, red_bn=bid)
     assert relerr(from_nhwc(out), ref) < TOL_BF16
+    gq = from_nhwc(out)                                  # the reduce sees g as stored (bf16)
+    s_, t_, mu_, is_ = (b_in[i].view(1, -1, 1, 1) for i in (0, 1, 5, 6))
+    dz = (gq * ((s_ * y_in + t_) > 0)).double()
+    xhat = (y_in * is_ - mu_ * is_).double()
+    st = st.cpu().double().sum(-1)
+    assert relerr(st[0], dz.sum((0, 2, 3))) < 1e-3
+    assert relerr(st[1], (dz * xhat).sum((0, 2, 3))) < 1e-3
 
 
 @pytest.mark.parametrize("shape", DENSE)
@@ -245,8 +256,21 @@ def test_dw_bwd(shape):
     a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts = N, H, W, C_, k, nparts
     a_.x, a_.dy = act_in(xd, dsc, dsh), grad_in(gd, yd, bd)
     a_.w, a_.gin, a_.wpartial = wp.data_ptr(), gin.data_ptr(), wpart.data_ptr()
+    # fused BN-backward reduce for the producer of x (x is its raw output, b_in its bnbuf)
+    b_in = rand_bn_coefs(C_, 22, O)
+    b_in[0], b_in[1] = sc, sh                       # rows 0,1 are the same scale/shift the act-on-load uses
+    bid = b_in.cuda()
+    redp = torch.full((2, C_, nparts), float("nan"), device="cuda")
+    a_.red_bn, a_.red_partial = bid.data_ptr(), redp.data_ptr()
     L.check(lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()), "dw_bwd")
     assert relerr(from_nhwc(gin), ref_gin) < TOL_BF16
+    gq = from_nhwc(gin)
+    s_, t_, mu_, is_ = (b_in[i].view(1, -1, 1, 1) for i in (0, 1, 5, 6))
+    dz = (gq * ((s_ * x + t_) > 0)).double()
+    xhat = (x * is_ - mu_ * is_).double()
+    rp = redp.cpu().double().sum(-1)
+    assert relerr(rp[0], dz.sum((0, 2, 3))) < 1e-3
+    assert relerr(rp[1], (dz * xhat).sum((0, 2, 3))) < 1e-3
     grad = torch.full((C_, 1, k, k), float("nan"), device="cuda")
     L.check(lib.mnas_dw_wgrad_finalize(wpart.data_ptr(), nparts, C_, k, grad.data_ptr(), 0, L.cur_stream()))
     assert relerr(grad.cpu(), ref_dw) < TOL_F32
