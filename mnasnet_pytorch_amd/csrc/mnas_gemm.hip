@@ -34,14 +34,15 @@ struct IgemmArgs {
     const float* red_bn;
 };
 
-template <int MODE, int NT, int PT>
+template <int MODE, int NT, int PT, int KCH>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
     constexpr int CROWS = (MODE == 1) ? 5 : 2;
-    const int kch = a.kch;
-    const int ldk = kch + 8;                       // LDS row stride in bf16 elements (16-byte padded)
-    const int kc8n = kch >> 3;                     // 16-byte chunks per row
+    constexpr int kch = KCH;                       // K elements staged per LDS chunk (32 or 64)
+    constexpr int ldk = KCH + 8;                   // LDS row stride in bf16 elements (16-byte padded)
+    constexpr int kc8n = KCH >> 3;                 // 16-byte chunks per row
+    constexpr int KSH = (KCH == 64) ? 3 : 2;       // log2(kc8n)
     const int ccols = (a.taps == 1) ? kch : a.Ci;  // coefficient columns kept in LDS
     float* lds_coef = (float*)smem;                                        // [CROWS][ccols]
     float* lds_red = lds_coef + CROWS * ccols;                             // [2][NT*16]
@@ -70,22 +71,46 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         }
     };
     auto stage_w = [&](int k0) {
-        const int chunks = NT * 16 * kc8n;
-        for (int q = tid; q < chunks; q += 256) {
-            const int r = q / kc8n, kc8 = q % kc8n;
+        constexpr int NW = (NT * 16 * kc8n + 255) / 256;
+        uint4 v[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int q = tid + 256 * i;
+            const int r = q >> KSH, kc8 = q & (kc8n - 1);
             const int k = k0 + kc8 * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (n0 + r < a.co_pad16 && k < a.Kpad) v = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + k);
-            *(uint4*)(lds_w + r * ldk + kc8 * 8) = v;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (r < NT * 16 && n0 + r < a.co_pad16 && k < a.Kpad) v[i] = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + k);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int q = tid + 256 * i;
+            const int r = q >> KSH, kc8 = q & (kc8n - 1);
+            if (r < NT * 16) *(uint4*)(lds_w + r * ldk + kc8 * 8) = v[i];
         }
     };
+    // activation / gradient tile: each thread owns NA (pixel, k-chunk) slots; its k-chunk column is the same
+    // for all of them (256 % kc8n == 0), so the per-channel coefficients are fetched once per call, and all
+    // loads of the call are issued before the first one is consumed
     auto stage_a = [&](int tile0, int k0) {
-        const int chunks = BP * kc8n;
-        for (int q = tid; q < chunks; q += 256) {
-            const int p = q / kc8n, kc8 = q % kc8n;
-            const int k = k0 + kc8 * 8;
+        constexpr int NA = BP * kc8n / 256;
+        const int kc8 = tid & (kc8n - 1);
+        const int k = k0 + kc8 * 8;
+        const bool kok = k < a.Ktot;
+        int ci = k, th = 0, tw = 0;
+        if (!a.is_pw && MODE != 2) {
+            const int tap = k / a.Ci;
+            ci = k - tap * a.Ci;
+            th = tap / a.kw; tw = tap - th * a.kw;
+        }
+        uint4 v0[NA], v1[NA];
+        bool ok[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = (tid >> KSH) + (256 >> KSH) * i;
             const int m = tile0 + p;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            v0[i] = make_uint4(0, 0, 0, 0);
+            if (MODE == 1) v1[i] = make_uint4(0, 0, 0, 0);
+            ok[i] = false;
             if (MODE == 2) {
                 // stem (mnasnet.py:179): im2col of the fp32 NCHW image, k = ci*9 + kh*3 + kw (reference
                 // weight order), 3x3 stride 2 pad 1; Hi,Wi = image dims
@@ -98,23 +123,21 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int kk = k + j;
-                        const int ci = kk / 9, r9 = kk - ci * 9, th = r9 / 3, tw = r9 - th * 3;
-                        const int ih = oh * 2 + th - 1, iw = ow * 2 + tw - 1;
+                        const int c3 = kk / 9, r9 = kk - c3 * 9, t3 = r9 / 3, u3 = r9 - t3 * 3;
+                        const int ih = oh * 2 + t3 - 1, iw = ow * 2 + u3 - 1;
                         const bool okj = kk < 27 && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-                        f[j] = okj ? x[(((size_t)n * 3 + ci) * a.Hi + ih) * a.Wi + iw] : 0.f;
+                        f[j] = okj ? x[(((size_t)n * 3 + c3) * a.Hi + ih) * a.Wi + iw] : 0.f;
                     }
-                    v = pack8(f);
+                    v0[i] = pack8(f);
                 }
-            } else if (m < a.M && k < a.Ktot) {
-                int ci = k;
+                continue;
+            }
+            if (m < a.M && kok) {
                 size_t src;
-                bool ok = true;
+                bool inb = true;
                 if (a.is_pw) {
                     src = (size_t)m * a.Ci + k;
                 } else {
-                    const int tap = k / a.Ci;
-                    ci = k - tap * a.Ci;
-                    const int th = tap / a.kw, tw = tap - th * a.kw;
                     const int hw = a.Ho * a.Wo;
                     const int n = m / hw, rem = m - n * hw;
                     const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
@@ -124,41 +147,48 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                         iw = ow * a.stride + tw - a.pad;
                     } else {   // transposed geometry: dy pixel that this forward-input pixel fed through tap
                         const int yh = oh + a.pad - th, yw = ow + a.pad - tw;
-                        ok = (yh >= 0) && (yw >= 0) && (yh % a.stride == 0) && (yw % a.stride == 0);
+                        inb = (yh >= 0) && (yw >= 0) && (yh % a.stride == 0) && (yw % a.stride == 0);
                         ih = yh / a.stride;
                         iw = yw / a.stride;
                     }
-                    ok = ok && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    inb = inb && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
                     src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + ci;
                 }
-                if (ok) {
-                    const int cc = (a.taps == 1) ? (k - k0) : ci;
+                if (inb) {
+                    ok[i] = true;
                     if (MODE != 1) {
-                        v = *(const uint4*)((const uint16_t*)a.act.data + src);
-                        if (has_coef) {
-                            float s[8], t[8];
-                            *(float4*)&s[0] = *(const float4*)(lds_coef + cc);
-                            *(float4*)&s[4] = *(const float4*)(lds_coef + cc + 4);
-                            *(float4*)&t[0] = *(const float4*)(lds_coef + ccols + cc);
-                            *(float4*)&t[4] = *(const float4*)(lds_coef + ccols + cc + 4);
-                            v = act8(v, s, t);
-                        }
+                        v0[i] = *(const uint4*)((const uint16_t*)a.act.data + src);
                     } else {
-                        const uint4 gv = *(const uint4*)((const uint16_t*)a.grad.g + src);
-                        const uint4 yv = *(const uint4*)((const uint16_t*)a.grad.y + src);
-                        float cf[5][8];
-#pragma unroll
-                        for (int r = 0; r < 5; ++r) {
-                            *(float4*)&cf[r][0] = *(const float4*)(lds_coef + r * ccols + cc);
-                            *(float4*)&cf[r][4] = *(const float4*)(lds_coef + r * ccols + cc + 4);
-                        }
-                        float o[8];
-                        dy8(gv, yv, cf[0], cf[1], cf[2], cf[3], cf[4], o);
-                        v = pack8(o);
+                        v0[i] = *(const uint4*)((const uint16_t*)a.grad.g + src);
+                        v1[i] = *(const uint4*)((const uint16_t*)a.grad.y + src);
                     }
                 }
             }
-            *(uint4*)(lds_a + p * ldk + kc8 * 8) = v;
+        }
+        if (MODE != 2 && has_coef) {
+            const int cc = (a.taps == 1) ? (k - k0) : ci;
+            float cf[CROWS][8];
+#pragma unroll
+            for (int r = 0; r < CROWS; ++r) {
+                *(float4*)&cf[r][0] = *(const float4*)(lds_coef + r * ccols + cc);
+                *(float4*)&cf[r][4] = *(const float4*)(lds_coef + r * ccols + cc + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (!ok[i]) continue;
+                if (MODE == 0) {
+                    v0[i] = act8(v0[i], cf[0], cf[1]);
+                } else if (MODE == 1) {
+                    float o[8];
+                    dy8(v0[i], v1[i], cf[0], cf[1], cf[2 % CROWS], cf[3 % CROWS], cf[4 % CROWS], o);
+                    v0[i] = pack8(o);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = (tid >> KSH) + (256 >> KSH) * i;
+            *(uint4*)(lds_a + p * ldk + kc8 * 8) = v0[i];
         }
     };
 
@@ -317,16 +347,21 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     }
 }
 
-template <int MODE, int NT, int PT>
-static int launch_igemm(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
+template <int MODE, int NT, int PT, int KCH>
+static int launch_igemm_k(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
     constexpr int CROWS = (MODE == 1) ? 5 : 2;
     const int ccols = (a.taps == 1) ? a.kch : a.Ci;
     const size_t lds = (size_t)(CROWS * ccols + 6 * NT * 16) * sizeof(float) +
                        (size_t)(NT * 16 + 64 * PT) * (a.kch + 8) * 2;
     if (lds > 160 * 1024) return MNAS_EINVAL;
-    hipLaunchKernelGGL((k_igemm<MODE, NT, PT>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
+}
+template <int MODE, int NT, int PT>
+static int launch_igemm(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
+    return a.kch == 64 ? launch_igemm_k<MODE, NT, PT, 64>(a, nparts, nblocks, stream)
+                       : launch_igemm_k<MODE, NT, PT, 32>(a, nparts, nblocks, stream);
 }
 
 extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
@@ -351,15 +386,22 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
     if (c->mode == 1 && (!c->grad.g || !c->grad.y || !c->grad.coef)) return MNAS_EINVAL;
 
-    // cout tiling: NT*16 channels per workgroup column, minimising padded tiles then blocks
+    // cout tiling: NT*16 channels per workgroup column.  Up to 8 tiles: one block (the activation tile is staged
+    // once).  Wider outputs: several blocks of <= 6 tiles (NT = 8 with 128-pixel tiles needs > 200 VGPRs and halves
+    // occupancy -- measured slower than re-staging the small-K activation tile), fewest padded tiles first.
     const int tiles = (c->Co + 15) / 16;
-    static const int opts[] = {8, 6, 4, 3, 2, 1};
     int best_nt = 1, best_waste = 1 << 30, best_blocks = 1 << 30;
-    for (int nt : opts) {
-        const int blocks = (tiles + nt - 1) / nt;
-        const int waste = blocks * nt - tiles;
-        if (waste < best_waste || (waste == best_waste && blocks < best_blocks)) {
-            best_nt = nt; best_waste = waste; best_blocks = blocks;
+    if (tiles <= 8) {
+        static const int opts1[] = {1, 2, 3, 4, 6, 8};
+        for (int nt : opts1) if (nt >= tiles) { best_nt = nt; best_blocks = 1; break; }
+    } else {
+        static const int opts[] = {6, 4, 3};
+        for (int nt : opts) {
+            const int blocks = (tiles + nt - 1) / nt;
+            const int waste = blocks * nt - tiles;
+            if (waste < best_waste || (waste == best_waste && blocks < best_blocks)) {
+                best_nt = nt; best_waste = waste; best_blocks = blocks;
+            }
         }
     }
     const int nblocks = best_blocks;
@@ -391,8 +433,8 @@ extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     a.red_y = nullptr; a.red_bn = nullptr;
     const int tiles = (c->Co + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    if (tiles == 1) return launch_igemm<2, 1, 2>(a, c->nparts, 1, s);
-    if (tiles == 2) return launch_igemm<2, 2, 2>(a, c->nparts, 1, s);
-    if (tiles <= 4) return launch_igemm<2, 4, 2>(a, c->nparts, 1, s);
-    return launch_igemm<2, 8, 2>(a, c->nparts, 1, s);
+    if (tiles == 1) return launch_igemm_k<2, 1, 2, 32>(a, c->nparts, 1, s);
+    if (tiles == 2) return launch_igemm_k<2, 2, 2, 32>(a, c->nparts, 1, s);
+    if (tiles <= 4) return launch_igemm_k<2, 4, 2, 32>(a, c->nparts, 1, s);
+    return launch_igemm_k<2, 8, 2, 32>(a, c->nparts, 1, s);
 }
