@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
 }
 
 // ---- weight gradient: dW[ky][kx][c] = sum_p dy[p][c] * act(x)[p + (ky-PAD, kx-PAD)][c] --------------------------
-// At image row iy: dy row o = iy - PAD (centre columns) x activation rows o-PAD..o+PAD = iy-2PAD..iy (all in the ring).
+// Streamed: at image row iy the dy row iy (centre columns) enters a register ring D[0..KS-1] (D[q] = dy row iy-q) and
+// the activation row r = iy-PAD is read once; it pairs with dy rows r-ky+PAD = iy-ky = D[ky].  12 LDS dwords per row.
 template <int KS>
 __global__ __launch_bounds__(256, 2) void k_dw_wgrad(DwArgs a, MnasActIn x, MnasGradIn d,
                                                                      float* __restrict__ wpartial) {
@@ -386,6 +387,11 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(DwArgs a, MnasActIn x, Mnas
             dw_load_coefs(lds_cd, nullptr, nullptr, d.coef, 5, a.C, c0, cblk);
         }
         const size_t coloff = (size_t)sxi * DW_BW * a.ps + cp;
+        float D[KS][DW_BW][2];          // register ring of the last KS dy rows (centre columns)
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+#pragma unroll
+            for (int ox = 0; ox < DW_BW; ++ox) { D[q][ox][0] = 0.f; D[q][ox][1] = 0.f; }
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * DW_G;
             __syncthreads();
@@ -395,37 +401,42 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(DwArgs a, MnasActIn x, Mnas
             if (!active) continue;
 #pragma unroll 1
             for (int j = 0; j < DW_G; ++j) {
-                const int oy = r0 + j - PAD;
-                if (oy < 0) continue;
-                if (oy >= a.H) break;
-                float dyc[DW_BW][2];
+                const int iy = r0 + j;
+                if (iy >= a.H + PAD) break;
+                // D[q] = centre columns of dy row (iy - q); rotate the ring and read the new row iy
+#pragma unroll
+                for (int q = KS - 1; q > 0; --q)
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) { D[q][ox][0] = D[q - 1][ox][0]; D[q][ox][1] = D[q - 1][ox][1]; }
                 {
-                    const uint32_t* rowp = ring_d + (size_t)dw_slot(oy) * a.iw * a.ps + coloff;
+                    const uint32_t* rowp = ring_d + (size_t)dw_slot(iy) * a.iw * a.ps + coloff;
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) {
-                        const uint32_t u = rowp[(ox + PAD) * a.ps];    // columns beyond W were staged as zeros
-                        dyc[ox][0] = bf_lo(u);
-                        dyc[ox][1] = bf_hi(u);
+                        const uint32_t u = rowp[(ox + PAD) * a.ps];    // rows/columns outside the image were staged as zeros
+                        D[0][ox][0] = bf_lo(u);
+                        D[0][ox][1] = bf_hi(u);
                     }
                 }
+                // activation row r = iy - PAD pairs with dy rows o = r - ky + PAD = iy - ky  (ky = 0..KS-1) -> D[ky]
+                const int r = iy - PAD;
+                if (r < -PAD) continue;
+                const uint32_t* rowp = ring_x + (size_t)dw_slot(r) * a.iw * a.ps + coloff;
+                float xr[WIN_W][2];
 #pragma unroll
-                for (int ky = 0; ky < KS; ++ky) {
-                    const uint32_t* rowp = ring_x + (size_t)dw_slot(oy + ky - PAD) * a.iw * a.ps + coloff;
-                    float xr[WIN_W][2];
+                for (int xx = 0; xx < WIN_W; ++xx) {
+                    const uint32_t u = rowp[xx * a.ps];
+                    xr[xx][0] = bf_lo(u);
+                    xr[xx][1] = bf_hi(u);
+                }
 #pragma unroll
-                    for (int xx = 0; xx < WIN_W; ++xx) {
-                        const uint32_t u = rowp[xx * a.ps];
-                        xr[xx][0] = bf_lo(u);
-                        xr[xx][1] = bf_hi(u);
-                    }
+                for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
                         for (int kx = 0; kx < KS; ++kx) {
-                            wacc[ky * KS + kx][0] = fmaf(dyc[ox][0], xr[ox + kx][0], wacc[ky * KS + kx][0]);
-                            wacc[ky * KS + kx][1] = fmaf(dyc[ox][1], xr[ox + kx][1], wacc[ky * KS + kx][1]);
+                            wacc[ky * KS + kx][0] = fmaf(D[ky][ox][0], xr[ox + kx][0], wacc[ky * KS + kx][0]);
+                            wacc[ky * KS + kx][1] = fmaf(D[ky][ox][1], xr[ox + kx][1], wacc[ky * KS + kx][1]);
                         }
-                }
             }
         }
     }
