@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     constexpr int kch = KCH;                       // K elements staged per LDS chunk (32 or 64)
     constexpr int ldk = KCH + 8;                   // LDS row stride in bf16 elements (16-byte padded)
     constexpr int kc8n = KCH >> 3;                 // 16-byte chunks per row
-    constexpr int KSH = (KCH == 64) ? 3 : 2;       // log2(kc8n)
+    constexpr int KSH = (KCH == 128) ? 4 : (KCH == 64) ? 3 : 2;       // log2(kc8n)
     const int ccols = (a.taps == 1) ? kch : a.Ci;  // coefficient columns kept in LDS
     float* lds_coef = (float*)smem;                                        // [CROWS][ccols]
     float* lds_red = lds_coef + CROWS * ccols;                             // [2][NT*16]
@@ -360,7 +360,12 @@ static int launch_igemm_k(const IgemmArgs& a, int nparts, int nblocks, hipStream
 }
 template <int MODE, int NT, int PT>
 static int launch_igemm(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
-    return a.kch == 64 ? launch_igemm_k<MODE, NT, PT, 64>(a, nparts, nblocks, stream)
+    // long reductions on small pixel counts (the 14x14 / 7x7 stages, dense 3x3): 128-wide K chunks put 4x more
+    // bytes in flight per staging pass (these launches are latency-bound, not bandwidth-bound)
+    if constexpr (PT == 1 && (NT == 2 || NT == 3 || NT == 6)) {
+        if (a.kch == 128) return launch_igemm_k<MODE, NT, PT, 128>(a, nparts, nblocks, stream);
+    }
+    return a.kch >= 64 ? launch_igemm_k<MODE, NT, PT, 64>(a, nparts, nblocks, stream)
                        : launch_igemm_k<MODE, NT, PT, 32>(a, nparts, nblocks, stream);
 }
 
@@ -407,6 +412,7 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     const int nblocks = best_blocks;
     // PT=2 (128-pixel tiles) when there are enough tiles to fill the chip twice over
     const int pt = ((int64_t)a.M * nblocks >= (int64_t)128 * 1024) ? 2 : 1;
+    if (pt == 1 && a.Kpad >= 256 && (best_nt == 2 || best_nt == 3 || best_nt == 6)) a.kch = 128;
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_IG(MODE_, NT_) \
     if (c->mode == MODE_ && best_nt == NT_) return pt == 2 ? launch_igemm<MODE_, NT_, 2>(a, c->nparts, nblocks, s) \

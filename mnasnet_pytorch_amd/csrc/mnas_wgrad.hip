@@ -66,6 +66,28 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
             const int r = i / xcols, c = (a.taps == 1 ? kc0 : 0) + i % xcols;
             lds_cx[i] = (c < a.Ci) ? (r == 0 ? a.x.scale[c] : a.x.shift[c]) : 0.f;
         }
+    // both tiles start zeroed: staging only ever writes the VALID 16-byte chunks of a row (cwd / cwa per row), so
+    // the padding columns of a partially filled 16-wide MFMA tile stay zero for the whole kernel
+    for (int i = tid; i < 2 * WG_BPIX * 72 / 8; i += 256) ((uint4*)tile_d)[i] = make_uint4(0, 0, 0, 0);
+
+    // ---- per-thread staging plan (tile-invariant): up to 4 (pixel, chunk) slots per tile for each operand
+    const int cwd = (con + 7) >> 3, cwa = STEM ? 4 : ((kn + 7) >> 3);
+    int pd[4], cd8[4], pa[4], ca8[4], aci[4], ath[4], atw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        pd[i] = q / cwd; cd8[i] = q - pd[i] * cwd;
+        if (pd[i] >= WG_BPIX) pd[i] = -1;
+        pa[i] = q / cwa; ca8[i] = q - pa[i] * cwa;
+        if (pa[i] >= WG_BPIX) pa[i] = -1;
+        const int k = kc0 + ca8[i] * 8;
+        aci[i] = k; ath[i] = 0; atw[i] = 0;
+        if (!STEM && !a.is_pw) {
+            const int tap = k / a.Ci;
+            aci[i] = k - tap * a.Ci;
+            ath[i] = tap / a.kw; atw[i] = tap - ath[i] * a.kw;
+        }
+    }
 
     f32x4_t acc[WG_T][WG_T];
 #pragma unroll
@@ -77,32 +99,30 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
     const int p_end = min(a.M, p_begin + a.chunk);
     for (int pc = p_begin; pc < p_end; pc += WG_BPIX) {
         __syncthreads();
-        // ---- stage dy tile: [128 pixels][64 couts]
-        for (int q = tid; q < WG_BPIX * 8; q += 256) {
-            const int p = q >> 3, c8 = q & 7;
-            const int m = pc + p, co = co0 + c8 * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < p_end && co < a.Co) {
-                const size_t off = (size_t)m * a.Co + co;
-                const uint4 gv = *(const uint4*)((const uint16_t*)a.dy.g + off);
-                const uint4 yv = *(const uint4*)((const uint16_t*)a.dy.y + off);
-                float cf[5][8];
+        // ---- issue every load of this 128-pixel chunk first: dy operands (g, y) and the activation operand
+        uint4 vg[4], vy[4], vx[4];
+        bool okd[4], oka[4];
 #pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    *(float4*)&cf[r][0] = *(const float4*)(lds_cd + r * 64 + c8 * 8);
-                    *(float4*)&cf[r][4] = *(const float4*)(lds_cd + r * 64 + c8 * 8 + 4);
+        for (int i = 0; i < 4; ++i) {
+            okd[i] = false;
+            vg[i] = make_uint4(0, 0, 0, 0); vy[i] = make_uint4(0, 0, 0, 0);
+            if (pd[i] >= 0) {
+                const int m = pc + pd[i];
+                if (m < p_end) {
+                    okd[i] = true;
+                    const size_t off = (size_t)m * a.Co + co0 + cd8[i] * 8;
+                    vg[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
+                    vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
                 }
-                float o[8];
-                dy8(gv, yv, cf[0], cf[1], cf[2], cf[3], cf[4], o);
-                v = pack8(o);
             }
-            *(uint4*)(tile_d + p * ldd + c8 * 8) = v;
         }
-        // ---- stage activation tile: [128 pixels][64 k columns], gathered per tap for kxk
-        for (int q = tid; q < WG_BPIX * 8; q += 256) {
-            const int p = q >> 3, c8 = q & 7;
-            const int m = pc + p, k = kc0 + c8 * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            oka[i] = false;
+            vx[i] = make_uint4(0, 0, 0, 0);
+            if (pa[i] < 0) continue;
+            const int m = pc + pa[i];
+            const int k = kc0 + ca8[i] * 8;
             if (STEM) {
                 // im2col of the fp32 NCHW image: k = ci*9 + kh*3 + kw (reference weight order)
                 if (m < p_end && k < 32) {
@@ -114,44 +134,64 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int kk = k + j;
-                        const int ci = kk / 9, r9 = kk - ci * 9, th = r9 / 3, tw = r9 - th * 3;
-                        const int ih = oh * 2 + th - 1, iw = ow * 2 + tw - 1;
+                        const int c3 = kk / 9, r9 = kk - c3 * 9, t3 = r9 / 3, u3 = r9 - t3 * 3;
+                        const int ih = oh * 2 + t3 - 1, iw = ow * 2 + u3 - 1;
                         const bool okj = kk < 27 && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-                        f[j] = okj ? x[(((size_t)n * 3 + ci) * a.Hi + ih) * a.Wi + iw] : 0.f;
+                        f[j] = okj ? x[(((size_t)n * 3 + c3) * a.Hi + ih) * a.Wi + iw] : 0.f;
                     }
-                    v = pack8(f);
+                    vx[i] = pack8(f);
                 }
             } else if (m < p_end && k < a.Ktot) {
-                int ci = k;
                 size_t src;
-                bool ok = true;
+                bool inb = true;
                 if (a.is_pw) {
                     src = (size_t)m * a.Ci + k;
                 } else {
-                    const int tap = k / a.Ci;
-                    ci = k - tap * a.Ci;
-                    const int th = tap / a.kw, tw = tap - th * a.kw;
                     const int hw = a.Ho * a.Wo;
                     const int n = m / hw, rem = m - n * hw;
                     const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                    const int ih = oh * a.stride + th - a.pad, iw = ow * a.stride + tw - a.pad;
-                    ok = ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-                    src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + ci;
+                    const int ih = oh * a.stride + ath[i] - a.pad, iw = ow * a.stride + atw[i] - a.pad;
+                    inb = ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + aci[i];
                 }
-                if (ok) {
-                    v = *(const uint4*)((const uint16_t*)a.x.data + src);
-                    if (hasx) {
-                        const int cc = (a.taps == 1) ? c8 * 8 : ci;
-                        float s[8], t[8];
-                        *(float4*)&s[0] = *(const float4*)(lds_cx + cc);
-                        *(float4*)&s[4] = *(const float4*)(lds_cx + cc + 4);
-                        *(float4*)&t[0] = *(const float4*)(lds_cx + xcols + cc);
-                        *(float4*)&t[4] = *(const float4*)(lds_cx + xcols + cc + 4);
-                        v = act8(v, s, t);
-                    }
+                if (inb) {
+                    oka[i] = true;
+                    vx[i] = *(const uint4*)((const uint16_t*)a.x.data + src);
                 }
             }
-            *(uint4*)(tile_a + p * lda + c8 * 8) = v;
+        }
+        // ---- transform + write
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (pd[i] < 0) continue;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (okd[i]) {
+                float cf[5][8];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    *(float4*)&cf[r][0] = *(const float4*)(lds_cd + r * 64 + cd8[i] * 8);
+                    *(float4*)&cf[r][4] = *(const float4*)(lds_cd + r * 64 + cd8[i] * 8 + 4);
+                }
+                float o[8];
+                dy8(vg[i], vy[i], cf[0], cf[1], cf[2], cf[3], cf[4], o);
+                v = pack8(o);
+            }
+            *(uint4*)(tile_d + pd[i] * ldd + cd8[i] * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (pa[i] < 0) continue;
+            uint4 v = vx[i];
+            if (hasx && oka[i]) {
+                const int cc = (a.taps == 1) ? ca8[i] * 8 : aci[i];
+                float s[8], t[8];
+                *(float4*)&s[0] = *(const float4*)(lds_cx + cc);
+                *(float4*)&s[4] = *(const float4*)(lds_cx + cc + 4);
+                *(float4*)&t[0] = *(const float4*)(lds_cx + xcols + cc);
+                *(float4*)&t[4] = *(const float4*)(lds_cx + xcols + cc + 4);
+                v = act8(v, s, t);
+            }
+            *(uint4*)(tile_a + pa[i] * lda + ca8[i] * 8) = v;
         }
         __syncthreads();
         // ---- each wave: its 32 pixels, all slab tiles
