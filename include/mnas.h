@@ -115,14 +115,18 @@ int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int ta
  * Replaces ATen conv2d fwd/bwd for ConvBlock's groups==C convs (mnasnet.py:122-125, 76-81). */
 typedef struct MnasDwFwd {
     int32_t N, H, W, C, k;
-    int32_t nparts;          /* workgroups launched = columns of `stats`; must be >= C/64 (channel blocks) */
+    int32_t nparts;          /* upper bound on workgroups; must be >= C/64 (channel blocks) */
     MnasActIn in;
     const float* w;          /* fp32 [k*k][C] (tap-major) */
     const float* bias;       /* [C] or NULL */
     void*  out;              /* bf16 (N,H,W,C) raw output */
-    float* stats;            /* float[2][C][nparts] or NULL */
+    float* stats;            /* float[2][C][rows] or NULL, rows = mnas_dw_rows(N,H,W,C,k,nparts,0) */
 } MnasDwFwd;
 int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
+/* Number of partial rows/columns a depthwise launch writes for this shape and nparts (host-side, no launch).
+ * which = 0: forward statistics and the backward launch's fused-reduce table (float[2][C][rows]);
+ * which = 1: the weight-gradient partial table (float[rows][k*k][C]).  Returns < 0 for unsupported shapes. */
+int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which);
 
 typedef struct MnasDwBwd {
     int32_t N, H, W, C, k;
@@ -131,14 +135,14 @@ typedef struct MnasDwBwd {
     MnasGradIn dy;           /* gradient of the forward output (dy-on-load) */
     const float* w;          /* fp32 [k*k][C] */
     void*  gin;              /* bf16 (N,H,W,C): dL/d act(x) */
-    float* wpartial;         /* float[nparts][k*k][C], fully overwritten */
+    float* wpartial;         /* float[rows1][k*k][C], rows1 = mnas_dw_rows(...,1), fully overwritten */
     /* optional fused BatchNorm-backward reduction for the producer of x (x.data = its raw output, red_bn = its
-     * bnbuf): red_partial receives float[2][C][nparts] (sum dz, sum dz*xhat) of (gin, x.data) */
+     * bnbuf): red_partial receives float[2][C][rows0] (sum dz, sum dz*xhat) of (gin, x.data), rows0 = mnas_dw_rows(...,0) */
     const float* red_bn;
     float* red_partial;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
-/* grad[c][0][kh][kw] (+)= sum_p wpartial[p][tap][c] */
+/* grad[c][0][kh][kw] (+)= sum_{p<nparts} wpartial[p][tap][c]   (pass nparts = rows1) */
 int mnas_dw_wgrad_finalize(const float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
                            void* stream);
 

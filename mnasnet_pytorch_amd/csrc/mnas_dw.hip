@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
         }
     }
     if ((MODE == 0 || red_y) && stats) {
-        // every workgroup writes its WHOLE column of the [2][C][nparts] table: its own channel block's sums,
-        // zeros elsewhere (idle workgroups: all zeros), so no memset is needed and the finalize sum is exact
+        // stats table is float[2][C][rows], rows = geff / cblocks: workgroup b owns column b / cblocks of its own
+        // channel block (b % cblocks), so every (channel, column) is written exactly once -- no zero fill, no atomics
         __syncthreads();
         for (int i = tid; i < 2 * cblk; i += blockDim.x) lds_red[i] = 0.f;
         __syncthreads();
@@ -343,10 +343,13 @@ __global__ __launch_bounds__(256, ((KS == 3 && MODE == 0) ? 3 : 2)) void k_dw_co
             atomicAdd(&lds_red[cblk + 2 * cp], s2[0]); atomicAdd(&lds_red[cblk + 2 * cp + 1], s2[1]);
         }
         __syncthreads();
-        for (int i = tid; i < 2 * a.C; i += blockDim.x) {
-            const int r = i / a.C, c = i - r * a.C;
-            const bool own = cur_c0 >= 0 && c >= cur_c0 && c < cur_c0 + cblk;
-            stats[(size_t)i * gridDim.x + blockIdx.x] = own ? lds_red[r * cblk + (c - cur_c0)] : 0.f;
+        if ((int)blockIdx.x < a.geff) {
+            const int rows = a.geff / a.cblocks, col = blockIdx.x / a.cblocks;
+            const int cb0 = (blockIdx.x % a.cblocks) * cblk;
+            for (int i = tid; i < 2 * cblk; i += blockDim.x) {
+                const int r = i / cblk, c = cb0 + i % cblk;
+                if (c < a.C) stats[((size_t)r * a.C + c) * rows + col] = (cur_c0 >= 0) ? lds_red[i] : 0.f;
+            }
         }
     }
 }
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(DwArgs a, MnasActIn x, Mnas
             }
         }
     }
-    // every workgroup writes its WHOLE row of wpartial[nparts][k*k][C] (zeros outside its channel block)
+    // wpartial is float[rows][k*k][C], rows = geff / cblocks: workgroup b writes row b / cblocks, its own channel block only
     __syncthreads();
     for (int i = tid; i < KS * KS * cblk; i += blockDim.x) lds_red[i] = 0.f;
     __syncthreads();
@@ -452,10 +455,13 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(DwArgs a, MnasActIn x, Mnas
         }
     }
     __syncthreads();
-    for (int i = tid; i < KS * KS * a.C; i += blockDim.x) {
-        const int k = i / a.C, c = i - k * a.C;
-        const bool own = cur_c0 >= 0 && c >= cur_c0 && c < cur_c0 + cblk;
-        wpartial[(size_t)blockIdx.x * KS * KS * a.C + i] = own ? lds_red[k * cblk + (c - cur_c0)] : 0.f;
+    if ((int)blockIdx.x < a.geff) {
+        const int row = blockIdx.x / a.cblocks;
+        const int cb0 = (blockIdx.x % a.cblocks) * cblk;
+        for (int i = tid; i < KS * KS * cblk; i += blockDim.x) {
+            const int k = i / cblk, c = cb0 + i % cblk;
+            if (c < a.C) wpartial[((size_t)row * KS * KS + k) * a.C + c] = (cur_c0 >= 0) ? lds_red[i] : 0.f;
+        }
     }
 }
 
@@ -467,6 +473,15 @@ static bool dw_setup(DwArgs* a, int N, int H, int W, int C, int k, int nrings, i
     return a->geff >= a->cblocks;
 }
 
+// rows of the partial tables a launch with `nparts` writes.  which = 0: forward statistics / the input-gradient
+// launch's fused-reduce table, float[2][C][rows]; which = 1: the weight-gradient launch, float[rows][k*k][C]
+// (it stages two rings and may pick a narrower strip, hence its own count).
+extern "C" int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which) {
+    DwArgs a;
+    if (!dw_setup(&a, N, H, W, C, k, which ? 2 : 1, nparts)) return -1;
+    return a.geff / a.cblocks;
+}
+
 extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
     DwArgs a;
@@ -475,9 +490,9 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MnasGradIn nod = {nullptr, nullptr, nullptr};
     if (c->k == 3)
-        hipLaunchKernelGGL((k_dw_conv<3, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats, nullptr, nullptr);
+        hipLaunchKernelGGL((k_dw_conv<3, 0>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((k_dw_conv<5, 0>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats, nullptr, nullptr);
+        hipLaunchKernelGGL((k_dw_conv<5, 0>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, nod, c->w, c->bias, (uint32_t*)c->out, c->stats, nullptr, nullptr);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -492,9 +507,9 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
         if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;
         const size_t lds = (size_t)7 * 2 * a.cpw * sizeof(float) + (size_t)DW_RR * a.iw * a.ps * 4;
         if (c->k == 3)
-            hipLaunchKernelGGL((k_dw_conv<3, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, red ? c->red_partial : nullptr, red ? (const uint32_t*)c->x.data : nullptr, c->red_bn);
+            hipLaunchKernelGGL((k_dw_conv<3, 1>), dim3(a.geff), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, red ? c->red_partial : nullptr, red ? (const uint32_t*)c->x.data : nullptr, c->red_bn);
         else
-            hipLaunchKernelGGL((k_dw_conv<5, 1>), dim3(c->nparts), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, red ? c->red_partial : nullptr, red ? (const uint32_t*)c->x.data : nullptr, c->red_bn);
+            hipLaunchKernelGGL((k_dw_conv<5, 1>), dim3(a.geff), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, red ? c->red_partial : nullptr, red ? (const uint32_t*)c->x.data : nullptr, c->red_bn);
         MNAS_CHECK_LAUNCH();
     }
     {   // weight gradient
@@ -502,9 +517,9 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
         if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 2, c->nparts)) return MNAS_EINVAL;
         const size_t lds = (size_t)(7 + c->k * c->k) * 2 * a.cpw * sizeof(float) + (size_t)2 * DW_RR * a.iw * a.ps * 4;
         if (c->k == 3)
-            hipLaunchKernelGGL(k_dw_wgrad<3>, dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->wpartial);
+            hipLaunchKernelGGL(k_dw_wgrad<3>, dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->wpartial);
         else
-            hipLaunchKernelGGL(k_dw_wgrad<5>, dim3(c->nparts), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->wpartial);
+            hipLaunchKernelGGL(k_dw_wgrad<5>, dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->wpartial);
         MNAS_CHECK_LAUNCH();
     }
     return MNAS_OK;

@@ -202,9 +202,12 @@ class Program:
                             [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
                 self.patch_x.append((j, 0))
             elif ci.kind == "dw":
-                nparts = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 2)))
-                fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nparts], [],
+                nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 2)))
+                fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nlaunch], [],
                         a_in.act_ptrs() + [ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
+                nparts = lib.mnas_dw_rows(N, Hi, Wi, ci.cout, ci.k, nlaunch, 0)      # columns of the stats table
+                if nparts < 1:
+                    raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, ci.cout, ci.k),))
             else:
                 fwd.add(L.OP_CONV_GEMM, [0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
                         a_in.act_ptrs() + [None, None, None, ci.w_fwd.data_ptr(), bias, None, y.data_ptr(), stats])
@@ -294,10 +297,13 @@ class Program:
                 red = [None, None]
                 if rt is not None:
                     red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
-                    ncols = nparts
+                    ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 0)
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts], [],
                         a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()] + red)
-                ops.add(L.OP_DW_WGRAD_FINALIZE, [nparts, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
+                wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1)
+                if wrows < 1 or (rt is not None and ncols < 1):
+                    raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, Co, ci.k),))
+                ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
             else:
                 K = ci.k * ci.k * ci.cin
                 slabs = _cdiv(Co, 64) * _cdiv(K, 64)

@@ -222,7 +222,9 @@ def test_dw_fwd(shape):
     wp = pack(w, L.PACK_DW)
     nparts = 40         # >= number of channel blocks (C/64)
     out = torch.empty((N, H, W, C_), dtype=torch.bfloat16, device="cuda")
-    st = torch.full((2, C_, nparts), float("nan"), device="cuda")
+    rows = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 0)
+    assert 1 <= rows <= nparts
+    st = torch.full((2, C_, rows), float("nan"), device="cuda")
     a_ = L.MnasDwFwd()
     a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts = N, H, W, C_, k, nparts
     a_.in_ = act_in(xd, dsc, dsh)
@@ -251,7 +253,8 @@ def test_dw_bwd(shape):
     wp = pack(w, L.PACK_DW)
     nparts = 37
     gin = torch.empty((N, H, W, C_), dtype=torch.bfloat16, device="cuda")
-    wpart = torch.full((nparts, k * k, C_), float("nan"), device="cuda")
+    rows0, rows1 = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 0), lib.mnas_dw_rows(N, H, W, C_, k, nparts, 1)
+    wpart = torch.full((rows1, k * k, C_), float("nan"), device="cuda")
     a_ = L.MnasDwBwd()
     a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts = N, H, W, C_, k, nparts
     a_.x, a_.dy = act_in(xd, dsc, dsh), grad_in(gd, yd, bd)
@@ -260,7 +263,7 @@ def test_dw_bwd(shape):
     b_in = rand_bn_coefs(C_, 22, O)
     b_in[0], b_in[1] = sc, sh                       # rows 0,1 are the same scale/shift the act-on-load uses
     bid = b_in.cuda()
-    redp = torch.full((2, C_, nparts), float("nan"), device="cuda")
+    redp = torch.full((2, C_, rows0), float("nan"), device="cuda")
     a_.red_bn, a_.red_partial = bid.data_ptr(), redp.data_ptr()
     L.check(lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()), "dw_bwd")
     assert relerr(from_nhwc(gin), ref_gin) < TOL_BF16
@@ -272,7 +275,7 @@ def test_dw_bwd(shape):
     assert relerr(rp[0], dz.sum((0, 2, 3))) < 1e-3
     assert relerr(rp[1], (dz * xhat).sum((0, 2, 3))) < 1e-3
     grad = torch.full((C_, 1, k, k), float("nan"), device="cuda")
-    L.check(lib.mnas_dw_wgrad_finalize(wpart.data_ptr(), nparts, C_, k, grad.data_ptr(), 0, L.cur_stream()))
+    L.check(lib.mnas_dw_wgrad_finalize(wpart.data_ptr(), rows1, C_, k, grad.data_ptr(), 0, L.cur_stream()))
     assert relerr(grad.cpu(), ref_dw) < TOL_F32
 
 
