@@ -161,13 +161,15 @@ def main():
     }
     # ---- roofline of the dominant kernel class ---------------------------------------------------
     if profile:
-        names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_fwd", L.OP_DW_BWD: "k_dw_bwd",
+        names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_conv<fwd>", L.OP_DW_BWD: "k_dw_bwd",
                  L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
                  L.OP_ADD_ACT: "k_add_act"}
         agg = {}
         detail = []
         for (tag, opc, ints), msv in eng.read_profile():
             key = names[opc] + ("" if opc != L.OP_CONV_GEMM else ("<dgrad>" if ints[0] == 1 else "<fwd>"))
+            if opc == L.OP_DW_BWD:          # i: N,H,W,C,k,nparts,phase (1 = input gradient, 2 = weight gradient launch)
+                key = "k_dw_conv<dgrad>" if ints[6] == 1 else ("k_dw_wgrad" if ints[6] == 2 else "k_dw_bwd")
             if opc == L.OP_CONV_GEMM:       # i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,...
                 _, N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:8]
                 e_in, e_out = N_ * Hi * Wi * Ci, N_ * Ho * Wo * Co
@@ -181,8 +183,12 @@ def main():
             elif opc in (L.OP_DW_FWD, L.OP_DW_BWD):
                 N_, H_, W_, C_, k_ = ints[:5]
                 e = N_ * H_ * W_ * C_
-                nbytes = 2 * (2 * e if opc == L.OP_DW_FWD else 4 * e)
-                flops = 2.0 * e * k_ * k_ * (1 if opc == L.OP_DW_FWD else 2)
+                if opc == L.OP_DW_FWD:
+                    nbytes, flops = 2 * 2 * e, 2.0 * e * k_ * k_
+                elif ints[6] == 0:
+                    nbytes, flops = 2 * 4 * e, 4.0 * e * k_ * k_
+                else:       # each backward launch reads (g, y) and one more tensor / writes gin: 3 tensors
+                    nbytes, flops = 2 * 3 * e, 2.0 * e * k_ * k_
             elif opc == L.OP_BN_BWD_REDUCE:
                 nbytes, flops = 0, 0.0     # pure overhead in SURVEY 8(d)'s accounting (reads g and y again)
             elif opc == L.OP_ADD_ACT:
@@ -202,7 +208,9 @@ def main():
                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                            "launches_per_step": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
                            "ms_per_step": round(tms, 3), "share_of_bracketed_time": round(tms / tot, 3),
-                           "note": "HIP events around every launch of this kernel class, last timed step"}
+                           "note": "HIP events around every launch of this kernel class, last timed step; weight-gradient "
+                                   "kernels run on a second stream concurrently with the input-gradient chain, so a "
+                                   "launch's duration includes the bandwidth it shares with its neighbour"}
         res["kernel_classes"] = {k: {"ms_per_step": round(v[0], 3), "algorithmic_GB": round(v[1] / 1e9, 3),
                                      "GBps": round(v[1] / max(v[0], 1e-9) / 1e6, 1), "TFLOP": round(v[2] / 1e12, 4),
                                      "TFLOPps": round(v[2] / max(v[0], 1e-9) / 1e9, 1), "launches": v[3]}

@@ -140,6 +140,9 @@ typedef struct MnasDwBwd {
      * bnbuf): red_partial receives float[2][C][rows0] (sum dz, sum dz*xhat) of (gin, x.data), rows0 = mnas_dw_rows(...,0) */
     const float* red_bn;
     float* red_partial;
+    int32_t phase;           /* 0: both launches; 1: input gradient only; 2: weight gradient only (lets the caller put
+                                the two on different streams) */
+    int32_t reserved;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
 /* grad[c][0][kh][kw] (+)= sum_{p<nparts} wpartial[p][tap][c]   (pass nparts = rows1) */
@@ -220,7 +223,8 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_ADD_ACT 12
 #define MNAS_OP_NCHW_TO_NHWC 13
 #define MNAS_OP_PACK_WEIGHTS 14
-#define MNAS_OP_EVENT_RECORD 15    /* p[0] = event handle from mnas_event_create: hipEventRecord on `stream` */
+#define MNAS_OP_EVENT_RECORD 15    /* p[0] = event handle from mnas_event_create: hipEventRecord on the op's stream */
+#define MNAS_OP_EVENT_WAIT 16      /* p[0] = event handle: hipStreamWaitEvent(op's stream, event) */
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];
@@ -230,6 +234,10 @@ typedef struct MnasOp {
 /* Field use per opcode is documented next to mnas_run_ops in csrc/mnas_abi.hip. Stops at the first error
  * and returns it (index of the failing op in *failed_at if non-NULL). */
 int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_at);
+/* Same, over several streams: op.i[14] selects streams[op.i[14]] (0 <= i[14] < nstreams).  Ordering between
+ * streams is expressed with MNAS_OP_EVENT_RECORD / MNAS_OP_EVENT_WAIT ops.  Used to run the weight-gradient
+ * kernels of a layer concurrently with the input-gradient chain (they only share read-only inputs). */
+int mnas_run_ops_multi(const MnasOp* ops, int n, void* const* streams, int nstreams, int* failed_at);
 
 /* ---- HIP events on the launch stream (measurement only: bench.py brackets single kernel launches inside
  * the timed region; torch.cuda.Event cannot be recorded from inside mnas_run_ops) ------------------------ */

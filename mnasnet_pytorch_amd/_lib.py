@@ -44,7 +44,8 @@ class MnasDwFwd(C.Structure):
 class MnasDwBwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
-                ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p)]
+                ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p), ("phase", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class MnasStemFwd(C.Structure):
@@ -64,7 +65,7 @@ class MnasOp(C.Structure):
 
 OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
-OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD = 12, 13, 14, 15
+OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT = 12, 13, 14, 15, 16
 PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
@@ -92,6 +93,7 @@ SYMBOLS = {
     "mnas_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),
     "mnas_run_ops": (c_int, [C.POINTER(MnasOp), c_int, c_void_p, C.POINTER(c_int)]),
+    "mnas_run_ops_multi": (c_int, [C.POINTER(MnasOp), c_int, C.POINTER(c_void_p), c_int, C.POINTER(c_int)]),
     "mnas_event_create": (c_int, [C.POINTER(c_void_p)]),
     "mnas_event_destroy": (c_int, [c_void_p]),
     "mnas_event_record": (c_int, [c_void_p, c_void_p]),

@@ -11,7 +11,7 @@ extern "C" const char* mnas_arch(void) { return "gfx950"; }
 //  CONV_WGRAD       i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw,stride,pad,nsplit   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, partial
 //  WGRAD_FINALIZE   i: nsplit,Co,Ci,taps,accumulate                  p: partial,grad
 //  DW_FWD           i: N,H,W,C,k,nparts      p: in.data,in.scale,in.shift, w,bias,out,stats
-//  DW_BWD           i: N,H,W,C,k,nparts      p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial, red_bn,red_partial
+//  DW_BWD           i: N,H,W,C,k,nparts,phase p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial, red_bn,red_partial
 //  DW_WGRAD_FINALIZE i: nparts,C,k,accumulate p: wpartial,grad
 //  STEM_FWD         i: N,H,W,Ho,Wo,Co,nparts p: x,w,bias,out,stats
 //  STEM_WGRAD       i: N,H,W,Ho,Wo,Co,nparts p: x, dy.g,dy.y,dy.coef, partial
@@ -59,7 +59,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = (const float*)p[6]; a.gin = p[7]; a.wpartial = (float*)p[8];
-            a.red_bn = (const float*)p[9]; a.red_partial = (float*)p[10];
+            a.red_bn = (const float*)p[9]; a.red_partial = (float*)p[10]; a.phase = i[6];
             return mnas_dw_bwd(&a, stream);
         }
         case MNAS_OP_DW_WGRAD_FINALIZE:
@@ -98,6 +98,8 @@ static int run_one(const MnasOp& o, void* stream) {
             return mnas_pack_weights((const float*)p[0], i[0], i[1], i[2], i[3], i[4], p[1], stream);
         case MNAS_OP_EVENT_RECORD:
             return (int)hipEventRecord((hipEvent_t)p[0], (hipStream_t)stream);
+        case MNAS_OP_EVENT_WAIT:
+            return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)p[0], 0);
         default:
             return MNAS_EINVAL;
     }
@@ -106,6 +108,22 @@ static int run_one(const MnasOp& o, void* stream) {
 extern "C" int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_at) {
     for (int k = 0; k < n; ++k) {
         const int rc = run_one(ops[k], stream);
+        if (rc != MNAS_OK) {
+            if (failed_at) *failed_at = k;
+            return rc;
+        }
+    }
+    return MNAS_OK;
+}
+
+extern "C" int mnas_run_ops_multi(const MnasOp* ops, int n, void* const* streams, int nstreams, int* failed_at) {
+    for (int k = 0; k < n; ++k) {
+        const int sid = ops[k].i[14];
+        if (sid < 0 || sid >= nstreams) {
+            if (failed_at) *failed_at = k;
+            return MNAS_EINVAL;
+        }
+        const int rc = run_one(ops[k], streams[sid]);
         if (rc != MNAS_OK) {
             if (failed_at) *failed_at = k;
             return rc;

@@ -502,7 +502,7 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MnasActIn noa = {nullptr, nullptr, nullptr};
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
-    {   // input gradient
+    if (c->phase != 2) {   // input gradient
         DwArgs a;
         if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;
         const size_t lds = (size_t)7 * 2 * a.cpw * sizeof(float) + (size_t)DW_RR * a.iw * a.ps * 4;
@@ -512,7 +512,7 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
             hipLaunchKernelGGL((k_dw_conv<5, 1>), dim3(a.geff), dim3(a.nthreads), lds, s, a, noa, c->dy, c->w, nullptr, (uint32_t*)c->gin, red ? c->red_partial : nullptr, red ? (const uint32_t*)c->x.data : nullptr, c->red_bn);
         MNAS_CHECK_LAUNCH();
     }
-    {   // weight gradient
+    if (c->phase != 1) {   // weight gradient
         DwArgs a;
         if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 2, c->nparts)) return MNAS_EINVAL;
         const size_t lds = (size_t)(7 + c->k * c->k) * 2 * a.cpw * sizeof(float) + (size_t)2 * DW_RR * a.iw * a.ps * 4;

@@ -112,23 +112,37 @@ class _OpList:
         self.items = []
         self.eng, self.tag = eng, tag
 
-    def add(self, opcode, ints=(), dbls=(), ptrs=()):
+    def add(self, opcode, ints=(), dbls=(), ptrs=(), stream=0):
+        """stream: 0 = main (torch's current stream), 1 = the engine's side stream (weight-gradient work)"""
         prof = self.eng is not None and self.eng.profile_opcodes and opcode in self.eng.profile_opcodes
         if prof:
             ev0, ev1 = self.eng.new_event(), self.eng.new_event()
-            self.items.append((L.OP_EVENT_RECORD, [], [], [ev0]))
-        self.items.append((opcode, list(ints), list(dbls), list(ptrs)))
+            self.items.append((L.OP_EVENT_RECORD, [], [], [ev0], stream))
+        self.items.append((opcode, list(ints), list(dbls), list(ptrs), stream))
         idx = len(self.items) - 1
         if prof:
-            self.items.append((L.OP_EVENT_RECORD, [], [], [ev1]))
+            self.items.append((L.OP_EVENT_RECORD, [], [], [ev1], stream))
             self.eng.profile_events.append(((self.tag, opcode, tuple(ints)), ev0, ev1))
         return idx
 
+    def fork(self):
+        """side stream may start from here: it waits for everything enqueued on main so far"""
+        ev = self.eng.new_event()
+        self.add(L.OP_EVENT_RECORD, [], [], [ev], 0)
+        self.add(L.OP_EVENT_WAIT, [], [], [ev], 1)
+
+    def join(self):
+        """main waits for everything enqueued on the side stream so far"""
+        ev = self.eng.new_event()
+        self.add(L.OP_EVENT_RECORD, [], [], [ev], 1)
+        self.add(L.OP_EVENT_WAIT, [], [], [ev], 0)
+
     def build(self):
         arr = (L.MnasOp * max(1, len(self.items)))()
-        for n, (opc, ints, dbls, ptrs) in enumerate(self.items):
+        for n, (opc, ints, dbls, ptrs, stream) in enumerate(self.items):
             o = arr[n]
             o.opcode = opc
+            o.i[14] = stream
             for j, v in enumerate(ints):
                 o.i[j] = int(v)
             for j, v in enumerate(dbls):
@@ -284,13 +298,18 @@ class Program:
                 ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), red_buf.data_ptr()])
             ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
                     [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
+            # the weight-gradient kernels only share READ-ONLY inputs (g, y, the dy coefficients just finalised, the
+            # forward activations) with the input-gradient chain: they go to the side stream and run concurrently
+            WS = 1 if eng.use_side_stream else 0
+            if WS:
+                ops.fork()
             gin, ncols = None, 0
             rt = red_target if (red_target is not None and need_gin) else None
             if ci.kind == "stem":
                 nsp = max(1, min(512, _cdiv(M, 1024)))
-                jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()])
+                jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()], WS)
                 self.patch_x_bwd = (ops, jx, 0)
-                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
+                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
             elif ci.kind == "dw":
                 nparts = max(64, min(1024, _cdiv(M * Co, 256 * 16 * 2)))
                 gin = new((N, Hi, Wi, ci.cin))
@@ -298,19 +317,20 @@ class Program:
                 if rt is not None:
                     red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
                     ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 0)
-                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts], [],
-                        a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()] + red)
+                dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()] + red
                 wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1)
                 if wrows < 1 or (rt is not None and ncols < 1):
                     raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, Co, ci.k),))
-                ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
+                ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
             else:
                 K = ci.k * ci.k * ci.cin
                 slabs = _cdiv(Co, 64) * _cdiv(K, 64)
                 nsp = max(1, min(_cdiv(1024, slabs), _cdiv(M, 256)))
                 ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
-                        a_in.act_ptrs() + gy + [eng.scratch_wgrad.data_ptr()])
-                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)])
+                        a_in.act_ptrs() + gy + [eng.scratch_wgrad.data_ptr()], WS)
+                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                 if need_gin:
                     gin = new((N, Hi, Wi, ci.cin))
                     Min = N * Hi * Wi
@@ -378,6 +398,8 @@ class Program:
             self.patch_dx = (step_records[0][1], j, 7)
         built = {}
         for st in order:
+            if eng.use_side_stream:
+                seg_ops[st].join()          # a stage's gradients are complete when its launch list returns (DDP buckets)
             built[st] = seg_ops[st].build()
         self.bwd_segments = [(st,) + built[st] for st in order]
         self._seg_index = {st: n for n, st in enumerate(order)}
@@ -389,7 +411,8 @@ class Program:
     # ------------------------------------------------------------------------------------------
     def _run(self, arr, n, what):
         failed = C.c_int(-1)
-        rc = self.eng.lib.mnas_run_ops(arr, n, L.cur_stream(), C.byref(failed))
+        streams = (C.c_void_p * 2)(L.cur_stream(), self.eng.side_stream.cuda_stream)
+        rc = self.eng.lib.mnas_run_ops_multi(arr, n, streams, 2, C.byref(failed))
         if rc != 0:
             raise RuntimeError("%s: mnas_run_ops failed with code %d at op %d (opcode %d)" %
                                (what, rc, failed.value, arr[failed.value].opcode if failed.value >= 0 else -1))
@@ -495,6 +518,8 @@ class Engine:
         self.grad_numel = off
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
+        self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        self.side_stream = None
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_events = []         # [(tag, start_handle, stop_handle)]
 
@@ -510,6 +535,8 @@ class Engine:
         self.lib = L.load()
         self.device = device
         self.programs.clear()
+        if self.side_stream is None or self.side_stream.device != device:
+            self.side_stream = torch.cuda.Stream(device=device)
         nbytes = self.lib.mnas_packed_bytes
         smax, wmax = 0, 0
         for ci in self.convs:
