@@ -114,7 +114,7 @@ __device__ __forceinline__ void dw_make_plan(const DwArgs& a, DwStagePlan& p) {
 // the ring.  MODE 0: act-on-load, coefficients lds_c = [2][cblk] (scale, shift).  MODE 1: dy-on-load,
 // lds_c = [5][cblk] (s,t,c1,c2,c3).  Slots t = 0..G*ncol-1 -> (row group t/ncol, column t%ncol) are processed
 // in batches of 4: the batch's loads are issued back to back, then transformed and written to LDS.
-template <int KS, int MODE>
+template <int KS, int MODE, int BATCH = 4>
 __device__ __forceinline__ void dw_stage(const DwArgs& a, const DwStagePlan& p, uint32_t* ring, const uint4* __restrict__ src0,
                                          const uint4* __restrict__ src1, const float* lds_c, bool has_coef, int n, int row0,
                                          int nrows, int x0, int c0) {
@@ -129,13 +129,13 @@ __device__ __forceinline__ void dw_stage(const DwArgs& a, const DwStagePlan& p, 
     const int nslots = DW_G * a.ncol;
     const int jshift = a.ncol - 1;           // ncol in {1,2}
 #pragma unroll
-    for (int tb = 0; tb < DW_G * DW_MAXCOL; tb += 4) {
+    for (int tb = 0; tb < DW_G * DW_MAXCOL; tb += BATCH) {
         if (tb >= nslots) break;
-        uint4 v0[4], v1[4];
-        bool inb[4], st[4];
-        int lofs[4];
+        uint4 v0[BATCH], v1[BATCH];
+        bool inb[BATCH], st[BATCH];
+        int lofs[BATCH];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             const int t = tb + u;
             const int q = t >> jshift, j = t & jshift;
             const int row = q * a.rpp + p.rl;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void dw_stage(const DwArgs& a, const DwStagePlan& p, 
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             if (!st[u]) continue;
             uint4 v = v0[u];
             if (MODE == 0) {
@@ -465,6 +465,204 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(DwArgs a, MnasActIn x, Mnas
     }
 }
 
+// ---- fused backward: input gradient + weight gradient (+ BN-backward reduce of the producer of x) in ONE sweep ----
+// Per image row iy (dy row iy and activation row iy-PAD are in the rings):
+//   xr  = dy row iy, k+3 columns        -> scattered into the register ring A of KS partial gin rows (flipped filter);
+//                                          its centre 4 columns become D[0] of the dy ring (D[q] = dy row iy-q)
+//   xa  = activation row r = iy-PAD     -> wacc[ky][kx] += D[ky][ox] * xa[ox+kx]   (dy rows r-ky+PAD = iy-ky)
+// 16 LDS dwords and 2*k*k*4*2 FMAs per row; g and y are read from HBM once, dy-on-load is computed once.
+template <int KS, bool RED>
+__global__ __launch_bounds__(256, 2) void k_dw_bwd_fused(DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w,
+                                                         uint32_t* __restrict__ gin, float* __restrict__ wpartial,
+                                                         float* __restrict__ red_partial, const float* __restrict__ red_bn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
+    const int cblk = 2 * a.cpw;
+    float* lds_cx = (float*)smem;                            // [2][cblk]
+    float* lds_cd = lds_cx + 2 * cblk;                       // [5][cblk]
+    float* lds_red = lds_cd + 5 * cblk;                      // [KS*KS][cblk]  (also reused for the [2][cblk] reduce)
+    uint32_t* ring_d = (uint32_t*)(lds_red + KS * KS * cblk);
+    uint32_t* ring_x = ring_d + (size_t)DW_RR * a.iw * a.ps;
+    const int tid = threadIdx.x;
+    const int cp = tid % a.cpw, sxi = tid / a.cpw;
+    const bool active = sxi < a.sx;
+    DwStagePlan plan;
+    dw_make_plan(a, plan);
+    const bool has_coef = x.scale != nullptr;
+    constexpr bool do_red = RED;
+    const uint32_t* red_y = (const uint32_t*)x.data;
+    // rings start zeroed: rows that are never staged (activation rows < -PAD of the first step) must read as finite
+    for (int i = tid; i < 2 * DW_RR * a.iw * a.ps; i += blockDim.x) ring_d[i] = 0u;
+    int cur_c0 = -1;
+    float wt[KS * KS][2], wacc[KS * KS][2];
+    float rs[2] = {0.f, 0.f}, rt[2] = {0.f, 0.f}, ris[2] = {0.f, 0.f}, rmu[2] = {0.f, 0.f};
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) { wacc[t][0] = 0.f; wacc[t][1] = 0.f; }
+    const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
+
+    for (int item = blockIdx.x; item < a.items && (int)blockIdx.x < a.geff; item += a.geff) {
+        int n, x0, c0;
+        dw_item(a, item, n, x0, c0);
+        const int ch = c0 + 2 * cp;
+        const bool ch_ok = ch < a.C;
+        if (c0 != cur_c0) {
+            cur_c0 = c0;
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) {      // flipped filter for the input gradient
+                wt[t][0] = ch_ok ? w[(size_t)(KS * KS - 1 - t) * a.C + ch] : 0.f;
+                wt[t][1] = ch_ok ? w[(size_t)(KS * KS - 1 - t) * a.C + ch + 1] : 0.f;
+            }
+            if (do_red && ch_ok) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    rs[e] = red_bn[0 * a.C + ch + e];
+                    rt[e] = red_bn[1 * a.C + ch + e];
+                    ris[e] = red_bn[6 * a.C + ch + e];
+                    rmu[e] = -red_bn[5 * a.C + ch + e] * ris[e];
+                }
+            }
+            __syncthreads();
+            dw_load_coefs(lds_cx, x.scale, x.shift, nullptr, 2, a.C, c0, cblk);
+            dw_load_coefs(lds_cd, nullptr, nullptr, d.coef, 5, a.C, c0, cblk);
+        }
+        float A[KS][DW_BW][2], D[KS][DW_BW][2];
+#pragma unroll
+        for (int i = 0; i < KS; ++i)
+#pragma unroll
+            for (int j = 0; j < DW_BW; ++j) { A[i][j][0] = 0.f; A[i][j][1] = 0.f; D[i][j][0] = 0.f; D[i][j][1] = 0.f; }
+        const int gx0 = x0 + sxi * DW_BW;
+        const size_t obase = (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
+        const size_t coloff = (size_t)sxi * DW_BW * a.ps + cp;
+
+        for (int s = 0; s < nsteps; ++s) {
+            const int r0 = -PAD + s * DW_G;
+            __syncthreads();
+            dw_stage<KS, 1, (KS == 3 ? 4 : 2)>(a, plan, ring_d, (const uint4*)d.g, (const uint4*)d.y, lds_cd, true, n, r0, DW_G, x0, c0);
+            dw_stage<KS, 0, (KS == 3 ? 4 : 2)>(a, plan, ring_x, (const uint4*)x.data, nullptr, lds_cx, has_coef, n, r0, DW_G, x0, c0);
+            __syncthreads();
+            if (!active) continue;
+#pragma unroll 1
+            for (int j = 0; j < DW_G; ++j) {
+                const int iy = r0 + j;
+                const int oy = iy - PAD;
+                const bool emit = oy >= 0 && oy < a.H && ch_ok;
+                uint32_t ypre[DW_BW];
+                if (do_red && emit) {
+                    const uint32_t* yp = red_y + obase + (size_t)oy * a.W * a.C / 2;
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) ypre[ox] = (gx0 + ox < a.W) ? yp[(size_t)ox * a.C / 2] : 0u;
+                }
+                // ---- dy row iy: input-gradient scatter + dy ring
+                {
+                    const uint32_t* rowp = ring_d + (size_t)dw_slot(iy) * a.iw * a.ps + coloff;
+                    float xr[WIN_W][2];
+#pragma unroll
+                    for (int xx = 0; xx < WIN_W; ++xx) {
+                        const uint32_t u = rowp[xx * a.ps];
+                        xr[xx][0] = bf_lo(u);
+                        xr[xx][1] = bf_hi(u);
+                    }
+#pragma unroll
+                    for (int i = 0; i < KS; ++i)
+#pragma unroll
+                        for (int ox = 0; ox < DW_BW; ++ox)
+#pragma unroll
+                            for (int kx = 0; kx < KS; ++kx) {
+                                A[i][ox][0] = fmaf(wt[(KS - 1 - i) * KS + kx][0], xr[ox + kx][0], A[i][ox][0]);
+                                A[i][ox][1] = fmaf(wt[(KS - 1 - i) * KS + kx][1], xr[ox + kx][1], A[i][ox][1]);
+                            }
+#pragma unroll
+                    for (int q = KS - 1; q > 0; --q)
+#pragma unroll
+                        for (int ox = 0; ox < DW_BW; ++ox) { D[q][ox][0] = D[q - 1][ox][0]; D[q][ox][1] = D[q - 1][ox][1]; }
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) { D[0][ox][0] = xr[ox + PAD][0]; D[0][ox][1] = xr[ox + PAD][1]; }
+                }
+                // ---- emit gin row oy (+ fused BN-backward reduce of the producer of x)
+                if (emit) {
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) {
+                        if (gx0 + ox < a.W) {
+                            const uint32_t pk = pack_bf16(A[0][ox][0], A[0][ox][1]);
+                            gin[obase + ((size_t)oy * a.W + ox) * a.C / 2] = pk;
+                            if (do_red) {
+                                const uint32_t yv = ypre[ox];
+                                const float g0 = bf_lo(pk), g1 = bf_hi(pk), y0 = bf_lo(yv), y1 = bf_hi(yv);
+                                const float dz0 = (fmaf(y0, rs[0], rt[0]) > 0.f) ? g0 : 0.f;
+                                const float dz1 = (fmaf(y1, rs[1], rt[1]) > 0.f) ? g1 : 0.f;
+                                s1[0] += dz0; s2[0] = fmaf(dz0, fmaf(y0, ris[0], rmu[0]), s2[0]);
+                                s1[1] += dz1; s2[1] = fmaf(dz1, fmaf(y1, ris[1], rmu[1]), s2[1]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i + 1 < KS; ++i)
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) { A[i][ox][0] = A[i + 1][ox][0]; A[i][ox][1] = A[i + 1][ox][1]; }
+#pragma unroll
+                for (int ox = 0; ox < DW_BW; ++ox) { A[KS - 1][ox][0] = 0.f; A[KS - 1][ox][1] = 0.f; }
+                // ---- activation row r = iy - PAD: weight gradient against the dy ring (rows < -PAD: zero-initialised ring)
+                {
+                    const uint32_t* rowp = ring_x + (size_t)dw_slot(oy) * a.iw * a.ps + coloff;
+                    float xa[WIN_W][2];
+#pragma unroll
+                    for (int xx = 0; xx < WIN_W; ++xx) {
+                        const uint32_t u = rowp[xx * a.ps];
+                        xa[xx][0] = bf_lo(u);
+                        xa[xx][1] = bf_hi(u);
+                    }
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                        for (int ox = 0; ox < DW_BW; ++ox)
+#pragma unroll
+                            for (int kx = 0; kx < KS; ++kx) {
+                                wacc[ky * KS + kx][0] = fmaf(D[ky][ox][0], xa[ox + kx][0], wacc[ky * KS + kx][0]);
+                                wacc[ky * KS + kx][1] = fmaf(D[ky][ox][1], xa[ox + kx][1], wacc[ky * KS + kx][1]);
+                            }
+                }
+            }
+        }
+    }
+    const int row = blockIdx.x / a.cblocks, rows = a.geff / a.cblocks;
+    const int cb0 = (blockIdx.x % a.cblocks) * cblk;
+    // ---- fused-reduce table float[2][C][rows]
+    if (do_red) {
+        __syncthreads();
+        for (int i = tid; i < 2 * cblk; i += blockDim.x) lds_red[i] = 0.f;
+        __syncthreads();
+        if (active && cur_c0 >= 0 && cur_c0 + 2 * cp < a.C) {
+            atomicAdd(&lds_red[2 * cp], s1[0]); atomicAdd(&lds_red[2 * cp + 1], s1[1]);
+            atomicAdd(&lds_red[cblk + 2 * cp], s2[0]); atomicAdd(&lds_red[cblk + 2 * cp + 1], s2[1]);
+        }
+        __syncthreads();
+        if ((int)blockIdx.x < a.geff)
+            for (int i = tid; i < 2 * cblk; i += blockDim.x) {
+                const int r = i / cblk, c = cb0 + i % cblk;
+                if (c < a.C) red_partial[((size_t)r * a.C + c) * rows + row] = (cur_c0 >= 0) ? lds_red[i] : 0.f;
+            }
+    }
+    // ---- wpartial float[rows][k*k][C]
+    __syncthreads();
+    for (int i = tid; i < KS * KS * cblk; i += blockDim.x) lds_red[i] = 0.f;
+    __syncthreads();
+    if (active && cur_c0 >= 0 && cur_c0 + 2 * cp < a.C) {
+#pragma unroll
+        for (int k = 0; k < KS * KS; ++k) {
+            atomicAdd(&lds_red[k * cblk + 2 * cp], wacc[k][0]);
+            atomicAdd(&lds_red[k * cblk + 2 * cp + 1], wacc[k][1]);
+        }
+    }
+    __syncthreads();
+    if ((int)blockIdx.x < a.geff)
+        for (int i = tid; i < KS * KS * cblk; i += blockDim.x) {
+            const int k = i / cblk, c = cb0 + i % cblk;
+            if (c < a.C) wpartial[((size_t)row * KS * KS + k) * a.C + c] = (cur_c0 >= 0) ? lds_red[i] : 0.f;
+        }
+}
+
 static bool dw_setup(DwArgs* a, int N, int H, int W, int C, int k, int nrings, int nparts) {
     if (!dw_pick(N, H, W, C, k, nrings, a)) return false;
     if (nparts < a->cblocks) return false;
@@ -502,6 +700,18 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MnasActIn noa = {nullptr, nullptr, nullptr};
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
+    if (c->phase == 0) {   // fused: one sweep, both partial tables have mnas_dw_rows(..., 1) rows
+        DwArgs a;
+        if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 2, c->nparts)) return MNAS_EINVAL;
+        const size_t lds = (size_t)(7 + c->k * c->k) * 2 * a.cpw * sizeof(float) + (size_t)2 * DW_RR * a.iw * a.ps * 4;
+#define MNAS_DWF(K_, R_) hipLaunchKernelGGL((k_dw_bwd_fused<K_, R_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->w, \
+                                            (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
+        if (c->k == 3) { if (red) MNAS_DWF(3, true); else MNAS_DWF(3, false); }
+        else { if (red) MNAS_DWF(5, true); else MNAS_DWF(5, false); }
+#undef MNAS_DWF
+        MNAS_CHECK_LAUNCH();
+        return MNAS_OK;
+    }
     if (c->phase != 2) {   // input gradient
         DwArgs a;
         if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;

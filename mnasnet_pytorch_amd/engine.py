@@ -317,13 +317,21 @@ class Program:
                 if rt is not None:
                     red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
                     ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 0)
-                dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), eng.scratch_wgrad.data_ptr()] + red
+                wsc = eng.scratch_wgrad2 if ci.k in eng.dw_fused_k else eng.scratch_wgrad     # fused runs on the main stream
+                dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), wsc.data_ptr()] + red
                 wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1)
                 if wrows < 1 or (rt is not None and ncols < 1):
                     raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, Co, ci.k),))
-                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
-                ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
-                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
+                if ci.k in eng.dw_fused_k:
+                    # one sweep: dgrad + wgrad (+ fused reduce); both partial tables have `wrows` rows
+                    if rt is not None:
+                        ncols = wrows
+                    ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0], [], dwp, 0)
+                    ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
+                else:
+                    ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
+                    ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+                    ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
             else:
                 K = ci.k * ci.k * ci.cin
                 slabs = _cdiv(Co, 64) * _cdiv(K, 64)
@@ -519,6 +527,7 @@ class Engine:
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        self.dw_fused_k = (3,)           # depthwise kernel sizes whose backward runs as ONE fused sweep
         self.side_stream = None
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_events = []         # [(tag, start_handle, stop_handle)]
@@ -555,6 +564,7 @@ class Engine:
             smax = max(smax, ci.cout)
         self.scratch_stats = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)
         self.scratch_wgrad = torch.empty(wmax, dtype=torch.float32, device=device)
+        self.scratch_wgrad2 = torch.empty(wmax, dtype=torch.float32, device=device)
         self.scratch_red = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)   # fused BN-bwd partials
         if self._ext_grad is not None:
             self.flat_grad = self._ext_grad

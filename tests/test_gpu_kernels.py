@@ -237,7 +237,9 @@ def test_dw_fwd(shape):
 
 
 @pytest.mark.parametrize("shape", DW)
-def test_dw_bwd(shape):
+@pytest.mark.parametrize("phase", [0, 12])
+def test_dw_bwd(shape, phase):
+    """phase 0: fused one-sweep backward; 12: the two-launch form (input gradient, then weight gradient)"""
     lib = L.load()
     N, H, W, C_, k = shape
     x = _x((N, C_, H, W), 1)
@@ -263,9 +265,17 @@ def test_dw_bwd(shape):
     b_in = rand_bn_coefs(C_, 22, O)
     b_in[0], b_in[1] = sc, sh                       # rows 0,1 are the same scale/shift the act-on-load uses
     bid = b_in.cuda()
+    if phase == 0:
+        rows0 = rows1                                   # the fused sweep writes both tables with the 2-ring row count
     redp = torch.full((2, C_, rows0), float("nan"), device="cuda")
     a_.red_bn, a_.red_partial = bid.data_ptr(), redp.data_ptr()
-    L.check(lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()), "dw_bwd")
+    if phase == 0:
+        a_.phase = 0
+        L.check(lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()), "dw_bwd")
+    else:
+        for ph in (1, 2):
+            a_.phase = ph
+            L.check(lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()), "dw_bwd")
     assert relerr(from_nhwc(gin), ref_gin) < TOL_BF16
     gq = from_nhwc(gin)
     s_, t_, mu_, is_ = (b_in[i].view(1, -1, 1, 1) for i in (0, 1, 5, 6))
