@@ -3,9 +3,10 @@
 Same arithmetic as oracle/mnasnet_oracle.py (i.e. as the reference: ConvBlock mnasnet.py:58-62, MBConv_block
 :131-137, autograd's batch-norm / ReLU / conv backward formulas), restated with an EXPLICIT backward and with
 a round-to-bf16 at exactly the points where the HIP path stores a tensor in HBM or stages it into LDS:
-  * activations consumed by a conv: relu(s*y+t) -> bf16      * raw conv output y -> bf16 (statistics from fp32)
+  * activations consumed by a 1x1/3x3 conv: relu(s*y+t) -> bf16 (depthwise convs apply it on the fly in fp32)
+  * raw conv output y -> bf16 (statistics from fp32)
   * 1x1 / 3x3 weights -> bf16 (depthwise weights stay fp32)   * residual sum r -> bf16
-  * incoming/outgoing activation gradients g -> bf16          * dy = c1*dz + c2*y + c3 -> bf16
+  * incoming/outgoing activation gradients g -> bf16          * dy = c1*dz + c2*y + c3 -> bf16 (fp32 in depthwise)
 Everything else is fp32 (fp64 for the per-channel reductions, like the finalize kernels).
 
 Why it exists: against the fp32 oracle a bf16 pipeline legitimately differs by a few % in L2 (ReLU-mask
@@ -43,7 +44,10 @@ def _kind(spec: ConvSpec):
 
 def conv_fwd(spec: ConvSpec, a_in, st, train, image=None):
     p = spec.prefix
-    a = round_bf16(image) if image is not None else a_in.staged()
+    if image is not None:
+        a = round_bf16(image)
+    else:
+        a = a_in.f32() if _kind(spec) == "dw" else a_in.staged()      # depthwise: act-on-read in fp32
     W = st[p + ".conv.weight"].detach()
     w = W if _kind(spec) == "dw" else round_bf16(W)
     y32 = F.conv2d(a, w, st[p + ".conv.bias"].detach(), stride=spec.stride, padding=spec.pad, groups=spec.groups)
@@ -85,7 +89,9 @@ def conv_bwd(saved, g, grads, resid=None, need_gin=True):
     c1 = s
     c2 = (-sd * isd * S2 / M).float()
     c3 = (sd * (md * isd * S2 / M - S1 / M)).float()
-    dy = round_bf16(v(c1) * dz + (v(c2) * y + v(c3)))
+    dy = v(c1) * dz + (v(c2) * y + v(c3))
+    if _kind(spec) != "dw":
+        dy = round_bf16(dy)                 # staged into LDS as bf16 for the MFMA kernels; depthwise keeps fp32
     p = spec.prefix
 
     def acc(name, val):

@@ -78,8 +78,10 @@ def rand_bn_coefs(C, seed, O):
     return b
 
 
-def dy_ref(g, y, b):
-    """g,y: NCHW fp32 (already bf16-rounded); b: [8][C].  Returns bf16-rounded dy (what the kernels stage)."""
+def dy_ref(g, y, b, rounded=True):
+    """g,y: NCHW fp32 (already bf16-rounded); b: [8][C].  Returns dy as the kernels use it: bf16-rounded where it is
+    staged into LDS for the MFMA kernels, fp32 for the depthwise kernels (which form it on the fly from raw g, y)."""
     s, t, c1, c2, c3 = (b[i].view(1, -1, 1, 1) for i in range(5))
     dz = g * ((s * y + t) > 0)
-    return bf16r(c1 * dz + c2 * y + c3)
+    d = c1 * dz + c2 * y + c3
+    return bf16r(d) if rounded else d

@@ -216,7 +216,7 @@ def test_dw_fwd(shape):
     w = O.det_param("t.conv.weight", (C_, 1, k, k), 2)
     bias = 0.1 * O.det_uniform((C_,), 3)
     sc, sh = 1 + 0.3 * O.det_uniform((C_,), 4), 0.2 * O.det_uniform((C_,), 5)
-    a = bf16r(F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))      # act-on-read: fp32, not re-rounded to bf16
     ref = F.conv2d(a, w, bias, padding=k // 2, groups=C_)
     xd, dsc, dsh, db = nhwc(x), sc.cuda(), sh.cuda(), bias.cuda()
     wp = pack(w, L.PACK_DW)
@@ -245,17 +245,18 @@ def test_dw_bwd(shape, phase):
     x = _x((N, C_, H, W), 1)
     w = O.det_param("t.conv.weight", (C_, 1, k, k), 2)
     sc, sh = 1 + 0.3 * O.det_uniform((C_,), 4), 0.2 * O.det_uniform((C_,), 5)
-    a = bf16r(F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))      # act-on-read / dy-on-read: fp32
     g, y = _x((N, C_, H, W), 6), _x((N, C_, H, W), 7)
     b = rand_bn_coefs(C_, 9, O)
-    dy = dy_ref(g, y, b)
+    dy = dy_ref(g, y, b, rounded=False)
     ref_gin = torch.nn.grad.conv2d_input((N, C_, H, W), w, dy, padding=k // 2, groups=C_)
     ref_dw = torch.nn.grad.conv2d_weight(a, (C_, 1, k, k), dy, padding=k // 2, groups=C_)
     xd, gd, yd, bd, dsc, dsh = nhwc(x), nhwc(g), nhwc(y), b.cuda(), sc.cuda(), sh.cuda()
     wp = pack(w, L.PACK_DW)
     nparts = 37
     gin = torch.empty((N, H, W, C_), dtype=torch.bfloat16, device="cuda")
-    rows0, rows1 = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 0), lib.mnas_dw_rows(N, H, W, C_, k, nparts, 1)
+    rows1 = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 1)
+    rows0 = rows1                    # every backward table of a layer has the same row count
     wpart = torch.full((rows1, k * k, C_), float("nan"), device="cuda")
     a_ = L.MnasDwBwd()
     a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts = N, H, W, C_, k, nparts
@@ -265,8 +266,6 @@ def test_dw_bwd(shape, phase):
     b_in = rand_bn_coefs(C_, 22, O)
     b_in[0], b_in[1] = sc, sh                       # rows 0,1 are the same scale/shift the act-on-load uses
     bid = b_in.cuda()
-    if phase == 0:
-        rows0 = rows1                                   # the fused sweep writes both tables with the 2-ring row count
     redp = torch.full((2, C_, rows0), float("nan"), device="cuda")
     a_.red_bn, a_.red_partial = bid.data_ptr(), redp.data_ptr()
     if phase == 0:
