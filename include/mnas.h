@@ -124,8 +124,10 @@ typedef struct MnasDwFwd {
 } MnasDwFwd;
 int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
 /* Number of partial rows/columns a depthwise launch writes for this shape and nparts (host-side, no launch).
- * which = 0: forward statistics and the backward launch's fused-reduce table (float[2][C][rows]);
- * which = 1: the weight-gradient partial table (float[rows][k*k][C]).  Returns < 0 for unsupported shapes. */
+ * which = 0: forward statistics float[2][C][rows];
+ * which = 1: tables of a backward launch that computes the weight gradient (phase 0 or 2): wpartial
+ *            float[rows][k*k][C] and, for phase 0, the fused-reduce table float[2][C][rows];
+ * which = 2: the fused-reduce table of an input-gradient-only launch (phase 1).  Returns < 0 for unsupported shapes. */
 int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which);
 
 typedef struct MnasDwBwd {
@@ -137,7 +139,8 @@ typedef struct MnasDwBwd {
     void*  gin;              /* bf16 (N,H,W,C): dL/d act(x) */
     float* wpartial;         /* float[rows1][k*k][C], rows1 = mnas_dw_rows(...,1), fully overwritten */
     /* optional fused BatchNorm-backward reduction for the producer of x (x.data = its raw output, red_bn = its
-     * bnbuf): red_partial receives float[2][C][rows0] (sum dz, sum dz*xhat) of (gin, x.data), rows0 = mnas_dw_rows(...,0) */
+     * bnbuf): red_partial receives float[2][C][r] (sum dz, sum dz*xhat) of (gin, x.data), r = mnas_dw_rows(...,1) for
+     * phase 0 and mnas_dw_rows(...,2) for phase 1 */
     const float* red_bn;
     float* red_partial;
     int32_t phase;           /* 0: both launches; 1: input gradient only; 2: weight gradient only (lets the caller put

@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
     float* __restrict__ red_partial, const float* __restrict__ red_bn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
-    constexpr bool NEEDX = WG || RED;
+    constexpr bool NEEDX = WG;                 // x ring only when the weight gradient is computed here
+    constexpr bool REDG = RED && !WG;          // input-gradient-only launch: the reduce reads raw x from global (2 rings)
     const int cblk = 2 * a.cpw;
     float* lds_red = (float*)smem;                           // [KS*KS][cblk]
     uint32_t* ring_g = (uint32_t*)(lds_red + KS * KS * cblk);
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
     const bool active = sxi < a.sx;
     const bool has_coef = x.scale != nullptr;
+    const uint32_t* xglob = (const uint32_t*)x.data;
     int cur_c0 = -1;
     float wt[DG ? KS * KS : 1][2], wacc[WG ? KS * KS : 1][2];
     float cf[5][2], cs[2] = {1.f, 1.f}, ct[2] = {0.f, 0.f};
@@ -382,6 +384,13 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
                 const int iy = r0 + j;
                 const int oy = iy - PAD;
                 const bool row_in = iy >= 0 && iy < a.H;
+                const bool orow_in = oy >= 0 && oy < a.H;
+                uint32_t xraw[DW_BW];
+                if (REDG && orow_in && ch_ok) {      // lands under the FMAs below
+                    const uint32_t* yp = xglob + obase + (size_t)oy * a.W * a.C / 2;
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) xraw[ox] = (gx0 + ox < a.W) ? yp[(size_t)ox * a.C / 2] : 0u;
+                }
                 // ---- dy row iy
                 float xr[WIN_W][2];
                 if (row_in) {
@@ -410,14 +419,12 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) { D[0][ox][0] = xr[ox + PAD][0]; D[0][ox][1] = xr[ox + PAD][1]; }
                 }
-                const bool orow_in = oy >= 0 && oy < a.H;
                 // ---- x row oy = iy - PAD: activation window (WG) and raw centre (RED)
                 float xa[WIN_W][2];
-                uint32_t xraw[DW_BW];
                 if (NEEDX && orow_in) {
                     const uint32_t* rowp = ring_x + (size_t)dw_slot(oy) * a.rc * 4 + coloff;
                     if (WG) dw_read_act<WIN_W>(rowp, ps, has_coef, cs, ct, colmask, xa);
-                    if (RED) {
+                    if (RED && !REDG) {
 #pragma unroll
                         for (int ox = 0; ox < DW_BW; ++ox) xraw[ox] = rowp[(ox + PAD) * ps];
                     }
@@ -499,12 +506,13 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-// Every backward launch form uses the 3-ring geometry, so all of a layer's backward partial tables have the same rows.
-// which = 0: forward statistics float[2][C][rows];  which = 1: backward tables (fused-reduce float[2][C][rows],
-// weight-gradient float[rows][k*k][C]).
+// LDS rings per launch form: forward 1 (x); input-gradient-only 2 (g, y); anything that computes the weight gradient 3.
+// Partial-table rows for a launch with `nparts`:  which = 0 forward statistics float[2][C][rows];
+// which = 1 tables written by a weight-gradient-computing launch (wpartial float[rows][k*k][C] and, when fused with the
+// input gradient, the reduce table float[2][C][rows]);  which = 2 the reduce table of an input-gradient-only launch.
 extern "C" int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which) {
     DwArgs a;
-    if (!dw_setup(&a, N, H, W, C, k, which ? 3 : 1, nparts)) return -1;
+    if (!dw_setup(&a, N, H, W, C, k, which == 0 ? 1 : (which == 1 ? 3 : 2), nparts)) return -1;
     return a.geff / a.cblocks;
 }
 
@@ -526,20 +534,22 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1 || c->phase < 0 || c->phase > 2) return MNAS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
+    // phase 0: everything in one fused sweep.  phase 1: input gradient (+reduce).  phase 2: weight gradient.
+    const bool want_dg = c->phase != 2, want_wg = c->phase != 1;
+    const int nrings = want_wg ? 3 : 2;
     DwArgs a;
-    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 3, c->nparts)) return MNAS_EINVAL;
-    const size_t lds = (size_t)c->k * c->k * 2 * a.cpw * sizeof(float) + (size_t)3 * DW_RR * a.rc * 16;
+    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, nrings, c->nparts)) return MNAS_EINVAL;
+    const size_t lds = (size_t)c->k * c->k * 2 * a.cpw * sizeof(float) + (size_t)nrings * DW_RR * a.rc * 16;
 #define MNAS_DWB(K_, DG_, WG_, R_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, \
                                                      c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
-    // phase 0: everything (one fused sweep for 3x3; two launches for 5x5).  phase 1: input gradient (+reduce).  phase 2: weight gradient.
-    const bool want_dg = c->phase != 2, want_wg = c->phase != 1;
     if (c->k == 3) {
         if (want_dg && want_wg) { if (red) MNAS_DWB(3, true, true, true); else MNAS_DWB(3, true, true, false); }
         else if (want_dg) { if (red) MNAS_DWB(3, true, false, true); else MNAS_DWB(3, true, false, false); }
         else MNAS_DWB(3, false, true, false);
     } else {
-        if (want_dg) { if (red) MNAS_DWB(5, true, false, true); else MNAS_DWB(5, true, false, false); }
-        if (want_wg) MNAS_DWB(5, false, true, false);
+        if (want_dg && want_wg) { if (red) MNAS_DWB(5, true, true, true); else MNAS_DWB(5, true, true, false); }
+        else if (want_dg) { if (red) MNAS_DWB(5, true, false, true); else MNAS_DWB(5, true, false, false); }
+        else MNAS_DWB(5, false, true, false);
     }
 #undef MNAS_DWB
     MNAS_CHECK_LAUNCH();

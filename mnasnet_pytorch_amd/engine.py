@@ -316,7 +316,7 @@ class Program:
                 red = [None, None]
                 if rt is not None:
                     red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
-                    ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1)
+                    ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 2)
                 wsc = eng.scratch_wgrad2 if ci.k in eng.dw_fused_k else eng.scratch_wgrad     # fused runs on the main stream
                 dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), wsc.data_ptr()] + red
                 wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1)
