@@ -112,6 +112,8 @@ def main():
     model = FineTuneModelPool(base, "mnasnet", 1000, "512").to(dev).train()
     trainer = Trainer(model, lr=1e-3, distributed=distributed)
     eng = trainer.engine
+    if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
+        eng.use_side_stream = False
     profile = (not args.no_roofline) and rank == 0
     if profile:
         eng.profile_opcodes = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE,

@@ -12,21 +12,48 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Sum one channel's two partial rows with TPC threads (64: one wave per channel, 4 channels per block; 256: the whole
+// block on one channel -- the early layers have 16-48 channels x 1024-2048 partials, where a wave per channel leaves
+// the chip empty and walks 32 dependent-latency rounds).  Result valid in every thread with (threadIdx.x % TPC) == 0.
+template <int TPC>
+__device__ __forceinline__ void bn_partial_sums(const float* __restrict__ partial, int nparts, int C, int c, double& s1,
+                                                double& s2) {
+    const int t = threadIdx.x % TPC;
+    const float* p1 = partial + (size_t)c * nparts;
+    const float* p2 = partial + ((size_t)C + c) * nparts;
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    int p = t;
+    for (; p + 3 * TPC < nparts; p += 4 * TPC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a1[j] += p1[p + j * TPC]; a2[j] += p2[p + j * TPC]; }
+    }
+    s1 = 0.0; s2 = 0.0;
+    for (; p < nparts; p += TPC) { s1 += (double)p1[p]; s2 += (double)p2[p]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1 += (double)a1[j]; s2 += (double)a2[j]; }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (TPC == 256) {
+        __shared__ double red[2][4];
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+template <int TPC>
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(
     const float* __restrict__ partial, int nparts, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
     float eps, int training, float* bnbuf) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x % TPC;
+    const int c = (TPC == 256) ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c < C) {
         float s, t;
         if (training) {
-            double s1 = 0.0, s2 = 0.0;
-            const float* p1 = partial + (size_t)c * nparts;
-            const float* p2 = partial + ((size_t)C + c) * nparts;
-            for (int p = lane; p < nparts; p += 64) { s1 += (double)p1[p]; s2 += (double)p2[p]; }
-            s1 = wave_sum_d(s1);
-            s2 = wave_sum_d(s2);
+            double s1, s2;
+            bn_partial_sums<TPC>(partial, nparts, C, c, s1, s2);
             const double mean = s1 / count;
             double var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -58,9 +85,14 @@ extern "C" int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, dou
                                     int64_t* num_batches_tracked, float momentum, float eps, int training,
                                     float* bnbuf, void* stream) {
     if (C <= 0 || (training && (!partial || nparts <= 0))) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
-                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training,
-                       bnbuf);
+    if (training && nparts > 256 && C <= 1024)
+        hipLaunchKernelGGL(k_bn_fwd_finalize<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+                           count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training,
+                           bnbuf);
+    else
+        hipLaunchKernelGGL(k_bn_fwd_finalize<64>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+                           count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training,
+                           bnbuf);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -128,18 +160,15 @@ extern "C" int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnb
 
 // dgamma, dbeta and the dy-on-load coefficients:
 //   dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) = c1*dz + c2*y + c3
+template <int TPC>
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nparts, int C,
                                                          double count, float* bnbuf, float* dgamma, float* dbeta,
                                                          int accumulate) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x % TPC;
+    const int c = (TPC == 256) ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    const float* p1 = partial + (size_t)c * nparts;
-    const float* p2 = partial + ((size_t)C + c) * nparts;
-    for (int p = lane; p < nparts; p += 64) { s1 += (double)p1[p]; s2 += (double)p2[p]; }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
+    double s1, s2;
+    bn_partial_sums<TPC>(partial, nparts, C, c, s1, s2);
     if (lane == 0) {
         const double s = bnbuf[0 * C + c], mean = bnbuf[5 * C + c], invstd = bnbuf[6 * C + c];
         const double md = s1 / count, mx = s2 / count;
@@ -154,8 +183,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
 extern "C" int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count, float* bnbuf, float* dgamma,
                                     float* dbeta, int accumulate, void* stream) {
     if (C <= 0 || nparts <= 0) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
-                       count, bnbuf, dgamma, dbeta, accumulate);
+    if (nparts > 256 && C <= 1024)
+        hipLaunchKernelGGL(k_bn_bwd_finalize<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+                           count, bnbuf, dgamma, dbeta, accumulate);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_finalize<64>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
+                           count, bnbuf, dgamma, dbeta, accumulate);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -305,61 +338,67 @@ extern "C" int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int k
 // ------------------------------------------------------------------------------------------------
 // wgrad reductions (+ relayout to the reference's [Co][Ci][kh][kw])
 // ------------------------------------------------------------------------------------------------
+// 32 outputs x 8 split lanes per block; a block covers <= FIN_SPLITS partial rows (16 independent loads per thread).
+// Longer split ranges are cut over grid.y and combined with global float atomics (accumulate mode only).
+#define FIN_SPLITS 128
+template <bool DW>
 __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict__ partial, int nsplit, int Co, int Ci,
                                                          int taps, float* __restrict__ grad, int accumulate) {
     __shared__ float red[8][33];
     const int K = taps * Ci;
-    const int total = Co * K;
+    const int total = DW ? Co * taps : Co * K;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;
+    const int p0 = blockIdx.y * FIN_SPLITS, p1 = (gridDim.y == 1) ? nsplit : min(nsplit, p0 + FIN_SPLITS);
     float s = 0.f;
-    if (i < total)
-        for (int p = ty; p < nsplit; p += 8) s += partial[(size_t)p * total + i];
+    if (i < total) {
+        const float* src = partial + i;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        int p = p0 + ty;
+        for (; p + 24 < p1; p += 32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += src[(size_t)(p + 8 * j) * total];
+        }
+        for (; p < p1; p += 8) s += src[(size_t)p * total];
+        s += (a[0] + a[1]) + (a[2] + a[3]);
+    }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && i < total) {
 #pragma unroll
         for (int j = 1; j < 8; ++j) s += red[j][tx];
-        const int co = i / K, k = i % K;
-        const int tap = k / Ci, ci = k % Ci;
-        float* d = grad + ((size_t)co * Ci + ci) * taps + tap;
-        *d = (accumulate ? *d : 0.f) + s;
+        float* d;
+        if (DW) {          // wpartial rows are [taps][C]; reference layout [C][1][kh][kw]
+            const int tap = i / Co, c = i % Co;
+            d = grad + (size_t)c * taps + tap;
+        } else {           // partial rows are [Co][taps*Ci]; reference layout [Co][Ci][kh][kw]
+            const int co = i / K, k = i % K;
+            const int tap = k / Ci, ci = k % Ci;
+            d = grad + ((size_t)co * Ci + ci) * taps + tap;
+        }
+        if (gridDim.y > 1) atomicAdd(d, s);
+        else *d = (accumulate ? *d : 0.f) + s;
     }
+}
+template <bool DW>
+static int launch_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps, float* grad, int accumulate,
+                                 void* stream) {
+    if (!partial || !grad || nsplit < 1 || Co < 1 || Ci < 1 || taps < 1) return MNAS_EINVAL;
+    const int total = DW ? Co * taps : Co * Ci * taps;
+    // overwrite mode must stay a single deterministic pass (no zero-fill launch hidden in here)
+    const int ny = accumulate ? (nsplit + FIN_SPLITS - 1) / FIN_SPLITS : 1;
+    hipLaunchKernelGGL(k_wgrad_finalize<DW>, dim3((total + 31) / 32, ny), dim3(256), 0, (hipStream_t)stream, partial,
+                       nsplit, Co, Ci, taps, grad, accumulate);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
 }
 extern "C" int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps, float* grad,
                                    int accumulate, void* stream) {
-    const int blocks = (Co * Ci * taps + 31) / 32;
-    hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, Co, Ci, taps,
-                       grad, accumulate);
-    MNAS_CHECK_LAUNCH();
-    return MNAS_OK;
-}
-__global__ __launch_bounds__(256) void k_dw_wgrad_finalize(const float* __restrict__ wpartial, int nparts, int C,
-                                                            int taps, float* __restrict__ grad, int accumulate) {
-    __shared__ float red[8][33];
-    const int total = C * taps;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + tx;
-    float s = 0.f;
-    if (i < total)
-        for (int p = ty; p < nparts; p += 8) s += wpartial[(size_t)p * total + i];
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && i < total) {
-#pragma unroll
-        for (int j = 1; j < 8; ++j) s += red[j][tx];
-        const int tap = i / C, c = i % C;
-        float* d = grad + (size_t)c * taps + tap;
-        *d = (accumulate ? *d : 0.f) + s;
-    }
+    return launch_wgrad_finalize<false>(partial, nsplit, Co, Ci, taps, grad, accumulate, stream);
 }
 extern "C" int mnas_dw_wgrad_finalize(const float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
                                       void* stream) {
-    const int blocks = (C * k * k + 31) / 32;
-    hipLaunchKernelGGL(k_dw_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, wpartial, nparts, C, k * k,
-                       grad, accumulate);
-    MNAS_CHECK_LAUNCH();
-    return MNAS_OK;
+    return launch_wgrad_finalize<true>(wpartial, nparts, C, 1, k * k, grad, accumulate, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

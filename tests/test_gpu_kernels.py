@@ -21,7 +21,8 @@ def _x(shape, seed):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("C_,nparts,count", [(16, 7, 100.0), (48, 64, 3211264.0), (1152, 33, 12544.0)])
+@pytest.mark.parametrize("C_,nparts,count", [(16, 7, 100.0), (48, 64, 3211264.0), (1152, 33, 12544.0),
+                                             (24, 1031, 802816.0), (48, 2048, 3211264.0)])   # block-per-channel path
 def test_bn_fwd_finalize(C_, nparts, count):
     lib = L.load()
     u = O.det_uniform((2, C_, nparts), 3)
@@ -443,3 +444,43 @@ def test_run_ops_batch():
     # a bad opcode is reported, not ignored
     ops[1].opcode = 999
     assert lib.mnas_run_ops(ops, 3, L.cur_stream(), C.byref(failed)) != 0 and failed.value == 1
+
+
+@pytest.mark.parametrize("C_,nparts", [(16, 1024), (40, 257), (1152, 64)])
+def test_bn_bwd_finalize_long_rows(C_, nparts):
+    """Both finalize shapes (wave per channel / block per channel) against an fp64 sum of the same partial table."""
+    lib = L.load()
+    partial = O.det_uniform((2, C_, nparts), 31)
+    b = rand_bn_coefs(C_, 9, O)
+    bd, pd = b.clone().cuda(), partial.clone().cuda()
+    dgamma, dbeta = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    rows = 12345.0
+    L.check(lib.mnas_bn_bwd_finalize(pd.data_ptr(), nparts, C_, rows, bd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                     0, L.cur_stream()))
+    S = partial.double().sum(-1)
+    s, mean, invstd = b[0].double(), b[5].double(), b[6].double()
+    out = bd.cpu().double()
+    assert relerr(dbeta.cpu(), S[0]) < 1e-5 and relerr(dgamma.cpu(), S[1]) < 1e-5
+    assert relerr(out[3], -s * invstd * S[1] / rows) < 1e-5
+    assert relerr(out[4], s * (mean * invstd * S[1] / rows - S[0] / rows)) < 1e-5
+
+
+@pytest.mark.parametrize("nsplit,Co,Ci,taps,acc", [(5, 24, 16, 1, 0), (300, 16, 48, 1, 1), (300, 16, 48, 1, 0),
+                                                   (1024, 16, 32, 1, 1), (129, 8, 8, 9, 1)])
+def test_wgrad_finalize_split_ranges(nsplit, Co, Ci, taps, acc):
+    """Split ranges longer than one block's share are cut over grid.y (atomic combine) in accumulate mode and walked by
+    one block in overwrite mode; dense [Co][taps*Ci] -> [Co][Ci][taps] and depthwise [taps][C] -> [C][taps] relayouts."""
+    lib = L.load()
+    part = O.det_uniform((nsplit, Co, taps * Ci), 41)
+    init = O.det_uniform((Co, Ci, taps), 42)
+    grad = init.clone().cuda()
+    L.check(lib.mnas_wgrad_finalize(part.cuda().data_ptr(), nsplit, Co, Ci, taps, grad.data_ptr(), acc, L.cur_stream()))
+    ref = part.double().sum(0).view(Co, taps, Ci).permute(0, 2, 1) + (init.double() if acc else 0)
+    assert relerr(grad.cpu(), ref) < 1e-5
+    k = 3
+    dpart = O.det_uniform((nsplit, k * k, Co), 43)
+    dinit = O.det_uniform((Co, k * k), 44)
+    dgrad = dinit.clone().cuda()
+    L.check(lib.mnas_dw_wgrad_finalize(dpart.cuda().data_ptr(), nsplit, Co, k, dgrad.data_ptr(), acc, L.cur_stream()))
+    dref = dpart.double().sum(0).t() + (dinit.double() if acc else 0)
+    assert relerr(dgrad.cpu(), dref) < 1e-5
