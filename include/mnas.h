@@ -107,8 +107,10 @@ typedef struct MnasConvWgrad {
 } MnasConvWgrad;
 int mnas_conv_wgrad(const MnasConvWgrad* a, void* stream);
 
-/* grad[co][ci][kh][kw] (reference layout, fp32) (+)= sum_s partial[s][co][tap*Ci+ci] */
-int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps,
+/* grad[co][ci][kh][kw] (reference layout, fp32) (+)= sum_s partial[s][co][tap*Ci+ci].  Deterministic (fixed summation
+ * order, no atomics).  `partial` is scratch: with more than 256 splits the first row of every 128-row chunk is
+ * overwritten by the chunk's sum (two-level reduction). */
+int mnas_wgrad_finalize(float* partial, int nsplit, int Co, int Ci, int taps,
                         float* grad, int accumulate, void* stream);
 
 /* ---- depthwise kxk (k in {3,5}, stride 1, pad k/2), LDS-tiled direct conv on the vector ALU ----------
@@ -143,13 +145,13 @@ typedef struct MnasDwBwd {
      * phase 0 and mnas_dw_rows(...,2) for phase 1 */
     const float* red_bn;
     float* red_partial;
-    int32_t phase;           /* 0: both launches; 1: input gradient only; 2: weight gradient only (lets the caller put
-                                the two on different streams) */
+    int32_t phase;           /* 0: one fused sweep (input gradient + weight gradient + reduce); 1: input gradient (+reduce)
+                                only; 2: weight gradient only (lets the caller put the two on different streams) */
     int32_t reserved;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
-/* grad[c][0][kh][kw] (+)= sum_{p<nparts} wpartial[p][tap][c]   (pass nparts = rows1) */
-int mnas_dw_wgrad_finalize(const float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
+/* grad[c][0][kh][kw] (+)= sum_{p<nparts} wpartial[p][tap][c]   (pass nparts = rows1); wpartial is scratch like above */
+int mnas_dw_wgrad_finalize(float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
                            void* stream);
 
 /* ---- stem: dense 3x3 stride 2 pad 1 on the fp32 NCHW network input (mnasnet.py:179) ------------------ */

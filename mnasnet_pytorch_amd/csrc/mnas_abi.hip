@@ -45,7 +45,7 @@ static int run_one(const MnasOp& o, void* stream) {
             return mnas_conv_wgrad(&a, stream);
         }
         case MNAS_OP_WGRAD_FINALIZE:
-            return mnas_wgrad_finalize((const float*)p[0], i[0], i[1], i[2], i[3], (float*)p[1], i[4], stream);
+            return mnas_wgrad_finalize((float*)p[0], i[0], i[1], i[2], i[3], (float*)p[1], i[4], stream);
         case MNAS_OP_DW_FWD: {
             MnasDwFwd a = {};
             a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.k = i[4]; a.nparts = i[5];
@@ -63,7 +63,7 @@ static int run_one(const MnasOp& o, void* stream) {
             return mnas_dw_bwd(&a, stream);
         }
         case MNAS_OP_DW_WGRAD_FINALIZE:
-            return mnas_dw_wgrad_finalize((const float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], stream);
+            return mnas_dw_wgrad_finalize((float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], stream);
         case MNAS_OP_STEM_FWD: {
             MnasStemFwd a = {};
             a.N = i[0]; a.H = i[1]; a.W = i[2]; a.Ho = i[3]; a.Wo = i[4]; a.Co = i[5]; a.nparts = i[6];

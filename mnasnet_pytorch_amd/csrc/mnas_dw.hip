@@ -23,6 +23,7 @@
 //     launches for 5x5 (the fused form needs 2*k*k*2 persistent accumulators on top of the two register rings).
 // Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5 forward; backward moves 4 tensors for 2x the FMAs).
 #include "mnas_common.h"
+#include <cstdlib>
 
 #define DW_G 4          // rows per sweep step
 #define DW_BW 4         // output columns per thread
@@ -52,7 +53,8 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, DwArgs* a) {
         for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
             const int tw = sx * DW_BW, iw = tw + k - 1;
             const size_t lds = (size_t)nrings * DW_RR * iw * cpw * 4;
-            if (lds > 60 * 1024) continue;
+            static const int cap_kb = getenv("MNAS_DW_LDS_KB") ? atoi(getenv("MNAS_DW_LDS_KB")) : 60;   // EXPERIMENT
+            if (lds > (size_t)cap_kb * 1024) continue;
             const int nth = ((sx * cpw + 63) / 64) * 64;
             const int rc = iw * cgn;
             if ((rc + 63) / 64 > 2 * (nth / 64)) continue;          // <= 2 DMA blocks per wave per row
@@ -178,6 +180,29 @@ __device__ __forceinline__ void dw_read_dy(const uint32_t* growp, const uint32_t
     }
 }
 
+// Deterministic workgroup reduction of per-thread accumulators v[NV][2] (thread = channel pair cp x column strip sxi)
+// over the column strips: every thread parks its values in LDS (the row rings are dead once the sweep is over; they
+// are always large enough: sx*NV*cblk*4 B <= nrings*RR*iw*cpw*4 B), then NV*cblk threads add the sx copies in strip
+// order.  No float atomics, so the partial tables are bit-reproducible run to run.
+template <int NV, typename F>
+__device__ __forceinline__ void dw_block_reduce(float* scratch, const float (&v)[NV][2], int cp, int sxi, int sx, int cblk,
+                                                bool active, F&& emit) {
+    __syncthreads();                                   // all ring reads done
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            scratch[(sxi * NV + k) * cblk + 2 * cp] = v[k][0];
+            scratch[(sxi * NV + k) * cblk + 2 * cp + 1] = v[k][1];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV * cblk; i += blockDim.x) {
+        float acc = scratch[i];
+        for (int sidx = 1; sidx < sx; ++sidx) acc += scratch[sidx * NV * cblk + i];
+        emit(i / cblk, i % cblk, acc);
+    }
+}
+
 // ---- forward -----------------------------------------------------------------------------------------------------
 template <int KS>
 __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, MnasActIn in, const float* __restrict__ w,
@@ -186,8 +211,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
     const int cblk = 2 * a.cpw;
-    float* lds_red = (float*)smem;                       // [2][cblk]
-    uint32_t* ring = (uint32_t*)(lds_red + 2 * cblk);    // [RR][rc*4 dwords]
+    uint32_t* ring = (uint32_t*)smem;                    // [RR][rc*4 dwords]; reused as reduction scratch at the end
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
@@ -276,20 +300,14 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     if (stats) {
         // stats table is float[2][C][rows], rows = geff / cblocks: workgroup b owns column b / cblocks of its own
         // channel block (b % cblocks), so every (channel, column) is written exactly once -- no zero fill, no atomics
-        __syncthreads();
-        for (int i = tid; i < 2 * cblk; i += blockDim.x) lds_red[i] = 0.f;
-        __syncthreads();
-        if (active && cur_c0 >= 0 && cur_c0 + 2 * cp < a.C) {
-            atomicAdd(&lds_red[2 * cp], s1[0]); atomicAdd(&lds_red[2 * cp + 1], s1[1]);
-            atomicAdd(&lds_red[cblk + 2 * cp], s2[0]); atomicAdd(&lds_red[cblk + 2 * cp + 1], s2[1]);
-        }
-        __syncthreads();
         const int rows = a.geff / a.cblocks, col = blockIdx.x / a.cblocks;
         const int cb0 = (blockIdx.x % a.cblocks) * cblk;
-        for (int i = tid; i < 2 * cblk; i += blockDim.x) {
-            const int r = i / cblk, c = cb0 + i % cblk;
-            if (c < a.C) stats[((size_t)r * a.C + c) * rows + col] = (cur_c0 >= 0) ? lds_red[i] : 0.f;
-        }
+        const float sv[2][2] = {{s1[0], s1[1]}, {s2[0], s2[1]}};
+        const bool any = cur_c0 >= 0;
+        dw_block_reduce<2>((float*)ring, sv, cp, sxi, a.sx, cblk, active, [&](int r, int cl, float v) {
+            const int c = cb0 + cl;
+            if (c < a.C) stats[((size_t)r * a.C + c) * rows + col] = any ? v : 0.f;
+        });
     }
 }
 
@@ -308,8 +326,7 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
     constexpr bool NEEDX = WG;                 // x ring only when the weight gradient is computed here
     constexpr bool REDG = RED && !WG;          // input-gradient-only launch: the reduce reads raw x from global (2 rings)
     const int cblk = 2 * a.cpw;
-    float* lds_red = (float*)smem;                           // [KS*KS][cblk]
-    uint32_t* ring_g = (uint32_t*)(lds_red + KS * KS * cblk);
+    uint32_t* ring_g = (uint32_t*)smem;                      // rings; reused as reduction scratch at the end
     uint32_t* ring_y = ring_g + (size_t)DW_RR * a.rc * 4;
     uint32_t* ring_x = ring_y + (size_t)DW_RR * a.rc * 4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -472,36 +489,19 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
     }
     const int row = blockIdx.x / a.cblocks, rows = a.geff / a.cblocks;
     const int cb0 = (blockIdx.x % a.cblocks) * cblk;
-    if (RED) {      // fused-reduce table float[2][C][rows]
-        __syncthreads();
-        for (int i = tid; i < 2 * cblk; i += blockDim.x) lds_red[i] = 0.f;
-        __syncthreads();
-        if (active && cur_c0 >= 0 && cur_c0 + 2 * cp < a.C) {
-            atomicAdd(&lds_red[2 * cp], s1[0]); atomicAdd(&lds_red[2 * cp + 1], s1[1]);
-            atomicAdd(&lds_red[cblk + 2 * cp], s2[0]); atomicAdd(&lds_red[cblk + 2 * cp + 1], s2[1]);
-        }
-        __syncthreads();
-        for (int i = tid; i < 2 * cblk; i += blockDim.x) {
-            const int r = i / cblk, c = cb0 + i % cblk;
-            if (c < a.C) red_partial[((size_t)r * a.C + c) * rows + row] = (cur_c0 >= 0) ? lds_red[i] : 0.f;
-        }
+    const bool any = cur_c0 >= 0;
+    if constexpr (RED) {      // fused-reduce table float[2][C][rows]
+        const float sv[2][2] = {{s1[0], s1[1]}, {s2[0], s2[1]}};
+        dw_block_reduce<2>((float*)ring_g, sv, cp, sxi, a.sx, cblk, active, [&](int r, int cl, float v) {
+            const int c = cb0 + cl;
+            if (c < a.C) red_partial[((size_t)r * a.C + c) * rows + row] = any ? v : 0.f;
+        });
     }
-    if (WG) {       // wpartial float[rows][k*k][C]
-        __syncthreads();
-        for (int i = tid; i < KS * KS * cblk; i += blockDim.x) lds_red[i] = 0.f;
-        __syncthreads();
-        if (active && cur_c0 >= 0 && cur_c0 + 2 * cp < a.C) {
-#pragma unroll
-            for (int k = 0; k < KS * KS; ++k) {
-                atomicAdd(&lds_red[k * cblk + 2 * cp], wacc[k][0]);
-                atomicAdd(&lds_red[k * cblk + 2 * cp + 1], wacc[k][1]);
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < KS * KS * cblk; i += blockDim.x) {
-            const int k = i / cblk, c = cb0 + i % cblk;
-            if (c < a.C) wpartial[((size_t)row * KS * KS + k) * a.C + c] = (cur_c0 >= 0) ? lds_red[i] : 0.f;
-        }
+    if constexpr (WG) {       // wpartial float[rows][k*k][C]
+        dw_block_reduce<KS * KS>((float*)ring_g, wacc, cp, sxi, a.sx, cblk, active, [&](int k, int cl, float v) {
+            const int c = cb0 + cl;
+            if (c < a.C) wpartial[((size_t)row * KS * KS + k) * a.C + c] = any ? v : 0.f;
+        });
     }
 }
 
@@ -520,7 +520,7 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
     DwArgs a;
     if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;
-    const size_t lds = (size_t)2 * 2 * a.cpw * sizeof(float) + (size_t)DW_RR * a.rc * 16;
+    const size_t lds = (size_t)DW_RR * a.rc * 16;
     hipStream_t s = (hipStream_t)stream;
     if (c->k == 3)
         hipLaunchKernelGGL(k_dw_fwd<3>, dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, (uint32_t*)c->out, c->stats);
@@ -539,7 +539,7 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     const int nrings = want_wg ? 3 : 2;
     DwArgs a;
     if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, nrings, c->nparts)) return MNAS_EINVAL;
-    const size_t lds = (size_t)c->k * c->k * 2 * a.cpw * sizeof(float) + (size_t)nrings * DW_RR * a.rc * 16;
+    const size_t lds = (size_t)nrings * DW_RR * a.rc * 16;
 #define MNAS_DWB(K_, DG_, WG_, R_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, \
                                                      c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
     if (c->k == 3) {

@@ -105,12 +105,10 @@ extern "C" int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, dou
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const uint4* __restrict__ g, const uint4* __restrict__ y,
                                                        const float* __restrict__ bnbuf, int64_t rows, int C,
                                                        float* __restrict__ partial) {
-    extern __shared__ float red[];   // [2][C]
+    extern __shared__ float red[];   // [R][2][C]: one slot per (row lane, channel), summed in row-lane order (deterministic)
     const int G = C >> 3;
     const int R = 256 / G;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
-    __syncthreads();
     const int64_t chunk = (rows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * chunk;
     const int64_t r1 = min(rows, r0 + chunk);
@@ -141,18 +139,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const uint4* __restrict__
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            atomicAdd(&red[cg * 8 + j], a1[j]);
-            atomicAdd(&red[C + cg * 8 + j], a2[j]);
+            red[(rl * 2 + 0) * C + cg * 8 + j] = a1[j];
+            red[(rl * 2 + 1) * C + cg * 8 + j] = a2[j];
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * C; i += 256) partial[(size_t)i * gridDim.x + blockIdx.x] = red[i];   // [2][C][P]
+    for (int i = tid; i < 2 * C; i += 256) {
+        float v = red[i];
+        for (int rl = 1; rl < R; ++rl) v += red[rl * 2 * C + i];
+        partial[(size_t)i * gridDim.x + blockIdx.x] = v;   // [2][C][P]
+    }
 }
 
 extern "C" int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnbuf, int64_t rows, int C, int nparts,
                                   float* partial, void* stream) {
     if (C <= 0 || (C & 7) || C > 2048 || nparts <= 0) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nparts), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nparts), dim3(256), (size_t)(256 / (C >> 3)) * 2 * C * sizeof(float), (hipStream_t)stream,
                        (const uint4*)g, (const uint4*)y, bnbuf, rows, C, partial);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
@@ -338,18 +340,20 @@ extern "C" int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int k
 // ------------------------------------------------------------------------------------------------
 // wgrad reductions (+ relayout to the reference's [Co][Ci][kh][kw])
 // ------------------------------------------------------------------------------------------------
-// 32 outputs x 8 split lanes per block; a block covers <= FIN_SPLITS partial rows (16 independent loads per thread).
-// Longer split ranges are cut over grid.y and combined with global float atomics (accumulate mode only).
+// 32 outputs x 8 split lanes per block, 16 independent loads per thread and pass.  Split ranges longer than FIN_SPLITS
+// rows are reduced in two deterministic levels: level 1 (FOLD) cuts the range over grid.y and writes each chunk's sum
+// back into the chunk's FIRST partial row (in place: a block only touches its own 32 columns); level 2 sums those rows
+// (row stride FIN_SPLITS) and applies the relayout to the reference's weight layout.  No float atomics.
 #define FIN_SPLITS 128
-template <bool DW>
-__global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict__ partial, int nsplit, int Co, int Ci,
+template <bool DW, bool FOLD>
+__global__ __launch_bounds__(256) void k_wgrad_finalize(float* __restrict__ partial, int nsplit, int pstride, int Co, int Ci,
                                                          int taps, float* __restrict__ grad, int accumulate) {
     __shared__ float red[8][33];
     const int K = taps * Ci;
     const int total = DW ? Co * taps : Co * K;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;
-    const int p0 = blockIdx.y * FIN_SPLITS, p1 = (gridDim.y == 1) ? nsplit : min(nsplit, p0 + FIN_SPLITS);
+    const int p0 = FOLD ? blockIdx.y * FIN_SPLITS : 0, p1 = FOLD ? min(nsplit, p0 + FIN_SPLITS) : nsplit;
     float s = 0.f;
     if (i < total) {
         const float* src = partial + i;
@@ -357,9 +361,9 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict_
         int p = p0 + ty;
         for (; p + 24 < p1; p += 32) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] += src[(size_t)(p + 8 * j) * total];
+            for (int j = 0; j < 4; ++j) a[j] += src[(size_t)(p + 8 * j) * pstride * total];
         }
-        for (; p < p1; p += 8) s += src[(size_t)p * total];
+        for (; p < p1; p += 8) s += src[(size_t)p * pstride * total];
         s += (a[0] + a[1]) + (a[2] + a[3]);
     }
     red[ty][tx] = s;
@@ -367,6 +371,10 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict_
     if (ty == 0 && i < total) {
 #pragma unroll
         for (int j = 1; j < 8; ++j) s += red[j][tx];
+        if (FOLD) {
+            partial[(size_t)p0 * total + i] = s;
+            return;
+        }
         float* d;
         if (DW) {          // wpartial rows are [taps][C]; reference layout [C][1][kh][kw]
             const int tap = i / Co, c = i % Co;
@@ -376,27 +384,33 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict_
             const int tap = k / Ci, ci = k % Ci;
             d = grad + ((size_t)co * Ci + ci) * taps + tap;
         }
-        if (gridDim.y > 1) atomicAdd(d, s);
-        else *d = (accumulate ? *d : 0.f) + s;
+        *d = (accumulate ? *d : 0.f) + s;
     }
 }
 template <bool DW>
-static int launch_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps, float* grad, int accumulate,
+static int launch_wgrad_finalize(float* partial, int nsplit, int Co, int Ci, int taps, float* grad, int accumulate,
                                  void* stream) {
     if (!partial || !grad || nsplit < 1 || Co < 1 || Ci < 1 || taps < 1) return MNAS_EINVAL;
     const int total = DW ? Co * taps : Co * Ci * taps;
-    // overwrite mode must stay a single deterministic pass (no zero-fill launch hidden in here)
-    const int ny = accumulate ? (nsplit + FIN_SPLITS - 1) / FIN_SPLITS : 1;
-    hipLaunchKernelGGL(k_wgrad_finalize<DW>, dim3((total + 31) / 32, ny), dim3(256), 0, (hipStream_t)stream, partial,
-                       nsplit, Co, Ci, taps, grad, accumulate);
+    const int nx = (total + 31) / 32;
+    if (nsplit > 2 * FIN_SPLITS) {
+        const int ny = (nsplit + FIN_SPLITS - 1) / FIN_SPLITS;
+        hipLaunchKernelGGL((k_wgrad_finalize<DW, true>), dim3(nx, ny), dim3(256), 0, (hipStream_t)stream, partial, nsplit, 1,
+                           Co, Ci, taps, grad, accumulate);
+        hipLaunchKernelGGL((k_wgrad_finalize<DW, false>), dim3(nx, 1), dim3(256), 0, (hipStream_t)stream, partial, ny,
+                           FIN_SPLITS, Co, Ci, taps, grad, accumulate);
+    } else {
+        hipLaunchKernelGGL((k_wgrad_finalize<DW, false>), dim3(nx, 1), dim3(256), 0, (hipStream_t)stream, partial, nsplit, 1,
+                           Co, Ci, taps, grad, accumulate);
+    }
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
-extern "C" int mnas_wgrad_finalize(const float* partial, int nsplit, int Co, int Ci, int taps, float* grad,
+extern "C" int mnas_wgrad_finalize(float* partial, int nsplit, int Co, int Ci, int taps, float* grad,
                                    int accumulate, void* stream) {
     return launch_wgrad_finalize<false>(partial, nsplit, Co, Ci, taps, grad, accumulate, stream);
 }
-extern "C" int mnas_dw_wgrad_finalize(const float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
+extern "C" int mnas_dw_wgrad_finalize(float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
                                       void* stream) {
     return launch_wgrad_finalize<true>(wpartial, nparts, C, 1, k * k, grad, accumulate, stream);
 }

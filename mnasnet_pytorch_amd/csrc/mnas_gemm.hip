@@ -34,7 +34,7 @@ struct IgemmArgs {
     const float* red_bn;
 };
 
-template <int MODE, int NT, int PT, int KCH>
+template <int MODE, int NT, int PT, int KCH, bool PIPE>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     constexpr int ldk = KCH + 8;                   // LDS row stride in bf16 elements (16-byte padded)
     constexpr int kc8n = KCH >> 3;                 // 16-byte chunks per row
     constexpr int KSH = (KCH == 128) ? 4 : (KCH == 64) ? 3 : 2;       // log2(kc8n)
-    const int ccols = (a.taps == 1) ? kch : a.Ci;  // coefficient columns kept in LDS
+    const int ccols = (a.taps == 1) ? a.Kpad : a.Ci;   // coefficient columns kept in LDS (whole K: no per-chunk reload)
     float* lds_coef = (float*)smem;                                        // [CROWS][ccols]
     float* lds_red = lds_coef + CROWS * ccols;                             // [2][NT*16]
     float* lds_redc = lds_red + 2 * NT * 16;                               // [4][NT*16] fused-reduce coefficients
@@ -63,36 +63,41 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         for (int r = 0; r < CROWS; ++r) coef_src[r] = a.grad.coef + (size_t)r * a.Ci;
     }
 
-    auto load_coefs = [&](int k0) {
+    auto load_coefs = [&]() {
         if (!has_coef) return;
         for (int i = tid; i < CROWS * ccols; i += 256) {
-            const int r = i / ccols, c = (a.taps == 1 ? k0 : 0) + i % ccols;
+            const int r = i / ccols, c = i % ccols;
             lds_coef[i] = (c < a.Ci) ? coef_src[r][c] : 0.f;
         }
     };
-    auto stage_w = [&](int k0) {
-        constexpr int NW = (NT * 16 * kc8n + 255) / 256;
-        uint4 v[NW];
+    constexpr int NW = (NT * 16 * kc8n + 255) / 256;
+    uint4 wv[NW];
+    auto load_w = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int q = tid + 256 * i;
             const int r = q >> KSH, kc8 = q & (kc8n - 1);
             const int k = k0 + kc8 * 8;
-            v[i] = make_uint4(0, 0, 0, 0);
-            if (r < NT * 16 && n0 + r < a.co_pad16 && k < a.Kpad) v[i] = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + k);
+            wv[i] = make_uint4(0, 0, 0, 0);
+            if (r < NT * 16 && n0 + r < a.co_pad16 && k < a.Kpad) wv[i] = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + k);
         }
+    };
+    auto store_w = [&]() {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int q = tid + 256 * i;
             const int r = q >> KSH, kc8 = q & (kc8n - 1);
-            if (r < NT * 16) *(uint4*)(lds_w + r * ldk + kc8 * 8) = v[i];
+            if (r < NT * 16) *(uint4*)(lds_w + r * ldk + kc8 * 8) = wv[i];
         }
     };
-    // activation / gradient tile: each thread owns NA (pixel, k-chunk) slots; its k-chunk column is the same
-    // for all of them (256 % kc8n == 0), so the per-channel coefficients are fetched once per call, and all
-    // loads of the call are issued before the first one is consumed
-    auto stage_a = [&](int tile0, int k0) {
-        constexpr int NA = BP * kc8n / 256;
+    // activation / gradient tile: each thread owns NA (pixel, k-chunk) slots; its k-chunk column is the same for all of
+    // them (256 % kc8n == 0), so the per-channel coefficients are fetched once per chunk.  Software pipeline: load_a
+    // issues the global loads of the NEXT (tile, chunk) before the MFMA phase of the current one; store_a applies the
+    // prologue transform and writes LDS one phase later, when they have landed.
+    constexpr int NA = BP * kc8n / 256;
+    uint4 v0[NA], v1[MODE == 1 ? NA : 1];
+    unsigned okm = 0;
+    auto load_a = [&](int tile0, int k0) {
         const int kc8 = tid & (kc8n - 1);
         const int k = k0 + kc8 * 8;
         const bool kok = k < a.Ktot;
@@ -102,15 +107,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
             ci = k - tap * a.Ci;
             th = tap / a.kw; tw = tap - th * a.kw;
         }
-        uint4 v0[NA], v1[NA];
-        bool ok[NA];
+        okm = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int p = (tid >> KSH) + (256 >> KSH) * i;
             const int m = tile0 + p;
             v0[i] = make_uint4(0, 0, 0, 0);
             if (MODE == 1) v1[i] = make_uint4(0, 0, 0, 0);
-            ok[i] = false;
             if (MODE == 2) {
                 // stem (mnasnet.py:179): im2col of the fp32 NCHW image, k = ci*9 + kh*3 + kw (reference
                 // weight order), 3x3 stride 2 pad 1; Hi,Wi = image dims
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                     src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + ci;
                 }
                 if (inb) {
-                    ok[i] = true;
+                    okm |= 1u << i;
                     if (MODE != 1) {
                         v0[i] = *(const uint4*)((const uint16_t*)a.act.data + src);
                     } else {
@@ -165,8 +168,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                 }
             }
         }
+    };
+    auto store_a = [&](int k0) {
+        const int kc8 = tid & (kc8n - 1);
         if (MODE != 2 && has_coef) {
-            const int cc = (a.taps == 1) ? (k - k0) : ci;
+            const int k = k0 + kc8 * 8;
+            int cc = k;
+            if (a.taps != 1) cc = k - (k / a.Ci) * a.Ci;
             float cf[CROWS][8];
 #pragma unroll
             for (int r = 0; r < CROWS; ++r) {
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                if (!ok[i]) continue;
+                if (!((okm >> i) & 1u)) continue;
                 if (MODE == 0) {
                     v0[i] = act8(v0[i], cf[0], cf[1]);
                 } else if (MODE == 1) {
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = n0 + nt * 16 + lg * 4 + r;
-            bias_r[nt][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+            bias_r[nt][r] = (MODE != 1 && a.bias && co < a.Co) ? a.bias[co] : 0.f;   // dgrad has no bias term
         }
     float s1[NT][4], s2[NT][4];
 #pragma unroll
@@ -222,14 +230,17 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         }
     }
 
-    if (nkc == 1) {       // weights + coefficients are tile-invariant: stage once
-        load_coefs(0);
-        stage_w(0);
-    } else if (a.taps != 1) {
-        load_coefs(0);    // all Ci channels resident
+    load_coefs();
+    if (nkc == 1) {       // weights are tile-invariant: stage once
+        load_w(0);
+        store_w();
     }
 
     const int ntiles = (a.M + BP - 1) / BP;
+    if (PIPE && (int)blockIdx.x < ntiles) {
+        load_a(blockIdx.x * BP, 0);
+        if (nkc > 1) load_w(0);
+    }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tile0 = t * BP;
         f32x4_t acc[PT][NT];
@@ -254,13 +265,23 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         }
         for (int kc = 0; kc < nkc; ++kc) {
             const int k0 = kc * kch;
-            __syncthreads();                       // previous chunk's fragments consumed
-            if (nkc > 1) {
-                if (a.taps == 1) { load_coefs(k0); __syncthreads(); }
-                stage_w(k0);
+            __syncthreads();                       // previous chunk's fragments consumed (first pass: coefficients visible)
+            if (!PIPE) {
+                load_a(tile0, k0);
+                if (nkc > 1) load_w(k0);
             }
-            stage_a(tile0, k0);
+            store_a(k0);
+            if (nkc > 1) store_w();
             __syncthreads();
+            // next (tile, chunk) of this workgroup: its loads fly under the MFMAs (and the epilogue / next ypre fetch)
+            if (PIPE) {
+                int nt_ = t, nk_ = kc + 1;
+                if (nk_ == nkc) { nk_ = 0; nt_ = t + gridDim.x; }
+                if (nt_ < ntiles) {
+                    load_a(nt_ * BP, nk_ * kch);
+                    if (nkc > 1) load_w(nk_ * kch);
+                }
+            }
             const int ksteps = min(kch, a.Kpad - k0) >> 5;
             for (int ks = 0; ks < ksteps; ++ks) {
                 bf16x8_t bfrag[PT];
@@ -324,8 +345,9 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     }
 
     if ((MODE != 1 || do_red) && a.stats) {
-        __syncthreads();
-        for (int i = tid; i < 2 * NT * 16; i += 256) lds_red[i] = 0.f;
+        // deterministic workgroup reduction: 16-lane shuffle tree, one LDS slot per (wave, channel), waves summed in
+        // fixed order (no float atomics: results are bit-reproducible run to run)
+        float* red4 = (float*)lds_a;                    // [4 waves][2][NT*16], the activation tile is dead by now
         __syncthreads();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -335,38 +357,51 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
                 if (l15 == 0) {
-                    atomicAdd(&lds_red[nt * 16 + lg * 4 + r], x1);
-                    atomicAdd(&lds_red[NT * 16 + nt * 16 + lg * 4 + r], x2);
+                    red4[(wave * 2 + 0) * NT * 16 + nt * 16 + lg * 4 + r] = x1;
+                    red4[(wave * 2 + 1) * NT * 16 + nt * 16 + lg * 4 + r] = x2;
                 }
             }
         __syncthreads();
         for (int i = tid; i < 2 * NT * 16; i += 256) {
-            const int r = i / (NT * 16), c = n0 + i % (NT * 16);
-            if (c < a.Co) a.stats[((size_t)r * a.Co + c) * gridDim.x + blockIdx.x] = lds_red[i];   // [2][Co][P]
+            const int r = i / (NT * 16), cl = i % (NT * 16), c = n0 + cl;
+            const float v = ((red4[(0 * 2 + r) * NT * 16 + cl] + red4[(1 * 2 + r) * NT * 16 + cl]) +
+                             red4[(2 * 2 + r) * NT * 16 + cl]) + red4[(3 * 2 + r) * NT * 16 + cl];
+            if (c < a.Co) a.stats[((size_t)r * a.Co + c) * gridDim.x + blockIdx.x] = v;   // [2][Co][P]
         }
     }
 }
 
 template <int MODE, int NT, int PT, int KCH>
-static int launch_igemm_k(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
+static int launch_igemm_k(const IgemmArgs& a, int nparts, int nblocks, bool pipe, hipStream_t stream) {
     constexpr int CROWS = (MODE == 1) ? 5 : 2;
-    const int ccols = (a.taps == 1) ? a.kch : a.Ci;
+    const int ccols = (a.taps == 1) ? a.Kpad : a.Ci;
     const size_t lds = (size_t)(CROWS * ccols + 6 * NT * 16) * sizeof(float) +
                        (size_t)(NT * 16 + 64 * PT) * (a.kch + 8) * 2;
     if (lds > 160 * 1024) return MNAS_EINVAL;
-    hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+    if (pipe) hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, true>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, false>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
 template <int MODE, int NT, int PT>
 static int launch_igemm(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
+    // Software pipelining (global loads of the next (tile, chunk) in flight under the MFMA phase) costs 30-50 VGPRs.
+    // It pays when a workgroup walks several load phases (long K, persistent tile loops) and the extra registers do
+    // not halve the occupancy; measured per layer shape on MI355X (igemm table).
+    const int ntiles = (a.M + 64 * PT - 1) / (64 * PT);
+    const int nkc = (a.Kpad + a.kch - 1) / a.kch;
+    const int phases = nkc * ((ntiles + nparts - 1) / nparts);
+    const bool s2 = a.taps > 1 && a.stride == 2;
+    bool pipe;
+    if (MODE == 0) pipe = phases >= 4 && !(s2 && PT == 2) && !(NT >= 6 && PT == 2);
+    else pipe = phases >= 2 && nkc > 1 && !s2;
     // long reductions on small pixel counts (the 14x14 / 7x7 stages, dense 3x3): 128-wide K chunks put 4x more
     // bytes in flight per staging pass (these launches are latency-bound, not bandwidth-bound)
     if constexpr (PT == 1 && (NT == 2 || NT == 3 || NT == 6)) {
-        if (a.kch == 128) return launch_igemm_k<MODE, NT, PT, 128>(a, nparts, nblocks, stream);
+        if (a.kch == 128) return launch_igemm_k<MODE, NT, PT, 128>(a, nparts, nblocks, pipe, stream);
     }
-    return a.kch >= 64 ? launch_igemm_k<MODE, NT, PT, 64>(a, nparts, nblocks, stream)
-                       : launch_igemm_k<MODE, NT, PT, 32>(a, nparts, nblocks, stream);
+    return a.kch >= 64 ? launch_igemm_k<MODE, NT, PT, 64>(a, nparts, nblocks, pipe, stream)
+                       : launch_igemm_k<MODE, NT, PT, 32>(a, nparts, nblocks, pipe, stream);
 }
 
 extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
@@ -439,8 +474,8 @@ extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     a.red_y = nullptr; a.red_bn = nullptr;
     const int tiles = (c->Co + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    if (tiles == 1) return launch_igemm_k<2, 1, 2, 32>(a, c->nparts, 1, s);
-    if (tiles == 2) return launch_igemm_k<2, 2, 2, 32>(a, c->nparts, 1, s);
-    if (tiles <= 4) return launch_igemm_k<2, 4, 2, 32>(a, c->nparts, 1, s);
-    return launch_igemm_k<2, 8, 2, 32>(a, c->nparts, 1, s);
+    if (tiles == 1) return launch_igemm_k<2, 1, 2, 32>(a, c->nparts, 1, true, s);
+    if (tiles == 2) return launch_igemm_k<2, 2, 2, 32>(a, c->nparts, 1, true, s);
+    if (tiles <= 4) return launch_igemm_k<2, 4, 2, 32>(a, c->nparts, 1, true, s);
+    return launch_igemm_k<2, 8, 2, 32>(a, c->nparts, 1, true, s);
 }

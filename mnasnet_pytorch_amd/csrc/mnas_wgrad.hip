@@ -10,8 +10,8 @@
 //
 // A workgroup owns a (<=64 cout) x (<=64 k) slab of dW and a contiguous range of pixels; its 4 waves split
 // each 128-pixel chunk (32 pixels = one MFMA k-step each) and hold the whole slab in accumulators; the
-// four copies are summed through LDS once at the end and written to partial[split][co][k] (plain stores, no
-// atomics, deterministic); mnas_wgrad_finalize reduces the splits.
+// four copies are summed through LDS in wave order once at the end and written to partial[split][co][k] (plain
+// stores, no atomics, deterministic); mnas_wgrad_finalize reduces the splits.
 // dy-on-load and act-on-load are applied while staging, exactly as in mnas_gemm.hip.
 #include "mnas_common.h"
 
@@ -208,18 +208,23 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
                 if (kt < ktn) acc[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[kt], acc[ct][kt], 0, 0, 0);
         }
     }
-    // ---- sum the 4 waves' slabs through LDS, then write partial[split][co][k]
-    __syncthreads();
-    for (int i = tid; i < 64 * 65; i += 256) lds_out[i] = 0.f;
-    __syncthreads();
+    // ---- sum the 4 waves' slabs through LDS in wave order (each lane owns its elements: no atomics, the sum is
+    // bit-reproducible), then write partial[split][co][k]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave != w) continue;
 #pragma unroll
-    for (int ct = 0; ct < WG_T; ++ct)
+        for (int ct = 0; ct < WG_T; ++ct)
 #pragma unroll
-        for (int kt = 0; kt < WG_T; ++kt) {
-            if (ct >= ctn || kt >= ktn) continue;
+            for (int kt = 0; kt < WG_T; ++kt) {
+                if (ct >= ctn || kt >= ktn) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&lds_out[(ct * 16 + lg * 4 + r) * 65 + kt * 16 + l15], acc[ct][kt][r]);
-        }
+                for (int r = 0; r < 4; ++r) {
+                    float* d = &lds_out[(ct * 16 + lg * 4 + r) * 65 + kt * 16 + l15];
+                    *d = (w == 0 ? 0.f : *d) + acc[ct][kt][r];
+                }
+            }
+    }
     __syncthreads();
     float* dst = a.partial + (size_t)blockIdx.x * a.Co * a.Ktot;
     for (int i = tid; i < 64 * 64; i += 256) {
