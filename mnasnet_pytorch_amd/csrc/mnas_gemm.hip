@@ -23,6 +23,7 @@ struct IgemmArgs {
     int M, Hi, Wi, Ci, Ho, Wo, Co;
     int kh, kw, stride, pad;
     int Ktot, Kpad, kch, taps, is_pw, co_pad16;
+    int s2, Mc, tpc;         // MODE 1, 3x3 stride 2: output-parity classes (pixels per class, tiles per class)
     MnasActIn act;
     MnasGradIn grad;
     const uint16_t* w;
@@ -72,6 +73,19 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     };
     constexpr int NW = (NT * 16 * kc8n + 255) / 256;
     uint4 wv[NW];
+    // Stride-2 3x3 input gradient: an output pixel (oh, ow) only receives taps th = oh+1 (mod 2), tw = ow+1 (mod 2), i.e.
+    // 1, 2, 2 or 4 of the 9 taps depending on its parity class.  Tiles are formed inside one class (cls = 2*ph + pw) and
+    // walk only that class's taps: K shrinks from 9*Ci to {1,2,2,4}*Ci (2.25*Ci on average), no MFMA work on zeros.
+    const bool par2 = (MODE == 1) && a.s2;
+    int c_ph = 0, c_pw = 0, c_ntw = 1, c_K = a.Ktot;      // class of the tile being STAGED (set by decode_tile)
+    auto decode_tile = [&](int t) -> int {                // returns the tile's first local pixel index
+        if (!par2) return t * BP;
+        const int cls = t / a.tpc;
+        c_ph = cls >> 1; c_pw = cls & 1;
+        c_ntw = c_pw ? 2 : 1;
+        c_K = (c_ph ? 2 : 1) * c_ntw * a.Ci;
+        return (t - cls * a.tpc) * BP;
+    };
     auto load_w = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -79,7 +93,17 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
             const int r = q >> KSH, kc8 = q & (kc8n - 1);
             const int k = k0 + kc8 * 8;
             wv[i] = make_uint4(0, 0, 0, 0);
-            if (r < NT * 16 && n0 + r < a.co_pad16 && k < a.Kpad) wv[i] = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + k);
+            if (!(r < NT * 16 && n0 + r < a.co_pad16)) continue;
+            if (par2) {
+                if (k < c_K) {
+                    const int tj = k / a.Ci, ci = k - tj * a.Ci;
+                    const int thj = tj / c_ntw, twj = tj - thj * c_ntw;
+                    const int th = c_ph ? 2 * thj : 1, tw = c_pw ? 2 * twj : 1;
+                    wv[i] = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + (th * 3 + tw) * a.Ci + ci);
+                }
+            } else if (k < a.Kpad) {
+                wv[i] = *(const uint4*)(a.w + (size_t)(n0 + r) * a.Kpad + k);
+            }
         }
     };
     auto store_w = [&]() {
@@ -97,12 +121,18 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     constexpr int NA = BP * kc8n / 256;
     uint4 v0[NA], v1[MODE == 1 ? NA : 1];
     unsigned okm = 0;
-    auto load_a = [&](int tile0, int k0) {
+    auto load_a = [&](int t, int k0) {
+        const int tile0 = decode_tile(t);
         const int kc8 = tid & (kc8n - 1);
         const int k = k0 + kc8 * 8;
-        const bool kok = k < a.Ktot;
+        const bool kok = k < (par2 ? c_K : a.Ktot);
         int ci = k, th = 0, tw = 0;
-        if (!a.is_pw && MODE != 2) {
+        if (par2) {
+            const int tj = k / a.Ci;
+            ci = k - tj * a.Ci;
+            const int thj = tj / c_ntw, twj = tj - thj * c_ntw;
+            th = c_ph ? 2 * thj : 1; tw = c_pw ? 2 * twj : 1;
+        } else if (!a.is_pw && MODE != 2) {
             const int tap = k / a.Ci;
             ci = k - tap * a.Ci;
             th = tap / a.kw; tw = tap - th * a.kw;
@@ -132,6 +162,21 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                         f[j] = okj ? x[(((size_t)n * 3 + c3) * a.Hi + ih) * a.Wi + iw] : 0.f;
                     }
                     v0[i] = pack8(f);
+                }
+                continue;
+            }
+            if (par2) {
+                if (m < a.Mc && kok) {
+                    const int w2 = a.Wo >> 1, hw2 = (a.Ho >> 1) * w2;
+                    const int n = m / hw2, rem = m - n * hw2;
+                    const int oh2 = rem / w2, ow2 = rem - oh2 * w2;
+                    const int ih = (2 * oh2 + c_ph + 1 - th) >> 1, iw = (2 * ow2 + c_pw + 1 - tw) >> 1;   // exact: parity matches
+                    if (ih < a.Hi && iw < a.Wi) {
+                        const size_t src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + ci;
+                        okm |= 1u << i;
+                        v0[i] = *(const uint4*)((const uint16_t*)a.grad.g + src);
+                        v1[i] = *(const uint4*)((const uint16_t*)a.grad.y + src);
+                    }
                 }
                 continue;
             }
@@ -174,7 +219,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         if (MODE != 2 && has_coef) {
             const int k = k0 + kc8 * 8;
             int cc = k;
-            if (a.taps != 1) cc = k - (k / a.Ci) * a.Ci;
+            if (a.taps != 1) cc = k - (k / a.Ci) * a.Ci;       // (class-space k for stride-2 dgrad: same formula)
             float cf[CROWS][8];
 #pragma unroll
             for (int r = 0; r < CROWS; ++r) {
@@ -231,18 +276,36 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     }
 
     load_coefs();
-    if (nkc == 1) {       // weights are tile-invariant: stage once
+    const bool wloop = nkc > 1 || par2;      // weights re-staged inside the K loop (several chunks, or per-class taps)
+    if (!wloop) {         // weights are tile-invariant: stage once
         load_w(0);
         store_w();
     }
 
-    const int ntiles = (a.M + BP - 1) / BP;
+    const int ntiles = par2 ? 4 * a.tpc : (a.M + BP - 1) / BP;
+    // local pixel index (inside the tile's parity class for stride-2 dgrad) -> output pixel, or -1
+    int e_ph = 0, e_pw = 0;
+    auto out_pixel = [&](int ml) -> int {
+        if (!par2) return ml < a.M ? ml : -1;
+        if (ml >= a.Mc) return -1;
+        const int w2 = a.Wo >> 1, hw2 = (a.Ho >> 1) * w2;
+        const int n = ml / hw2, rem = ml - n * hw2;
+        const int oh2 = rem / w2, ow2 = rem - oh2 * w2;
+        return (n * a.Ho + 2 * oh2 + e_ph) * a.Wo + 2 * ow2 + e_pw;
+    };
     if (PIPE && (int)blockIdx.x < ntiles) {
-        load_a(blockIdx.x * BP, 0);
-        if (nkc > 1) load_w(0);
+        load_a(blockIdx.x, 0);
+        if (wloop) load_w(0);
     }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tile0 = t * BP;
+        int tile0 = t * BP, t_nkc = nkc, t_kpad = a.Kpad;
+        if (par2) {
+            const int cls = t / a.tpc;
+            e_ph = cls >> 1; e_pw = cls & 1;
+            tile0 = (t - cls * a.tpc) * BP;
+            t_kpad = ((e_ph ? 2 : 1) * (e_pw ? 2 : 1) * a.Ci + 31) & ~31;
+            t_nkc = (t_kpad + kch - 1) / kch;
+        }
         f32x4_t acc[PT][NT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
@@ -254,35 +317,35 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         if (do_red) {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                const int m = tile0 + (wave * PT + pt) * 16 + l15;
+                const int m = out_pixel(tile0 + (wave * PT + pt) * 16 + l15);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int co = n0 + nt * 16 + lg * 4;
                     ypre[pt][nt] = make_uint2(0, 0);
-                    if (m < a.M && co < a.Co) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + (size_t)m * a.Co + co);
+                    if (m >= 0 && co < a.Co) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + (size_t)m * a.Co + co);
                 }
             }
         }
-        for (int kc = 0; kc < nkc; ++kc) {
+        for (int kc = 0; kc < t_nkc; ++kc) {
             const int k0 = kc * kch;
             __syncthreads();                       // previous chunk's fragments consumed (first pass: coefficients visible)
             if (!PIPE) {
-                load_a(tile0, k0);
-                if (nkc > 1) load_w(k0);
+                load_a(t, k0);
+                if (wloop) load_w(k0);
             }
             store_a(k0);
-            if (nkc > 1) store_w();
+            if (wloop) store_w();
             __syncthreads();
             // next (tile, chunk) of this workgroup: its loads fly under the MFMAs (and the epilogue / next ypre fetch)
             if (PIPE) {
                 int nt_ = t, nk_ = kc + 1;
-                if (nk_ == nkc) { nk_ = 0; nt_ = t + gridDim.x; }
+                if (nk_ == t_nkc) { nk_ = 0; nt_ = t + gridDim.x; }
                 if (nt_ < ntiles) {
-                    load_a(nt_ * BP, nk_ * kch);
-                    if (nkc > 1) load_w(nk_ * kch);
+                    load_a(nt_, nk_ * kch);
+                    if (wloop) load_w(nk_ * kch);
                 }
             }
-            const int ksteps = min(kch, a.Kpad - k0) >> 5;
+            const int ksteps = min(kch, t_kpad - k0) >> 5;
             for (int ks = 0; ks < ksteps; ++ks) {
                 bf16x8_t bfrag[PT];
 #pragma unroll
@@ -300,8 +363,8 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         // ---- epilogue: lane holds couts n0+nt*16+lg*4+{0..3} of pixel tile0+(wave*PT+pt)*16+l15
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int m = tile0 + (wave * PT + pt) * 16 + l15;
-            if (m >= a.M) continue;
+            const int m = out_pixel(tile0 + (wave * PT + pt) * 16 + l15);
+            if (m < 0) continue;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = n0 + nt * 16 + lg * 4;
@@ -384,11 +447,13 @@ static int launch_igemm_k(const IgemmArgs& a, int nparts, int nblocks, bool pipe
     return MNAS_OK;
 }
 template <int MODE, int NT, int PT>
-static int launch_igemm(const IgemmArgs& a, int nparts, int nblocks, hipStream_t stream) {
+static int launch_igemm(const IgemmArgs& a_in, int nparts, int nblocks, hipStream_t stream) {
+    IgemmArgs a = a_in;
+    if (a.s2) a.tpc = (a.Mc + 64 * PT - 1) / (64 * PT);
     // Software pipelining (global loads of the next (tile, chunk) in flight under the MFMA phase) costs 30-50 VGPRs.
     // It pays when a workgroup walks several load phases (long K, persistent tile loops) and the extra registers do
     // not halve the occupancy; measured per layer shape on MI355X (igemm table).
-    const int ntiles = (a.M + 64 * PT - 1) / (64 * PT);
+    const int ntiles = a.s2 ? 4 * a.tpc : (a.M + 64 * PT - 1) / (64 * PT);
     const int nkc = (a.Kpad + a.kch - 1) / a.kch;
     const int phases = nkc * ((ntiles + nparts - 1) / nparts);
     const bool s2 = a.taps > 1 && a.stride == 2;
@@ -420,6 +485,10 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     a.act = c->act; a.grad = c->grad;
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = c->resid; a.out = c->out; a.stats = c->stats;
     a.red_y = (c->mode == 1) ? c->red_y : nullptr; a.red_bn = c->red_bn;
+    // stride-2 3x3 input gradient over even output sizes: parity-class tiling (see k_igemm)
+    a.s2 = (c->mode == 1 && c->kh == 3 && c->kw == 3 && c->stride == 2 && c->pad == 1 && !(c->Ho & 1) && !(c->Wo & 1)) ? 1 : 0;
+    a.Mc = c->N * (c->Ho / 2) * (c->Wo / 2);
+    a.tpc = 0;
     if (a.red_y && (!a.red_bn || !a.stats)) return MNAS_EINVAL;
     if (a.taps != 1 && c->Ci > 1024) return MNAS_EINVAL;
     if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;   // strided / padded 1x1 does not occur in this network
@@ -472,6 +541,7 @@ extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     a.grad.g = nullptr; a.grad.y = nullptr; a.grad.coef = nullptr;
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = nullptr; a.out = c->out; a.stats = c->stats;
     a.red_y = nullptr; a.red_bn = nullptr;
+    a.s2 = 0; a.Mc = 0; a.tpc = 0;
     const int tiles = (c->Co + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     if (tiles == 1) return launch_igemm_k<2, 1, 2, 32>(a, c->nparts, 1, true, s);
