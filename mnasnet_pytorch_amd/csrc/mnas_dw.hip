@@ -144,55 +144,61 @@ __device__ __forceinline__ void dw_dma_rows(const DwArgs& a, const DwDma& p, uin
     }
 }
 
-// window row of activations: relu(s*x+t) (or x), zero outside the image columns
+// A thread works on ONE channel pair: every per-element quantity is a float2 (lo, hi channel) so that the multiply-adds
+// are v_pk_fma_f32 -- two FMAs per issue slot, 2x the plain-f32 VALU rate (these kernels carry no MFMAs and their inner
+// loops are VALU-issue bound: 25 FMAs per 5x5 output element against ~4.5 B of HBM traffic).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 f2bf(uint32_t u) { f2 r; r.x = bf_lo(u); r.y = bf_hi(u); return r; }   // bf16 pair -> f32 pair
+
+// window row of activations: relu(s*x+t) (or x), zero outside the image columns (mz[xx] = 1.0 inside, 0.0 outside)
 template <int WIN_W>
-__device__ __forceinline__ void dw_read_act(const uint32_t* rowp, int ps, bool has_coef, const float* s, const float* t,
-                                            unsigned colmask, float (&xr)[WIN_W][2]) {
+__device__ __forceinline__ void dw_read_act(const uint32_t* rowp, int ps, bool has_coef, f2 s, f2 t, unsigned colmask,
+                                            f2 (&xr)[WIN_W]) {
 #pragma unroll
     for (int xx = 0; xx < WIN_W; ++xx) {
-        const uint32_t u = rowp[xx * ps];
-        float v0 = bf_lo(u), v1 = bf_hi(u);
+        f2 v = f2bf(rowp[xx * ps]);
         if (has_coef) {
-            v0 = fmaxf(fmaf(v0, s[0], t[0]), 0.f);
-            v1 = fmaxf(fmaf(v1, s[1], t[1]), 0.f);
+            v = f2fma(v, s, t);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
         }
         const bool in = (colmask >> xx) & 1u;
-        xr[xx][0] = in ? v0 : 0.f;
-        xr[xx][1] = in ? v1 : 0.f;
+        xr[xx].x = in ? v.x : 0.f;
+        xr[xx].y = in ? v.y : 0.f;
     }
 }
 
-// window row of dy = c1*(g*[s*y+t>0]) + c2*y + c3, zero outside the image columns.  cf = {s,t,c1,c2,c3} x 2 channels
+// window row of dy = c1*(g*[s*y+t>0]) + c2*y + c3, zero outside the image columns.  cf = {s,t,c1,c2,c3}
 template <int WIN_W>
-__device__ __forceinline__ void dw_read_dy(const uint32_t* growp, const uint32_t* yrowp, int ps, const float (&cf)[5][2],
-                                           unsigned colmask, float (&xr)[WIN_W][2]) {
+__device__ __forceinline__ void dw_read_dy(const uint32_t* growp, const uint32_t* yrowp, int ps, const f2 (&cf)[5],
+                                           unsigned colmask, f2 (&xr)[WIN_W]) {
 #pragma unroll
     for (int xx = 0; xx < WIN_W; ++xx) {
-        const uint32_t ug = growp[xx * ps], uy = yrowp[xx * ps];
-        const float g0 = bf_lo(ug), g1 = bf_hi(ug), y0 = bf_lo(uy), y1 = bf_hi(uy);
-        const float dz0 = (fmaf(y0, cf[0][0], cf[1][0]) > 0.f) ? g0 : 0.f;
-        const float dz1 = (fmaf(y1, cf[0][1], cf[1][1]) > 0.f) ? g1 : 0.f;
-        const float d0 = fmaf(cf[2][0], dz0, fmaf(cf[3][0], y0, cf[4][0]));
-        const float d1 = fmaf(cf[2][1], dz1, fmaf(cf[3][1], y1, cf[4][1]));
+        const f2 g = f2bf(growp[xx * ps]), y = f2bf(yrowp[xx * ps]);
+        const f2 z = f2fma(y, cf[0], cf[1]);
+        f2 dz;
+        dz.x = (z.x > 0.f) ? g.x : 0.f;
+        dz.y = (z.y > 0.f) ? g.y : 0.f;
+        const f2 d = f2fma(cf[2], dz, f2fma(cf[3], y, cf[4]));
         const bool in = (colmask >> xx) & 1u;
-        xr[xx][0] = in ? d0 : 0.f;
-        xr[xx][1] = in ? d1 : 0.f;
+        xr[xx].x = in ? d.x : 0.f;
+        xr[xx].y = in ? d.y : 0.f;
     }
 }
 
-// Deterministic workgroup reduction of per-thread accumulators v[NV][2] (thread = channel pair cp x column strip sxi)
+// Deterministic workgroup reduction of per-thread accumulators v[NV] (channel pairs) (thread = channel pair cp x column strip sxi)
 // over the column strips: every thread parks its values in LDS (the row rings are dead once the sweep is over; they
 // are always large enough: sx*NV*cblk*4 B <= nrings*RR*iw*cpw*4 B), then NV*cblk threads add the sx copies in strip
 // order.  No float atomics, so the partial tables are bit-reproducible run to run.
 template <int NV, typename F>
-__device__ __forceinline__ void dw_block_reduce(float* scratch, const float (&v)[NV][2], int cp, int sxi, int sx, int cblk,
+__device__ __forceinline__ void dw_block_reduce(float* scratch, const f2 (&v)[NV], int cp, int sxi, int sx, int cblk,
                                                 bool active, F&& emit) {
     __syncthreads();                                   // all ring reads done
     if (active) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            scratch[(sxi * NV + k) * cblk + 2 * cp] = v[k][0];
-            scratch[(sxi * NV + k) * cblk + 2 * cp + 1] = v[k][1];
+            scratch[(sxi * NV + k) * cblk + 2 * cp] = v[k].x;
+            scratch[(sxi * NV + k) * cblk + 2 * cp + 1] = v[k].y;
         }
     }
     __syncthreads();
@@ -217,9 +223,10 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
     const bool active = sxi < a.sx;
     const bool has_coef = in.scale != nullptr;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const f2 zero2 = {0.f, 0.f};
+    f2 s1 = zero2, s2 = zero2;
     int cur_c0 = -1;
-    float wt[KS * KS][2], b0 = 0.f, b1 = 0.f, cs[2] = {1.f, 1.f}, ct[2] = {0.f, 0.f};
+    f2 wt[KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
     const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
     const int ps = a.cpw;
 
@@ -232,12 +239,12 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
             cur_c0 = c0;
 #pragma unroll
             for (int t = 0; t < KS * KS; ++t) {
-                wt[t][0] = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
-                wt[t][1] = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
+                wt[t].x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
+                wt[t].y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
             }
-            b0 = (bias && ch_ok) ? bias[ch] : 0.f;
-            b1 = (bias && ch_ok) ? bias[ch + 1] : 0.f;
-            if (has_coef && ch_ok) { cs[0] = in.scale[ch]; cs[1] = in.scale[ch + 1]; ct[0] = in.shift[ch]; ct[1] = in.shift[ch + 1]; }
+            b2.x = (bias && ch_ok) ? bias[ch] : 0.f;
+            b2.y = (bias && ch_ok) ? bias[ch + 1] : 0.f;
+            if (has_coef && ch_ok) { cs.x = in.scale[ch]; cs.y = in.scale[ch + 1]; ct.x = in.shift[ch]; ct.y = in.shift[ch + 1]; }
         }
         DwDma plan;
         dw_dma_plan<KS>(a, plan, wave, nwaves, lane, x0, c0);
@@ -246,11 +253,11 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
 #pragma unroll
         for (int xx = 0; xx < WIN_W; ++xx) { const int gx = gx0 - PAD + xx; colmask |= (gx >= 0 && gx < a.W) ? (1u << xx) : 0u; }
         // register ring of KS partial output rows: A[i] = output row (iy - PAD + i) while input row iy is processed
-        float A[KS][DW_BW][2];
+        f2 A[KS][DW_BW];
 #pragma unroll
         for (int i = 0; i < KS; ++i)
 #pragma unroll
-            for (int j = 0; j < DW_BW; ++j) { A[i][j][0] = b0; A[i][j][1] = b1; }
+            for (int j = 0; j < DW_BW; ++j) A[i][j] = b2;
         uint32_t* outp = out + (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
         const uint32_t* colp = ring + (size_t)sxi * DW_BW * ps + cp;
 
@@ -265,35 +272,33 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
                 const int iy = r0 + j;
                 const int oy = iy - PAD;             // A[0] is complete after this row
                 if (iy >= 0 && iy < a.H) {           // uniform: rows outside the image contribute nothing
-                    float xr[WIN_W][2];
+                    f2 xr[WIN_W];
                     dw_read_act<WIN_W>(colp + (size_t)dw_slot(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
 #pragma unroll
                     for (int i = 0; i < KS; ++i)
 #pragma unroll
                         for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
-                            for (int kx = 0; kx < KS; ++kx) {
-                                A[i][ox][0] = fmaf(wt[(KS - 1 - i) * KS + kx][0], xr[ox + kx][0], A[i][ox][0]);
-                                A[i][ox][1] = fmaf(wt[(KS - 1 - i) * KS + kx][1], xr[ox + kx][1], A[i][ox][1]);
-                            }
+                            for (int kx = 0; kx < KS; ++kx)
+                                A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
                 }
                 if (oy >= 0 && oy < a.H && ch_ok) {
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) {
                         if (gx0 + ox < a.W) {
-                            const float v0 = A[0][ox][0], v1 = A[0][ox][1];
-                            s1[0] += v0; s2[0] = fmaf(v0, v0, s2[0]);
-                            s1[1] += v1; s2[1] = fmaf(v1, v1, s2[1]);
-                            outp[((size_t)oy * a.W + ox) * a.C / 2] = pack_bf16(v0, v1);
+                            const f2 v = A[0][ox];
+                            s1 += v;
+                            s2 = f2fma(v, v, s2);
+                            outp[((size_t)oy * a.W + ox) * a.C / 2] = pack_bf16(v.x, v.y);
                         }
                     }
                 }
 #pragma unroll
                 for (int i = 0; i + 1 < KS; ++i)
 #pragma unroll
-                    for (int ox = 0; ox < DW_BW; ++ox) { A[i][ox][0] = A[i + 1][ox][0]; A[i][ox][1] = A[i + 1][ox][1]; }
+                    for (int ox = 0; ox < DW_BW; ++ox) A[i][ox] = A[i + 1][ox];
 #pragma unroll
-                for (int ox = 0; ox < DW_BW; ++ox) { A[KS - 1][ox][0] = b0; A[KS - 1][ox][1] = b1; }
+                for (int ox = 0; ox < DW_BW; ++ox) A[KS - 1][ox] = b2;
             }
         }
     }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         // channel block (b % cblocks), so every (channel, column) is written exactly once -- no zero fill, no atomics
         const int rows = a.geff / a.cblocks, col = blockIdx.x / a.cblocks;
         const int cb0 = (blockIdx.x % a.cblocks) * cblk;
-        const float sv[2][2] = {{s1[0], s1[1]}, {s2[0], s2[1]}};
+        const f2 sv[2] = {s1, s2};
         const bool any = cur_c0 >= 0;
         dw_block_reduce<2>((float*)ring, sv, cp, sxi, a.sx, cblk, active, [&](int r, int cl, float v) {
             const int c = cb0 + cl;
@@ -335,13 +340,14 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
     const bool active = sxi < a.sx;
     const bool has_coef = x.scale != nullptr;
     const uint32_t* xglob = (const uint32_t*)x.data;
+    const f2 zero2 = {0.f, 0.f};
     int cur_c0 = -1;
-    float wt[DG ? KS * KS : 1][2], wacc[WG ? KS * KS : 1][2];
-    float cf[5][2], cs[2] = {1.f, 1.f}, ct[2] = {0.f, 0.f};
-    float ris[2] = {0.f, 0.f}, rmu[2] = {0.f, 0.f};
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    f2 wt[DG ? KS * KS : 1], wacc[WG ? KS * KS : 1];
+    f2 cf[5], cs = {1.f, 1.f}, ct = zero2;
+    f2 ris = zero2, rmu = zero2;
+    f2 s1 = zero2, s2 = zero2;
 #pragma unroll
-    for (int t = 0; t < (WG ? KS * KS : 1); ++t) { wacc[t][0] = 0.f; wacc[t][1] = 0.f; }
+    for (int t = 0; t < (WG ? KS * KS : 1); ++t) wacc[t] = zero2;
     const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
     const int ps = a.cpw;
 
@@ -355,19 +361,19 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
             if (DG) {
 #pragma unroll
                 for (int t = 0; t < KS * KS; ++t) {      // flipped filter for the input gradient
-                    wt[t][0] = ch_ok ? w[(size_t)(KS * KS - 1 - t) * a.C + ch] : 0.f;
-                    wt[t][1] = ch_ok ? w[(size_t)(KS * KS - 1 - t) * a.C + ch + 1] : 0.f;
+                    wt[t].x = ch_ok ? w[(size_t)(KS * KS - 1 - t) * a.C + ch] : 0.f;
+                    wt[t].y = ch_ok ? w[(size_t)(KS * KS - 1 - t) * a.C + ch + 1] : 0.f;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                cf[r][0] = ch_ok ? d.coef[(size_t)r * a.C + ch] : 0.f;
-                cf[r][1] = ch_ok ? d.coef[(size_t)r * a.C + ch + 1] : 0.f;
+                cf[r].x = ch_ok ? d.coef[(size_t)r * a.C + ch] : 0.f;
+                cf[r].y = ch_ok ? d.coef[(size_t)r * a.C + ch + 1] : 0.f;
             }
-            if (has_coef && ch_ok) { cs[0] = x.scale[ch]; cs[1] = x.scale[ch + 1]; ct[0] = x.shift[ch]; ct[1] = x.shift[ch + 1]; }
+            if (has_coef && ch_ok) { cs.x = x.scale[ch]; cs.y = x.scale[ch + 1]; ct.x = x.shift[ch]; ct.y = x.shift[ch + 1]; }
             if (RED && ch_ok) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) { ris[e] = red_bn[6 * a.C + ch + e]; rmu[e] = -red_bn[5 * a.C + ch + e] * ris[e]; }
+                ris.x = red_bn[6 * a.C + ch]; ris.y = red_bn[6 * a.C + ch + 1];
+                rmu.x = -red_bn[5 * a.C + ch] * ris.x; rmu.y = -red_bn[5 * a.C + ch + 1] * ris.y;
             }
         }
         DwDma plan;
@@ -376,15 +382,15 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
         unsigned colmask = 0;
 #pragma unroll
         for (int xx = 0; xx < WIN_W; ++xx) { const int gx = gx0 - PAD + xx; colmask |= (gx >= 0 && gx < a.W) ? (1u << xx) : 0u; }
-        float A[DG ? KS : 1][DW_BW][2], D[WG ? KS : 1][DW_BW][2];
+        f2 A[DG ? KS : 1][DW_BW], D[WG ? KS : 1][DW_BW];
 #pragma unroll
         for (int i = 0; i < (DG ? KS : 1); ++i)
 #pragma unroll
-            for (int j = 0; j < DW_BW; ++j) { A[i][j][0] = 0.f; A[i][j][1] = 0.f; }
+            for (int j = 0; j < DW_BW; ++j) A[i][j] = zero2;
 #pragma unroll
         for (int i = 0; i < (WG ? KS : 1); ++i)
 #pragma unroll
-            for (int j = 0; j < DW_BW; ++j) { D[i][j][0] = 0.f; D[i][j][1] = 0.f; }
+            for (int j = 0; j < DW_BW; ++j) D[i][j] = zero2;
         const size_t obase = (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
         const size_t coloff = (size_t)sxi * DW_BW * ps + cp;
 
@@ -409,13 +415,13 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
                     for (int ox = 0; ox < DW_BW; ++ox) xraw[ox] = (gx0 + ox < a.W) ? yp[(size_t)ox * a.C / 2] : 0u;
                 }
                 // ---- dy row iy
-                float xr[WIN_W][2];
+                f2 xr[WIN_W];
                 if (row_in) {
                     const size_t ro = (size_t)dw_slot(iy) * a.rc * 4 + coloff;
                     dw_read_dy<WIN_W>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
                 } else {
 #pragma unroll
-                    for (int xx = 0; xx < WIN_W; ++xx) { xr[xx][0] = 0.f; xr[xx][1] = 0.f; }
+                    for (int xx = 0; xx < WIN_W; ++xx) xr[xx] = zero2;
                 }
                 if (DG && row_in) {
 #pragma unroll
@@ -423,21 +429,19 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
 #pragma unroll
                         for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
-                            for (int kx = 0; kx < KS; ++kx) {
-                                A[i][ox][0] = fmaf(wt[(KS - 1 - i) * KS + kx][0], xr[ox + kx][0], A[i][ox][0]);
-                                A[i][ox][1] = fmaf(wt[(KS - 1 - i) * KS + kx][1], xr[ox + kx][1], A[i][ox][1]);
-                            }
+                            for (int kx = 0; kx < KS; ++kx)
+                                A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
                 }
                 if (WG) {
 #pragma unroll
                     for (int q = KS - 1; q > 0; --q)
 #pragma unroll
-                        for (int ox = 0; ox < DW_BW; ++ox) { D[q][ox][0] = D[q - 1][ox][0]; D[q][ox][1] = D[q - 1][ox][1]; }
+                        for (int ox = 0; ox < DW_BW; ++ox) D[q][ox] = D[q - 1][ox];
 #pragma unroll
-                    for (int ox = 0; ox < DW_BW; ++ox) { D[0][ox][0] = xr[ox + PAD][0]; D[0][ox][1] = xr[ox + PAD][1]; }
+                    for (int ox = 0; ox < DW_BW; ++ox) D[0][ox] = xr[ox + PAD];
                 }
                 // ---- x row oy = iy - PAD: activation window (WG) and raw centre (RED)
-                float xa[WIN_W][2];
+                f2 xa[WIN_W];
                 if (NEEDX && orow_in) {
                     const uint32_t* rowp = ring_x + (size_t)dw_slot(oy) * a.rc * 4 + coloff;
                     if (WG) dw_read_act<WIN_W>(rowp, ps, has_coef, cs, ct, colmask, xa);
@@ -451,15 +455,16 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) {
                         if (gx0 + ox < a.W) {
-                            const uint32_t pk = pack_bf16(A[0][ox][0], A[0][ox][1]);
+                            const uint32_t pk = pack_bf16(A[0][ox].x, A[0][ox].y);
                             gin[obase + ((size_t)oy * a.W + ox) * a.C / 2] = pk;
                             if (RED) {
-                                const uint32_t yv = xraw[ox];
-                                const float g0 = bf_lo(pk), g1 = bf_hi(pk), y0 = bf_lo(yv), y1 = bf_hi(yv);
-                                const float dz0 = (fmaf(y0, cs[0], ct[0]) > 0.f) ? g0 : 0.f;
-                                const float dz1 = (fmaf(y1, cs[1], ct[1]) > 0.f) ? g1 : 0.f;
-                                s1[0] += dz0; s2[0] = fmaf(dz0, fmaf(y0, ris[0], rmu[0]), s2[0]);
-                                s1[1] += dz1; s2[1] = fmaf(dz1, fmaf(y1, ris[1], rmu[1]), s2[1]);
+                                const f2 gq = f2bf(pk), yq = f2bf(xraw[ox]);
+                                const f2 z = f2fma(yq, cs, ct);
+                                f2 dz;
+                                dz.x = (z.x > 0.f) ? gq.x : 0.f;
+                                dz.y = (z.y > 0.f) ? gq.y : 0.f;
+                                s1 += dz;
+                                s2 = f2fma(dz, f2fma(yq, ris, rmu), s2);
                             }
                         }
                     }
@@ -468,9 +473,9 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
 #pragma unroll
                     for (int i = 0; i + 1 < KS; ++i)
 #pragma unroll
-                        for (int ox = 0; ox < DW_BW; ++ox) { A[i][ox][0] = A[i + 1][ox][0]; A[i][ox][1] = A[i + 1][ox][1]; }
+                        for (int ox = 0; ox < DW_BW; ++ox) A[i][ox] = A[i + 1][ox];
 #pragma unroll
-                    for (int ox = 0; ox < DW_BW; ++ox) { A[KS - 1][ox][0] = 0.f; A[KS - 1][ox][1] = 0.f; }
+                    for (int ox = 0; ox < DW_BW; ++ox) A[KS - 1][ox] = zero2;
                 }
                 // ---- weight gradient: activation row oy against the dy ring (dy rows oy-ky+PAD = iy-ky = D[ky])
                 if (WG && orow_in) {
@@ -479,10 +484,8 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
 #pragma unroll
                         for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
-                            for (int kx = 0; kx < KS; ++kx) {
-                                wacc[ky * KS + kx][0] = fmaf(D[ky][ox][0], xa[ox + kx][0], wacc[ky * KS + kx][0]);
-                                wacc[ky * KS + kx][1] = fmaf(D[ky][ox][1], xa[ox + kx][1], wacc[ky * KS + kx][1]);
-                            }
+                            for (int kx = 0; kx < KS; ++kx)
+                                wacc[ky * KS + kx] = f2fma(D[ky][ox], xa[ox + kx], wacc[ky * KS + kx]);
                 }
             }
         }
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
     const int cb0 = (blockIdx.x % a.cblocks) * cblk;
     const bool any = cur_c0 >= 0;
     if constexpr (RED) {      // fused-reduce table float[2][C][rows]
-        const float sv[2][2] = {{s1[0], s1[1]}, {s2[0], s2[1]}};
+        const f2 sv[2] = {s1, s2};
         dw_block_reduce<2>((float*)ring_g, sv, cp, sxi, a.sx, cblk, active, [&](int r, int cl, float v) {
             const int c = cb0 + cl;
             if (c < a.C) red_partial[((size_t)r * a.C + c) * rows + row] = any ? v : 0.f;
