@@ -35,7 +35,7 @@ struct IgemmArgs {
     const float* red_bn;
 };
 
-template <int MODE, int NT, int PT, int KCH, bool PIPE>
+template <int MODE, int NT, int PT, int KCH, bool PIPE, bool PAR2>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     // Stride-2 3x3 input gradient: an output pixel (oh, ow) only receives taps th = oh+1 (mod 2), tw = ow+1 (mod 2), i.e.
     // 1, 2, 2 or 4 of the 9 taps depending on its parity class.  Tiles are formed inside one class (cls = 2*ph + pw) and
     // walk only that class's taps: K shrinks from 9*Ci to {1,2,2,4}*Ci (2.25*Ci on average), no MFMA work on zeros.
-    const bool par2 = (MODE == 1) && a.s2;
+    constexpr bool par2 = PAR2;            // host sets it for MODE 1 && a.s2 only
     int c_ph = 0, c_pw = 0, c_ntw = 1, c_K = a.Ktot;      // class of the tile being STAGED (set by decode_tile)
     auto decode_tile = [&](int t) -> int {                // returns the tile's first local pixel index
-        if (!par2) return t * BP;
+        if constexpr (!par2) return t * BP;
         const int cls = t / a.tpc;
         c_ph = cls >> 1; c_pw = cls & 1;
         c_ntw = c_pw ? 2 : 1;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     // local pixel index (inside the tile's parity class for stride-2 dgrad) -> output pixel, or -1
     int e_ph = 0, e_pw = 0;
     auto out_pixel = [&](int ml) -> int {
-        if (!par2) return ml < a.M ? ml : -1;
+        if constexpr (!par2) return ml < a.M ? ml : -1;
         if (ml >= a.Mc) return -1;
         const int w2 = a.Wo >> 1, hw2 = (a.Ho >> 1) * w2;
         const int n = ml / hw2, rem = ml - n * hw2;
@@ -298,14 +298,16 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         if (wloop) load_w(0);
     }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        int tile0 = t * BP, t_nkc = nkc, t_kpad = a.Kpad;
-        if (par2) {
+        int tile0_ = t * BP, t_nkc_ = nkc, t_kpad_ = a.Kpad;
+        if constexpr (par2) {
             const int cls = t / a.tpc;
             e_ph = cls >> 1; e_pw = cls & 1;
-            tile0 = (t - cls * a.tpc) * BP;
-            t_kpad = ((e_ph ? 2 : 1) * (e_pw ? 2 : 1) * a.Ci + 31) & ~31;
-            t_nkc = (t_kpad + kch - 1) / kch;
+            tile0_ = (t - cls * a.tpc) * BP;
+            t_kpad_ = ((e_ph ? 2 : 1) * (e_pw ? 2 : 1) * a.Ci + 31) & ~31;
+            t_nkc_ = (t_kpad_ + kch - 1) / kch;
         }
+        const int tile0 = tile0_;
+        const int t_nkc = par2 ? t_nkc_ : nkc, t_kpad = par2 ? t_kpad_ : a.Kpad;
         f32x4_t acc[PT][NT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
@@ -317,7 +319,9 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         if (do_red) {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                const int m = out_pixel(tile0 + (wave * PT + pt) * 16 + l15);
+                int m = tile0 + (wave * PT + pt) * 16 + l15;
+                if constexpr (par2) m = out_pixel(m);
+                else if (m >= a.M) m = -1;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int co = n0 + nt * 16 + lg * 4;
@@ -363,8 +367,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         // ---- epilogue: lane holds couts n0+nt*16+lg*4+{0..3} of pixel tile0+(wave*PT+pt)*16+l15
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int m = out_pixel(tile0 + (wave * PT + pt) * 16 + l15);
-            if (m < 0) continue;
+            int m = tile0 + (wave * PT + pt) * 16 + l15;
+            if constexpr (par2) {
+                m = out_pixel(m);
+                if (m < 0) continue;
+            } else {
+                if (m >= a.M) continue;
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = n0 + nt * 16 + lg * 4;
@@ -441,8 +450,15 @@ static int launch_igemm_k(const IgemmArgs& a, int nparts, int nblocks, bool pipe
     const size_t lds = (size_t)(CROWS * ccols + 6 * NT * 16) * sizeof(float) +
                        (size_t)(NT * 16 + 64 * PT) * (a.kch + 8) * 2;
     if (lds > 160 * 1024) return MNAS_EINVAL;
-    if (pipe) hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, true>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, false>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+    if constexpr (MODE == 1) {
+        if (a.s2) {       // parity-class tiling: never pipelined (launch_igemm), own instantiation
+            hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, false, true>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+            MNAS_CHECK_LAUNCH();
+            return MNAS_OK;
+        }
+    }
+    if (pipe) hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, true, false>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, false, false>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -496,16 +512,19 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (c->mode == 1 && (!c->grad.g || !c->grad.y || !c->grad.coef)) return MNAS_EINVAL;
 
     // cout tiling: NT*16 channels per workgroup column.  Up to 8 tiles: one block (the activation tile is staged
-    // once).  Wider outputs: several blocks of <= 6 tiles (NT = 8 with 128-pixel tiles needs > 200 VGPRs and halves
-    // occupancy -- measured slower than re-staging the small-K activation tile), fewest padded tiles first.
+    // once).  Wider outputs: several blocks of 4 or 3 tiles, fewest padded tiles first (NT = 6/8 blocks need 150-250
+    // VGPRs; measured 15-25 % slower on the 14x14 / 7x7 expand-type layers than re-staging the small-K activation tile;
+    // with K >= 512 re-staging costs more than the registers and 6-tile blocks win by 5-20 %).
     const int tiles = (c->Co + 15) / 16;
     int best_nt = 1, best_waste = 1 << 30, best_blocks = 1 << 30;
     if (tiles <= 8) {
         static const int opts1[] = {1, 2, 3, 4, 6, 8};
         for (int nt : opts1) if (nt >= tiles) { best_nt = nt; best_blocks = 1; break; }
     } else {
-        static const int opts[] = {6, 4, 3};
-        for (int nt : opts) {
+        // long reductions (K >= 512: the activation tile is the expensive operand) keep 6-tile blocks
+        static const int opts_small_k[3] = {4, 3, 0}, opts_large_k[3] = {6, 4, 3};
+        for (int nt : (a.Kpad >= 512 ? opts_large_k : opts_small_k)) {
+            if (nt == 0) continue;
             const int blocks = (tiles + nt - 1) / nt;
             const int waste = blocks * nt - tiles;
             if (waste < best_waste || (waste == best_waste && blocks < best_blocks)) {

@@ -52,6 +52,57 @@ def pmc_main(path, steps):
         print("%-86s %-14s %8.1f %16.1f" % (nm, cname, n / steps, (v or 0) / steps))
 
 
+def timeline_main(path, nlast):
+    """Idle analysis: rocpd_stats.py --timeline results.db [N]  -- union of kernel intervals vs span over the LAST N
+    dispatches (default 2000), per-queue gap totals, and the 25 largest gaps with the kernels on either side."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    cols = [r[1] for r in cur.execute("pragma table_info(`%s`)" % kd)]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    q = "select d.start, d.end, s.display_name, %s from `%s` d join `%s` s on d.kernel_id=s.id order by d.start" % (
+        ("d." + qcol) if qcol else "0", kd, ks)
+    rows = cur.execute(q).fetchall()[-nlast:]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    busy, cur_end = 0, t0
+    gaps = []
+    prev_name = None
+    for st, en, name, qq in rows:
+        if st > cur_end:
+            gaps.append((st - cur_end, prev_name, name))
+            busy += en - st
+            cur_end = en
+        elif en > cur_end:
+            busy += en - cur_end
+            cur_end = en
+        if en >= cur_end:
+            prev_name = name
+    print("# last %d dispatches: span %.3f ms, some kernel running %.3f ms (%.1f %%), idle %.3f ms in %d gaps" % (
+        len(rows), (t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0), (t1 - t0 - busy) / 1e6, len(gaps)))
+    byq = {}
+    for st, en, name, qq in rows:
+        byq.setdefault(qq, []).append((st, en, name))
+    for qq, lst in byq.items():
+        b = sum(e - s_ for s_, e, _ in lst)
+        print("# queue %s: %d dispatches, kernel time %.3f ms" % (qq, len(lst), b / 1e6))
+    hist = {}
+    for g, a, b in gaps:
+        k = "<2us" if g < 2000 else "<5us" if g < 5000 else "<10us" if g < 10000 else "<50us" if g < 50000 else ">=50us"
+        h = hist.setdefault(k, [0, 0]); h[0] += 1; h[1] += g
+    for k in ("<2us", "<5us", "<10us", "<50us", ">=50us"):
+        if k in hist:
+            print("# gaps %-6s n=%-5d total %.3f ms" % (k, hist[k][0], hist[k][1] / 1e6))
+    print("# largest gaps (us): after -> before")
+    for g, a, b in sorted(gaps, key=lambda x: -x[0])[:25]:
+        print("%9.1f  %s  ->  %s" % (g / 1e3, (a or "")[:60], (b or "")[:60]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--timeline":
+    timeline_main(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 2000)
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--pmc":
     pmc_main(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
     sys.exit(0)
