@@ -23,7 +23,6 @@
 //     launches for 5x5 (the fused form needs 2*k*k*2 persistent accumulators on top of the two register rings).
 // Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5 forward; backward moves 4 tensors for 2x the FMAs).
 #include "mnas_common.h"
-#include <cstdlib>
 
 #define DW_G 4          // rows per sweep step
 #define DW_BW 4         // output columns per thread
@@ -53,8 +52,10 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, DwArgs* a) {
         for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
             const int tw = sx * DW_BW, iw = tw + k - 1;
             const size_t lds = (size_t)nrings * DW_RR * iw * cpw * 4;
-            static const int cap_kb = getenv("MNAS_DW_LDS_KB") ? atoi(getenv("MNAS_DW_LDS_KB")) : 60;   // EXPERIMENT
-            if (lds > (size_t)cap_kb * 1024) continue;
+            // two workgroups per CU either way (160 KB LDS): wide strips (78 KB) measured 8-10 % faster than 60 KB for
+            // every launch form except the 5x5 weight-gradient sweep (3 rings), which is 14 % slower with them
+            const size_t cap = (k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024;
+            if (lds > cap) continue;
             const int nth = ((sx * cpw + 63) / 64) * 64;
             const int rc = iw * cgn;
             if ((rc + 63) / 64 > 2 * (nth / 64)) continue;          // <= 2 DMA blocks per wave per row
