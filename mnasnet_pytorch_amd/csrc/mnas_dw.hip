@@ -8,7 +8,8 @@
 //   * the RAW tensors (forward: the producer's raw output y; backward: g, y and the forward input) are copied
 //     HBM -> LDS with `global_load_lds` (16 B per lane, no VGPR round trip, no staging ALU work), into 8-row rings
 //     laid out exactly like the HBM row segment ([x][c], 16-byte chunks in (x, channel-group) order); every input
-//     element is fetched from HBM once per strip (halo only horizontally);
+//     element is fetched from HBM once per strip (halo only horizontally); the ring is two buffers of G rows, so the
+//     DMA of the next row group overlaps the arithmetic of the current one;
 //   * the producer's BatchNorm+ReLU ("act-on-load") and the BatchNorm/ReLU backward ("dy-on-load") are applied
 //     when a thread READS its window from LDS: a thread always works on the same channel pair, so the
 //     coefficients are 4 (resp. 10) registers; padding is handled by a per-thread column mask and a uniform row test;
@@ -19,8 +20,9 @@
 //   * BatchNorm partial statistics (forward), the fused BatchNorm-backward reduction of the producer of x and the
 //     k*k weight-gradient sums (backward) are accumulated in registers over the whole sweep and written once
 //     per workgroup (no atomics in HBM, deterministic);
-//   * backward is ONE launch for 3x3 (input gradient + weight gradient + reduce from the same three rings) and two
-//     launches for 5x5 (the fused form needs 2*k*k*2 persistent accumulators on top of the two register rings).
+//   * backward is ONE launch for 3x3 (input gradient + weight gradient + reduce from the same three rings); the engine
+//     uses two launches for 5x5 (the fused form needs 2*k*k*2 persistent accumulators on top of the two register rings
+//     and spills: measured 25.5 vs 23.0 ms/step).
 // Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5 forward; backward moves 4 tensors for 2x the FMAs).
 #include "mnas_common.h"
 
@@ -262,11 +264,16 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         uint32_t* outp = out + (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
         const uint32_t* colp = ring + (size_t)sxi * DW_BW * ps + cp;
 
+        // Every input row is read from LDS exactly once (the vertical window lives in the register ring A), so the 8 ring
+        // rows are two buffers of G = 4: the DMA of group s+1 is in flight while group s is computed.  One barrier per
+        // step: it publishes group s (hipcc drains vmcnt before s_barrier) and retires the readers of group s-1, whose
+        // buffer the next DMA overwrites.
+        __syncthreads();                             // previous item's last group consumed
+        dw_dma_rows<KS>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * DW_G;
-            __syncthreads();                         // previous group fully consumed
-            dw_dma_rows<KS>(a, plan, ring, (const uint4*)in.data, n, r0, x0, c0, wave, nwaves);
-            __syncthreads();                         // (hipcc drains the DMA queue before the barrier)
+            __syncthreads();
+            if (s + 1 < nsteps) dw_dma_rows<KS>(a, plan, ring, (const uint4*)in.data, n, r0 + DW_G, x0, c0, wave, nwaves);
             if (!active) continue;
 #pragma unroll 1
             for (int j = 0; j < DW_G; ++j) {
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
 //   xa = act(x) row r = iy-PAD   -> WG: wacc[ky][kx] += D[ky][ox] * xa[ox+kx]      (dy rows r-ky+PAD = iy-ky)
 //   RED: the raw x centre values of row iy-PAD are in the x ring too: sum dz, sum dz*xhat for the emitted gin row.
 template <int KS, bool DG, bool WG, bool RED>
-__global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_bwd(
+__global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
     float* __restrict__ red_partial, const float* __restrict__ red_bn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -395,13 +402,42 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
         const size_t obase = (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
         const size_t coloff = (size_t)sxi * DW_BW * ps + cp;
 
+        // double-buffered groups of G rows (see k_dw_fwd); the x ring runs PAD rows behind g/y: row iy of dy meets row
+        // oy = iy - PAD of x, and each row of either is read from LDS exactly once
+        auto dma_group = [&](int r0) {
+            dw_dma_rows<KS>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
+            dw_dma_rows<KS>(a, plan, ring_y, (const uint4*)d.y, n, r0, x0, c0, wave, nwaves);
+            if (NEEDX) dw_dma_rows<KS>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves);
+        };
+        // input-gradient-only launch with the fused reduce: the raw x values of the rows it emits come from global memory,
+        // fetched one group AHEAD (with the DMA, before the barrier that drains vmcnt) so that no load issued inside the
+        // compute phase has to wait behind the in-flight DMA of the next group (vmcnt retires in order)
+        uint32_t xq[REDG ? DW_G : 1][DW_BW], xn[REDG ? DW_G : 1][DW_BW];
+        auto load_xn = [&](int r0) {
+            if constexpr (REDG) {
+#pragma unroll
+                for (int j = 0; j < DW_G; ++j) {
+                    const int oy = r0 - PAD + j;
+                    const bool ok = oy >= 0 && oy < a.H && ch_ok && active;
+                    const uint32_t* yp = xglob + obase + (size_t)oy * a.W * a.C / 2;
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) xn[j][ox] = (ok && gx0 + ox < a.W) ? yp[(size_t)ox * a.C / 2] : 0u;
+                }
+            }
+        };
+        __syncthreads();                             // previous item's last group consumed
+        dma_group(-PAD);
+        load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * DW_G;
             __syncthreads();
-            dw_dma_rows<KS>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
-            dw_dma_rows<KS>(a, plan, ring_y, (const uint4*)d.y, n, r0, x0, c0, wave, nwaves);
-            if (NEEDX) dw_dma_rows<KS>(a, plan, ring_x, (const uint4*)x.data, n, r0, x0, c0, wave, nwaves);
-            __syncthreads();
+            if constexpr (REDG) {
+#pragma unroll
+                for (int j = 0; j < DW_G; ++j)
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) xq[j][ox] = xn[j][ox];
+            }
+            if (s + 1 < nsteps) { dma_group(r0 + DW_G); load_xn(r0 + DW_G); }
             if (!active) continue;
 #pragma unroll 1
             for (int j = 0; j < DW_G; ++j) {
@@ -410,10 +446,13 @@ __global__ __launch_bounds__(256, ((KS == 3 || !(DG && WG)) ? 3 : 2)) void k_dw_
                 const bool row_in = iy >= 0 && iy < a.H;
                 const bool orow_in = oy >= 0 && oy < a.H;
                 uint32_t xraw[DW_BW];
-                if (REDG && orow_in && ch_ok) {      // lands under the FMAs below
-                    const uint32_t* yp = xglob + obase + (size_t)oy * a.W * a.C / 2;
+                if constexpr (REDG) {                // row j of the group fetched one step ago; rotate the register rows
 #pragma unroll
-                    for (int ox = 0; ox < DW_BW; ++ox) xraw[ox] = (gx0 + ox < a.W) ? yp[(size_t)ox * a.C / 2] : 0u;
+                    for (int ox = 0; ox < DW_BW; ++ox) xraw[ox] = xq[0][ox];
+#pragma unroll
+                    for (int q = 0; q + 1 < DW_G; ++q)
+#pragma unroll
+                        for (int ox = 0; ox < DW_BW; ++ox) xq[q][ox] = xq[q + 1][ox];
                 }
                 // ---- dy row iy
                 f2 xr[WIN_W];
