@@ -127,9 +127,9 @@ typedef struct MnasDwFwd {
 int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
 /* Number of partial rows/columns a depthwise launch writes for this shape and nparts (host-side, no launch).
  * which = 0: forward statistics float[2][C][rows];
- * which = 1: tables of a backward launch that computes the weight gradient (phase 0 or 2): wpartial
- *            float[rows][k*k][C] and, for phase 0, the fused-reduce table float[2][C][rows];
- * which = 2: the fused-reduce table of an input-gradient-only launch (phase 1).  Returns < 0 for unsupported shapes. */
+ * which = 1: both tables of a phase-0 (fused) backward launch: wpartial float[rows][k*k][C], reduce float[2][C][rows];
+ * which = 2: the fused-reduce table of a phase-1 (input-gradient-only) launch;
+ * which = 3: wpartial of a phase-2 (weight-gradient-only) launch.  Returns < 0 for unsupported shapes. */
 int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which);
 
 typedef struct MnasDwBwd {
@@ -142,7 +142,7 @@ typedef struct MnasDwBwd {
     float* wpartial;         /* float[rows1][k*k][C], rows1 = mnas_dw_rows(...,1), fully overwritten */
     /* optional fused BatchNorm-backward reduction for the producer of x (x.data = its raw output, red_bn = its
      * bnbuf): red_partial receives float[2][C][r] (sum dz, sum dz*xhat) of (gin, x.data), r = mnas_dw_rows(...,1) for
-     * phase 0 and mnas_dw_rows(...,2) for phase 1 */
+     * phase 0 and mnas_dw_rows(...,2) for phase 1; wpartial rows: which = 1 (phase 0) / 3 (phase 2) */
     const float* red_bn;
     float* red_partial;
     int32_t phase;           /* 0: one fused sweep (input gradient + weight gradient + reduce); 1: input gradient (+reduce)

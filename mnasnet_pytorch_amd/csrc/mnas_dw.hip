@@ -26,9 +26,9 @@
 // Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5 forward; backward moves 4 tensors for 2x the FMAs).
 #include "mnas_common.h"
 
-#define DW_G 4          // rows per sweep step
+#define DW_G 4          // rows per sweep step (default; the 5x5 weight-gradient sweep uses 2, see mnas_dw_bwd)
 #define DW_BW 4         // output columns per thread
-#define DW_RR 8         // ring rows (>= G + k - 1)
+#define DW_RR 8         // ring rows = 2 * G (two buffers of G rows)
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
@@ -40,7 +40,7 @@ struct DwArgs {
     int rc, nb;                             // 16-byte chunks per ring row; DMA blocks (64 chunks) per row
 };
 
-static bool dw_pick(int N, int H, int W, int C, int k, int nrings, DwArgs* a) {
+static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a) {
     const int cps = C / 2;
     // Search (channel pairs per workgroup, column strips).  Whole pixel when it fits (cps <= 72), otherwise channel
     // blocks of >= 32 pairs (>= 128-byte runs per pixel).  Score = lane utilisation x occupancy / halo.
@@ -53,7 +53,7 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, DwArgs* a) {
         const int cgn = cpw / 4;
         for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
             const int tw = sx * DW_BW, iw = tw + k - 1;
-            const size_t lds = (size_t)nrings * DW_RR * iw * cpw * 4;
+            const size_t lds = (size_t)nrings * rr * iw * cpw * 4;
             // two workgroups per CU either way (160 KB LDS): wide strips (78 KB) measured 8-10 % faster than 60 KB for
             // every launch form except the 5x5 weight-gradient sweep (3 rings), which is 14 % slower with them
             const size_t cap = (k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024;
@@ -83,15 +83,16 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, DwArgs* a) {
     return true;
 }
 
-static bool dw_setup(DwArgs* a, int N, int H, int W, int C, int k, int nrings, int nparts) {
-    if (!dw_pick(N, H, W, C, k, nrings, a)) return false;
+static bool dw_setup(DwArgs* a, int N, int H, int W, int C, int k, int nrings, int rr, int nparts) {
+    if (!dw_pick(N, H, W, C, k, nrings, rr, a)) return false;
     if (nparts < a->cblocks) return false;
     int g = nparts < a->items ? nparts : a->items;
     a->geff = g / a->cblocks * a->cblocks;          // multiple of cblocks: item % cblocks is constant per workgroup
     return a->geff >= a->cblocks;
 }
 
-__device__ __forceinline__ int dw_slot(int image_row) { return (image_row + DW_RR) & (DW_RR - 1); }   // rows >= -RR
+template <int RR>
+__device__ __forceinline__ int dw_slot(int image_row) { return (image_row + RR) & (RR - 1); }   // rows >= -RR
 
 __device__ __forceinline__ void dw_item(const DwArgs& a, int item, int& n, int& x0, int& c0) {
     const int cb = item % a.cblocks;
@@ -126,17 +127,17 @@ __device__ __forceinline__ void dw_dma_plan(const DwArgs& a, DwDma& p, int wave,
 }
 
 // copy image rows [row0, row0+G) of one tensor (rows outside the image are skipped: readers test the row themselves)
-template <int KS>
+template <int KS, int G>
 __device__ __forceinline__ void dw_dma_rows(const DwArgs& a, const DwDma& p, uint32_t* ring, const uint4* __restrict__ src,
                                             int n, int row0, int x0, int c0, int wave, int nwaves) {
     constexpr int PAD = KS / 2;
     const int C8 = a.C >> 3;
 #pragma unroll
-    for (int r = 0; r < DW_G; ++r) {
+    for (int r = 0; r < G; ++r) {
         const int gy = row0 + r;
         if (gy < 0 || gy >= a.H) continue;                                   // uniform
         const uint4* rowsrc = src + ((size_t)n * a.H + gy) * a.W * C8 + (ptrdiff_t)(x0 - PAD) * C8 + (c0 >> 3);
-        uint32_t* rowdst = ring + (size_t)dw_slot(gy) * a.rc * 4;
+        uint32_t* rowdst = ring + (size_t)dw_slot<2 * G>(gy) * a.rc * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int b = wave + j * nwaves;
@@ -269,11 +270,11 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         // step: it publishes group s (hipcc drains vmcnt before s_barrier) and retires the readers of group s-1, whose
         // buffer the next DMA overwrites.
         __syncthreads();                             // previous item's last group consumed
-        dw_dma_rows<KS>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
+        dw_dma_rows<KS, DW_G>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * DW_G;
             __syncthreads();
-            if (s + 1 < nsteps) dw_dma_rows<KS>(a, plan, ring, (const uint4*)in.data, n, r0 + DW_G, x0, c0, wave, nwaves);
+            if (s + 1 < nsteps) dw_dma_rows<KS, DW_G>(a, plan, ring, (const uint4*)in.data, n, r0 + DW_G, x0, c0, wave, nwaves);
             if (!active) continue;
 #pragma unroll 1
             for (int j = 0; j < DW_G; ++j) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
                 const int oy = iy - PAD;             // A[0] is complete after this row
                 if (iy >= 0 && iy < a.H) {           // uniform: rows outside the image contribute nothing
                     f2 xr[WIN_W];
-                    dw_read_act<WIN_W>(colp + (size_t)dw_slot(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
+                    dw_read_act<WIN_W>(colp + (size_t)dw_slot<DW_RR>(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
 #pragma unroll
                     for (int i = 0; i < KS; ++i)
 #pragma unroll
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
 //                                   its centre 4 columns become D[0] of the dy ring (D[q] = dy row iy-q)
 //   xa = act(x) row r = iy-PAD   -> WG: wacc[ky][kx] += D[ky][ox] * xa[ox+kx]      (dy rows r-ky+PAD = iy-ky)
 //   RED: the raw x centre values of row iy-PAD are in the x ring too: sum dz, sum dz*xhat for the emitted gin row.
-template <int KS, bool DG, bool WG, bool RED>
+template <int KS, bool DG, bool WG, bool RED, int G>
 __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
     float* __restrict__ red_partial, const float* __restrict__ red_bn) {
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     constexpr bool REDG = RED && !WG;          // input-gradient-only launch: the reduce reads raw x from global (2 rings)
     const int cblk = 2 * a.cpw;
     uint32_t* ring_g = (uint32_t*)smem;                      // rings; reused as reduction scratch at the end
-    uint32_t* ring_y = ring_g + (size_t)DW_RR * a.rc * 4;
-    uint32_t* ring_x = ring_y + (size_t)DW_RR * a.rc * 4;
+    uint32_t* ring_y = ring_g + (size_t)(2 * G) * a.rc * 4;
+    uint32_t* ring_x = ring_y + (size_t)(2 * G) * a.rc * 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     f2 s1 = zero2, s2 = zero2;
 #pragma unroll
     for (int t = 0; t < (WG ? KS * KS : 1); ++t) wacc[t] = zero2;
-    const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
+    const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
     for (int item = blockIdx.x; item < a.items; item += a.geff) {
@@ -405,18 +406,18 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
         // double-buffered groups of G rows (see k_dw_fwd); the x ring runs PAD rows behind g/y: row iy of dy meets row
         // oy = iy - PAD of x, and each row of either is read from LDS exactly once
         auto dma_group = [&](int r0) {
-            dw_dma_rows<KS>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
-            dw_dma_rows<KS>(a, plan, ring_y, (const uint4*)d.y, n, r0, x0, c0, wave, nwaves);
-            if (NEEDX) dw_dma_rows<KS>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves);
+            dw_dma_rows<KS, G>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
+            dw_dma_rows<KS, G>(a, plan, ring_y, (const uint4*)d.y, n, r0, x0, c0, wave, nwaves);
+            if (NEEDX) dw_dma_rows<KS, G>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves);
         };
         // input-gradient-only launch with the fused reduce: the raw x values of the rows it emits come from global memory,
         // fetched one group AHEAD (with the DMA, before the barrier that drains vmcnt) so that no load issued inside the
         // compute phase has to wait behind the in-flight DMA of the next group (vmcnt retires in order)
-        uint32_t xq[REDG ? DW_G : 1][DW_BW], xn[REDG ? DW_G : 1][DW_BW];
+        uint32_t xq[REDG ? G : 1][DW_BW], xn[REDG ? G : 1][DW_BW];
         auto load_xn = [&](int r0) {
             if constexpr (REDG) {
 #pragma unroll
-                for (int j = 0; j < DW_G; ++j) {
+                for (int j = 0; j < G; ++j) {
                     const int oy = r0 - PAD + j;
                     const bool ok = oy >= 0 && oy < a.H && ch_ok && active;
                     const uint32_t* yp = xglob + obase + (size_t)oy * a.W * a.C / 2;
@@ -429,18 +430,18 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
         dma_group(-PAD);
         load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
-            const int r0 = -PAD + s * DW_G;
+            const int r0 = -PAD + s * G;
             __syncthreads();
             if constexpr (REDG) {
 #pragma unroll
-                for (int j = 0; j < DW_G; ++j)
+                for (int j = 0; j < G; ++j)
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) xq[j][ox] = xn[j][ox];
             }
-            if (s + 1 < nsteps) { dma_group(r0 + DW_G); load_xn(r0 + DW_G); }
+            if (s + 1 < nsteps) { dma_group(r0 + G); load_xn(r0 + G); }
             if (!active) continue;
 #pragma unroll 1
-            for (int j = 0; j < DW_G; ++j) {
+            for (int j = 0; j < G; ++j) {
                 const int iy = r0 + j;
                 const int oy = iy - PAD;
                 const bool row_in = iy >= 0 && iy < a.H;
@@ -450,14 +451,14 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) xraw[ox] = xq[0][ox];
 #pragma unroll
-                    for (int q = 0; q + 1 < DW_G; ++q)
+                    for (int q = 0; q + 1 < G; ++q)
 #pragma unroll
                         for (int ox = 0; ox < DW_BW; ++ox) xq[q][ox] = xq[q + 1][ox];
                 }
                 // ---- dy row iy
                 f2 xr[WIN_W];
                 if (row_in) {
-                    const size_t ro = (size_t)dw_slot(iy) * a.rc * 4 + coloff;
+                    const size_t ro = (size_t)dw_slot<2 * G>(iy) * a.rc * 4 + coloff;
                     dw_read_dy<WIN_W>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
                 } else {
 #pragma unroll
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 // ---- x row oy = iy - PAD: activation window (WG) and raw centre (RED)
                 f2 xa[WIN_W];
                 if (NEEDX && orow_in) {
-                    const uint32_t* rowp = ring_x + (size_t)dw_slot(oy) * a.rc * 4 + coloff;
+                    const uint32_t* rowp = ring_x + (size_t)dw_slot<2 * G>(oy) * a.rc * 4 + coloff;
                     if (WG) dw_read_act<WIN_W>(rowp, ps, has_coef, cs, ct, colmask, xa);
                     if (RED && !REDG) {
 #pragma unroll
@@ -549,20 +550,31 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-// LDS rings per launch form: forward 1 (x); input-gradient-only 2 (g, y); anything that computes the weight gradient 3.
-// Partial-table rows for a launch with `nparts`:  which = 0 forward statistics float[2][C][rows];
-// which = 1 tables written by a weight-gradient-computing launch (wpartial float[rows][k*k][C] and, when fused with the
-// input gradient, the reduce table float[2][C][rows]);  which = 2 the reduce table of an input-gradient-only launch.
+// Launch forms: forward (1 ring, x); phase 1 = input gradient (+reduce) (2 rings: g, y); phase 0 = fused and phase 2 =
+// weight gradient only (3 rings: g, y, x).  Rows per DMA group G = 4 (ring = 8 rows) except the 5x5 weight-gradient-only
+// sweep, G = 2: its three rings are what limits the strip width, and with 4-row rings it gets 2 full-width strips on a
+// 56-wide image where 8-row rings allow only 5 narrow ones (halo 1.33, 84 % of the lanes busy).
+static void dw_form(int k, int form, int* nrings, int* g) {      // form: -1 forward, else phase
+    *nrings = form < 0 ? 1 : (form == 1 ? 2 : 3);
+    *g = (k == 5 && form == 2) ? 2 : DW_G;
+}
+// Partial-table rows for a launch with `nparts`:  which = 0 forward statistics float[2][C][rows];  which = 1 both tables of
+// a phase-0 launch (wpartial float[rows][k*k][C], reduce float[2][C][rows]);  which = 2 the reduce table of a phase-1
+// launch;  which = 3 wpartial of a phase-2 launch.
 extern "C" int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which) {
+    if (which < 0 || which > 3) return -1;
+    static const int form_of[4] = {-1, 0, 1, 2};
+    int nrings, g;
+    dw_form(k, form_of[which], &nrings, &g);
     DwArgs a;
-    if (!dw_setup(&a, N, H, W, C, k, which == 0 ? 1 : (which == 1 ? 3 : 2), nparts)) return -1;
+    if (!dw_setup(&a, N, H, W, C, k, nrings, 2 * g, nparts)) return -1;
     return a.geff / a.cblocks;
 }
 
 extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
     DwArgs a;
-    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, c->nparts)) return MNAS_EINVAL;
+    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, DW_RR, c->nparts)) return MNAS_EINVAL;
     const size_t lds = (size_t)DW_RR * a.rc * 16;
     hipStream_t s = (hipStream_t)stream;
     if (c->k == 3)
@@ -579,20 +591,23 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
     // phase 0: everything in one fused sweep.  phase 1: input gradient (+reduce).  phase 2: weight gradient.
     const bool want_dg = c->phase != 2, want_wg = c->phase != 1;
-    const int nrings = want_wg ? 3 : 2;
+    int nrings, g;
+    dw_form(c->k, c->phase, &nrings, &g);
     DwArgs a;
-    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, nrings, c->nparts)) return MNAS_EINVAL;
-    const size_t lds = (size_t)nrings * DW_RR * a.rc * 16;
-#define MNAS_DWB(K_, DG_, WG_, R_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, \
-                                                     c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
+    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, nrings, 2 * g, c->nparts)) return MNAS_EINVAL;
+    size_t lds = (size_t)nrings * 2 * g * a.rc * 16;
+    const size_t red_need = (size_t)a.sx * (want_wg ? c->k * c->k : 2) * 2 * a.cpw * sizeof(float);   // dw_block_reduce scratch
+    if (lds < red_need) lds = red_need;
+#define MNAS_DWB(K_, DG_, WG_, R_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
+                                                         c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
     if (c->k == 3) {
-        if (want_dg && want_wg) { if (red) MNAS_DWB(3, true, true, true); else MNAS_DWB(3, true, true, false); }
-        else if (want_dg) { if (red) MNAS_DWB(3, true, false, true); else MNAS_DWB(3, true, false, false); }
-        else MNAS_DWB(3, false, true, false);
+        if (want_dg && want_wg) { if (red) MNAS_DWB(3, true, true, true, 4); else MNAS_DWB(3, true, true, false, 4); }
+        else if (want_dg) { if (red) MNAS_DWB(3, true, false, true, 4); else MNAS_DWB(3, true, false, false, 4); }
+        else MNAS_DWB(3, false, true, false, 4);
     } else {
-        if (want_dg && want_wg) { if (red) MNAS_DWB(5, true, true, true); else MNAS_DWB(5, true, true, false); }
-        else if (want_dg) { if (red) MNAS_DWB(5, true, false, true); else MNAS_DWB(5, true, false, false); }
-        else MNAS_DWB(5, false, true, false);
+        if (want_dg && want_wg) { if (red) MNAS_DWB(5, true, true, true, 4); else MNAS_DWB(5, true, true, false, 4); }
+        else if (want_dg) { if (red) MNAS_DWB(5, true, false, true, 4); else MNAS_DWB(5, true, false, false, 4); }
+        else MNAS_DWB(5, false, true, false, 2);
     }
 #undef MNAS_DWB
     MNAS_CHECK_LAUNCH();

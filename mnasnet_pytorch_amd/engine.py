@@ -319,7 +319,7 @@ class Program:
                     ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 2)
                 wsc = eng.scratch_wgrad2 if ci.k in eng.dw_fused_k else eng.scratch_wgrad     # fused runs on the main stream
                 dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), wsc.data_ptr()] + red
-                wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1)
+                wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 3)
                 if wrows < 1 or (rt is not None and ncols < 1):
                     raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, Co, ci.k),))
                 if ci.k in eng.dw_fused_k:

@@ -256,7 +256,7 @@ def test_dw_bwd(shape, phase):
     wp = pack(w, L.PACK_DW)
     nparts = 37
     gin = torch.empty((N, H, W, C_), dtype=torch.bfloat16, device="cuda")
-    rows1 = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 1)
+    rows1 = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 1 if phase == 0 else 3)     # wpartial: fused or weight-gradient-only launch
     # reduce table: written by the fused launch (3-ring geometry) or by the input-gradient-only launch (2 rings)
     rows0 = rows1 if phase == 0 else lib.mnas_dw_rows(N, H, W, C_, k, nparts, 2)
     wpart = torch.full((rows1, k * k, C_), float("nan"), device="cuda")
