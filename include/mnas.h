@@ -130,6 +130,9 @@ int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
  * which = 1: both tables of a phase-0 (fused) backward launch: wpartial float[rows][k*k][C], reduce float[2][C][rows];
  * which = 2: the fused-reduce table of a phase-1 (input-gradient-only) launch;
  * which = 3: wpartial of a phase-2 (weight-gradient-only) launch.  Returns < 0 for unsupported shapes. */
+/* Diagnostics: geometry picked for a launch form (`which` as in mnas_dw_rows).  out[7] = {channel pairs per workgroup,
+ * 4-column strips per workgroup, threads, strips per image row, channel blocks, LDS bytes, rows per DMA group}. */
+int mnas_dw_geometry(int N, int H, int W, int C, int k, int which, int* out);
 int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which);
 
 typedef struct MnasDwBwd {

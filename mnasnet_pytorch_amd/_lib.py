@@ -78,6 +78,7 @@ SYMBOLS = {
     "mnas_dw_fwd": (c_int, [C.POINTER(MnasDwFwd), c_void_p]),
     "mnas_dw_bwd": (c_int, [C.POINTER(MnasDwBwd), c_void_p]),
     "mnas_dw_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mnas_dw_geometry": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_int)]),
     "mnas_dw_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mnas_stem_fwd": (c_int, [C.POINTER(MnasStemFwd), c_void_p]),
     "mnas_stem_wgrad": (c_int, [C.POINTER(MnasStemWgrad), c_void_p]),

@@ -38,6 +38,7 @@ struct DwArgs {
     int cpw, sx, nthreads, cgn, iw;
     int strips_x, cblocks, items, geff;     // geff: workgroups that take items (multiple of cblocks)
     int rc, nb;                             // 16-byte chunks per ring row; DMA blocks (64 chunks) per row
+    float score;                            // geometry score of dw_pick (host only)
 };
 
 static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a) {
@@ -70,6 +71,7 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArg
         }
     }
     if (best_sx == 0) return false;
+    a->score = (float)best;
     const int cpw = best_cpw, cgn = cpw / 4;
     a->N = N; a->H = H; a->W = W; a->C = C;
     a->cpw = cpw; a->sx = best_sx; a->cgn = cgn;
@@ -81,14 +83,6 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArg
     a->rc = a->iw * cgn;
     a->nb = (a->rc + 63) / 64;
     return true;
-}
-
-static bool dw_setup(DwArgs* a, int N, int H, int W, int C, int k, int nrings, int rr, int nparts) {
-    if (!dw_pick(N, H, W, C, k, nrings, rr, a)) return false;
-    if (nparts < a->cblocks) return false;
-    int g = nparts < a->items ? nparts : a->items;
-    a->geff = g / a->cblocks * a->cblocks;          // multiple of cblocks: item % cblocks is constant per workgroup
-    return a->geff >= a->cblocks;
 }
 
 template <int RR>
@@ -214,7 +208,7 @@ __device__ __forceinline__ void dw_block_reduce(float* scratch, const f2 (&v)[NV
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------
-template <int KS>
+template <int KS, int G>
 __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, MnasActIn in, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, uint32_t* __restrict__ out,
                                                                    float* __restrict__ stats) {
@@ -231,7 +225,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     f2 s1 = zero2, s2 = zero2;
     int cur_c0 = -1;
     f2 wt[KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
-    const int nsteps = (a.H + 2 * PAD + DW_G - 1) / DW_G;
+    const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
     for (int item = blockIdx.x; item < a.items; item += a.geff) {
@@ -270,19 +264,19 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         // step: it publishes group s (hipcc drains vmcnt before s_barrier) and retires the readers of group s-1, whose
         // buffer the next DMA overwrites.
         __syncthreads();                             // previous item's last group consumed
-        dw_dma_rows<KS, DW_G>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
+        dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
         for (int s = 0; s < nsteps; ++s) {
-            const int r0 = -PAD + s * DW_G;
+            const int r0 = -PAD + s * G;
             __syncthreads();
-            if (s + 1 < nsteps) dw_dma_rows<KS, DW_G>(a, plan, ring, (const uint4*)in.data, n, r0 + DW_G, x0, c0, wave, nwaves);
+            if (s + 1 < nsteps) dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, r0 + G, x0, c0, wave, nwaves);
             if (!active) continue;
 #pragma unroll 1
-            for (int j = 0; j < DW_G; ++j) {
+            for (int j = 0; j < G; ++j) {
                 const int iy = r0 + j;
                 const int oy = iy - PAD;             // A[0] is complete after this row
                 if (iy >= 0 && iy < a.H) {           // uniform: rows outside the image contribute nothing
                     f2 xr[WIN_W];
-                    dw_read_act<WIN_W>(colp + (size_t)dw_slot<DW_RR>(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
+                    dw_read_act<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
 #pragma unroll
                     for (int i = 0; i < KS; ++i)
 #pragma unroll
@@ -554,33 +548,62 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 // weight gradient only (3 rings: g, y, x).  Rows per DMA group G = 4 (ring = 8 rows) except the 5x5 weight-gradient-only
 // sweep, G = 2: its three rings are what limits the strip width, and with 4-row rings it gets 2 full-width strips on a
 // 56-wide image where 8-row rings allow only 5 narrow ones (halo 1.33, 84 % of the lanes busy).
-static void dw_form(int k, int form, int* nrings, int* g) {      // form: -1 forward, else phase
-    *nrings = form < 0 ? 1 : (form == 1 ? 2 : 3);
-    *g = (k == 5 && form == 2) ? 2 : DW_G;
+static int dw_rings(int form) { return form < 0 ? 1 : (form == 1 ? 2 : 3); }      // form: -1 forward, else phase
+// Pick rows-per-group G in {4, 2} and the strip geometry for a launch form: 2-row groups halve the ring footprint (wider
+// strips / more channels per workgroup) at the price of a barrier every 2 rows instead of 4 (priced at 7 %).
+static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g) {
+    DwArgs a4, a2;
+    const int nrings = dw_rings(form);
+    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2);
+    if (!ok4 && !ok2) return false;
+    if (ok2 && (!ok4 || 0.93f * a2.score > a4.score)) { *a = a2; *g = 2; }
+    else { *a = a4; *g = 4; }
+    return true;
+}
+static bool dw_finish(DwArgs* a, int nparts) {
+    if (nparts < a->cblocks) return false;
+    int g = nparts < a->items ? nparts : a->items;
+    a->geff = g / a->cblocks * a->cblocks;          // multiple of cblocks: item % cblocks is constant per workgroup
+    return a->geff >= a->cblocks;
 }
 // Partial-table rows for a launch with `nparts`:  which = 0 forward statistics float[2][C][rows];  which = 1 both tables of
 // a phase-0 launch (wpartial float[rows][k*k][C], reduce float[2][C][rows]);  which = 2 the reduce table of a phase-1
 // launch;  which = 3 wpartial of a phase-2 launch.
+static const int dw_form_of[4] = {-1, 0, 1, 2};
 extern "C" int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which) {
     if (which < 0 || which > 3) return -1;
-    static const int form_of[4] = {-1, 0, 1, 2};
-    int nrings, g;
-    dw_form(k, form_of[which], &nrings, &g);
     DwArgs a;
-    if (!dw_setup(&a, N, H, W, C, k, nrings, 2 * g, nparts)) return -1;
+    int g;
+    if (!dw_choose(N, H, W, C, k, dw_form_of[which], &a, &g) || !dw_finish(&a, nparts)) return -1;
     return a.geff / a.cblocks;
+}
+
+// Geometry chosen for a launch form (diagnostics / DESIGN.md tables): out = {channel pairs per workgroup, 4-column strips
+// per workgroup, threads, strips per image row, channel blocks, LDS bytes, rows per DMA group}
+extern "C" int mnas_dw_geometry(int N, int H, int W, int C, int k, int which, int* out) {
+    if (which < 0 || which > 3 || !out) return MNAS_EINVAL;
+    DwArgs a;
+    int g;
+    if (!dw_choose(N, H, W, C, k, dw_form_of[which], &a, &g)) return MNAS_EINVAL;
+    out[0] = a.cpw; out[1] = a.sx; out[2] = a.nthreads; out[3] = a.strips_x; out[4] = a.cblocks;
+    out[5] = dw_rings(dw_form_of[which]) * 2 * g * a.rc * 16; out[6] = g;
+    return MNAS_OK;
 }
 
 extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
     DwArgs a;
-    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, 1, DW_RR, c->nparts)) return MNAS_EINVAL;
-    const size_t lds = (size_t)DW_RR * a.rc * 16;
+    int g;
+    if (!dw_choose(c->N, c->H, c->W, c->C, c->k, -1, &a, &g) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
+    size_t lds = (size_t)2 * g * a.rc * 16;
+    const size_t red_need = (size_t)a.sx * 2 * 2 * a.cpw * sizeof(float);          // dw_block_reduce scratch
+    if (lds < red_need) lds = red_need;
     hipStream_t s = (hipStream_t)stream;
-    if (c->k == 3)
-        hipLaunchKernelGGL(k_dw_fwd<3>, dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, (uint32_t*)c->out, c->stats);
-    else
-        hipLaunchKernelGGL(k_dw_fwd<5>, dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, (uint32_t*)c->out, c->stats);
+#define MNAS_DWF(K_, G_) hipLaunchKernelGGL((k_dw_fwd<K_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
+                                            (uint32_t*)c->out, c->stats)
+    if (c->k == 3) { if (g == 4) MNAS_DWF(3, 4); else MNAS_DWF(3, 2); }
+    else { if (g == 4) MNAS_DWF(5, 4); else MNAS_DWF(5, 2); }
+#undef MNAS_DWF
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -591,24 +614,26 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
     // phase 0: everything in one fused sweep.  phase 1: input gradient (+reduce).  phase 2: weight gradient.
     const bool want_dg = c->phase != 2, want_wg = c->phase != 1;
-    int nrings, g;
-    dw_form(c->k, c->phase, &nrings, &g);
+    const int nrings = dw_rings(c->phase);
     DwArgs a;
-    if (!dw_setup(&a, c->N, c->H, c->W, c->C, c->k, nrings, 2 * g, c->nparts)) return MNAS_EINVAL;
+    int g;
+    if (!dw_choose(c->N, c->H, c->W, c->C, c->k, c->phase, &a, &g) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
     size_t lds = (size_t)nrings * 2 * g * a.rc * 16;
     const size_t red_need = (size_t)a.sx * (want_wg ? c->k * c->k : 2) * 2 * a.cpw * sizeof(float);   // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
 #define MNAS_DWB(K_, DG_, WG_, R_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
                                                          c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
+#define MNAS_DWB_G(K_, DG_, WG_, R_) do { if (g == 4) MNAS_DWB(K_, DG_, WG_, R_, 4); else MNAS_DWB(K_, DG_, WG_, R_, 2); } while (0)
     if (c->k == 3) {
-        if (want_dg && want_wg) { if (red) MNAS_DWB(3, true, true, true, 4); else MNAS_DWB(3, true, true, false, 4); }
-        else if (want_dg) { if (red) MNAS_DWB(3, true, false, true, 4); else MNAS_DWB(3, true, false, false, 4); }
-        else MNAS_DWB(3, false, true, false, 4);
+        if (want_dg && want_wg) { if (red) MNAS_DWB_G(3, true, true, true); else MNAS_DWB_G(3, true, true, false); }
+        else if (want_dg) { if (red) MNAS_DWB_G(3, true, false, true); else MNAS_DWB_G(3, true, false, false); }
+        else MNAS_DWB_G(3, false, true, false);
     } else {
-        if (want_dg && want_wg) { if (red) MNAS_DWB(5, true, true, true, 4); else MNAS_DWB(5, true, true, false, 4); }
-        else if (want_dg) { if (red) MNAS_DWB(5, true, false, true, 4); else MNAS_DWB(5, true, false, false, 4); }
-        else MNAS_DWB(5, false, true, false, 2);
+        if (want_dg && want_wg) { if (red) MNAS_DWB_G(5, true, true, true); else MNAS_DWB_G(5, true, true, false); }
+        else if (want_dg) { if (red) MNAS_DWB_G(5, true, false, true); else MNAS_DWB_G(5, true, false, false); }
+        else MNAS_DWB_G(5, false, true, false);
     }
+#undef MNAS_DWB_G
 #undef MNAS_DWB
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
