@@ -40,7 +40,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const uint16_t* tile, int ld, int ro
 }
 
 template <bool STEM>
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
 
     const int p_begin = blockIdx.x * a.chunk;
     const int p_end = min(a.M, p_begin + a.chunk);
-    for (int pc = p_begin; pc < p_end; pc += WG_BPIX) {
-        __syncthreads();
-        // ---- issue every load of this 128-pixel chunk first: dy operands (g, y) and the activation operand
-        uint4 vg[4], vy[4], vx[4];
-        bool okd[4], oka[4];
+    // software pipeline: the global loads of chunk pc+128 are issued before the MFMAs of chunk pc and consumed (transform
+    // + LDS write) one iteration later
+    uint4 vg[4], vy[4], vx[4];
+    bool okd[4], oka[4];
+    auto issue = [&](int pc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             okd[i] = false;
@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
                 }
             }
         }
+    };
+    if (p_begin < p_end) issue(p_begin);
+    for (int pc = p_begin; pc < p_end; pc += WG_BPIX) {
+        __syncthreads();
         // ---- transform + write
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
             *(uint4*)(tile_a + pa[i] * lda + ca8[i] * 8) = v;
         }
         __syncthreads();
+        if (pc + WG_BPIX < p_end) issue(pc + WG_BPIX);
         // ---- each wave: its 32 pixels, all slab tiles
         bf16x8_t bf[WG_T];
 #pragma unroll
