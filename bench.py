@@ -117,7 +117,7 @@ def main():
     profile = (not args.no_roofline) and rank == 0
     if profile:
         eng.profile_opcodes = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE,
-                               L.OP_STEM_FWD, L.OP_STEM_WGRAD, L.OP_ADD_ACT}
+                               L.OP_STEM_FWD, L.OP_STEM_WGRAD, L.OP_ADD_ACT, L.OP_PW_BWD}
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size
@@ -165,7 +165,7 @@ def main():
     if profile:
         names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_conv<fwd>", L.OP_DW_BWD: "k_dw_bwd",
                  L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
-                 L.OP_ADD_ACT: "k_add_act"}
+                 L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd"}
         agg = {}
         detail = []
         for (tag, opc, ints), msv in eng.read_profile():
@@ -178,6 +178,10 @@ def main():
                 nbytes = 2 * ((2 * e_in + e_out) if ints[0] == 1 else (e_in + e_out))     # dgrad reads g AND y
                 flops = 2.0 * N_ * Ho * Wo * Co * Ci * ints[8] * ints[9] if ints[0] == 0 else \
                     2.0 * N_ * Hi * Wi * Ci * Co * ints[8] * ints[9]
+            elif opc == L.OP_PW_BWD:        # i: M,Ci,Co,nparts: reads g, y (Co) and x (Ci), writes gin (Ci)
+                M_, Ci, Co = ints[:3]
+                nbytes = 2 * M_ * (2 * Co + 2 * Ci)
+                flops = 2 * 2.0 * M_ * Co * Ci
             elif opc == L.OP_CONV_WGRAD:    # i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw
                 N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:7]
                 nbytes = 2 * (N_ * Hi * Wi * Ci + 2 * N_ * Ho * Wo * Co)

@@ -113,6 +113,29 @@ int mnas_conv_wgrad(const MnasConvWgrad* a, void* stream);
 int mnas_wgrad_finalize(float* partial, int nsplit, int Co, int Ci, int taps,
                         float* grad, int accumulate, void* stream);
 
+/* ---- fused backward of a 1x1 conv: input gradient + weight-gradient partials + (optionally) the BatchNorm-backward
+ * reduce of the ConvBlock that produced x, in one sweep over the pixels.  Replaces the pair
+ * mnas_conv_gemm(mode 1) + mnas_conv_wgrad for the large-pixel-count layers (autograd mirror of mnasnet.py:48-62).
+ * Supported channel pairs: mnas_pw_bwd_supported(Ci, Co) != 0 (the 112^2/56^2/28^2 pointwise convs of MNASNet-1.0).
+ * wpartial: float[nparts][Co][Ci], one slab per workgroup, fully overwritten -> mnas_wgrad_finalize(wpartial, nparts,
+ * Co, Ci, 1, grad, ...).  red_partial (or NULL): float[2][Ci][nparts] = (sum dz, sum dz*xhat) of (gin, red_y) under
+ * red_bn -- the fused BatchNorm-backward reduce of the ConvBlock whose activated output gin is the gradient of (red_y =
+ * its raw output; equals x.data when x is that block's virtual activation). */
+typedef struct MnasPwBwd {
+    int32_t M, Ci, Co, nparts;   /* pixels, conv input / output channels, persistent workgroups (<= 65535) */
+    MnasActIn  x;                /* forward input (M,Ci): raw + producer's (scale,shift), or a materialised activation */
+    MnasGradIn dy;               /* g, y (M,Co) and coef[5][Co] of this ConvBlock's BatchNorm */
+    const void* w;               /* MNAS_PACK_DGRAD weights */
+    const void* resid;           /* bf16 (M,Ci) added to gin, or NULL */
+    void*  gin;                  /* bf16 (M,Ci) */
+    float* wpartial;
+    float* red_partial;
+    const void*  red_y;
+    const float* red_bn;
+} MnasPwBwd;
+int mnas_pw_bwd(const MnasPwBwd* a, void* stream);
+int mnas_pw_bwd_supported(int Ci, int Co);
+
 /* ---- depthwise kxk (k in {3,5}, stride 1, pad k/2), LDS-tiled direct conv on the vector ALU ----------
  * Replaces ATen conv2d fwd/bwd for ConvBlock's groups==C convs (mnasnet.py:122-125, 76-81). */
 typedef struct MnasDwFwd {
@@ -233,6 +256,7 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_PACK_WEIGHTS 14
 #define MNAS_OP_EVENT_RECORD 15    /* p[0] = event handle from mnas_event_create: hipEventRecord on the op's stream */
 #define MNAS_OP_EVENT_WAIT 16      /* p[0] = event handle: hipStreamWaitEvent(op's stream, event) */
+#define MNAS_OP_PW_BWD 17
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

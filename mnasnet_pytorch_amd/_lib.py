@@ -48,6 +48,12 @@ class MnasDwBwd(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class MnasPwBwd(C.Structure):
+    _fields_ = [("M", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32), ("nparts", C.c_int32), ("x", MnasActIn),
+                ("dy", MnasGradIn), ("w", c_void_p), ("resid", c_void_p), ("gin", c_void_p), ("wpartial", c_void_p),
+                ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p)]
+
+
 class MnasStemFwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("Co", C.c_int32), ("nparts", C.c_int32), ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p),
@@ -65,7 +71,7 @@ class MnasOp(C.Structure):
 
 OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
-OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT = 12, 13, 14, 15, 16
+OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD = 12, 13, 14, 15, 16, 17
 PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
@@ -75,6 +81,8 @@ SYMBOLS = {
     "mnas_conv_gemm": (c_int, [C.POINTER(MnasConvGemm), c_void_p]),
     "mnas_conv_wgrad": (c_int, [C.POINTER(MnasConvWgrad), c_void_p]),
     "mnas_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mnas_pw_bwd": (c_int, [C.POINTER(MnasPwBwd), c_void_p]),
+    "mnas_pw_bwd_supported": (c_int, [c_int, c_int]),
     "mnas_dw_fwd": (c_int, [C.POINTER(MnasDwFwd), c_void_p]),
     "mnas_dw_bwd": (c_int, [C.POINTER(MnasDwBwd), c_void_p]),
     "mnas_dw_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -21,6 +21,7 @@ extern "C" const char* mnas_arch(void) { return "gfx950"; }
 //  ADD_ACT          i: C,HW               d: rows                 p: a.data,a.scale,a.shift, b.data,b.scale,b.shift, out_bf16,out_nchw
 //  NCHW_TO_NHWC     i: N,C,HW                                     p: src,dst
 //  PACK_WEIGHTS     i: kind,Co,Ci,kh,kw                           p: w,dst
+//  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
     void* const* p = o.p;
@@ -43,6 +44,15 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.partial = (float*)p[6];
             return mnas_conv_wgrad(&a, stream);
+        }
+        case MNAS_OP_PW_BWD: {
+            MnasPwBwd a = {};
+            a.M = i[0]; a.Ci = i[1]; a.Co = i[2]; a.nparts = i[3];
+            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
+            a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
+            a.w = p[6]; a.resid = p[7]; a.gin = p[8]; a.wpartial = (float*)p[9];
+            a.red_partial = (float*)p[10]; a.red_y = p[11]; a.red_bn = (const float*)p[12];
+            return mnas_pw_bwd(&a, stream);
         }
         case MNAS_OP_WGRAD_FINALIZE:
             return mnas_wgrad_finalize((float*)p[0], i[0], i[1], i[2], i[3], (float*)p[1], i[4], stream);

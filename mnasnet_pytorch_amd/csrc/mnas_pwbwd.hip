@@ -1,0 +1,352 @@
+// Fused backward of a 1x1 convolution for the large-pixel-count stages (112x112 / 56x56 / 28x28):
+//     gin[pix][ci]  = sum_co dy[pix][co] * W[co][ci]  (+ residual gradient)        -- ATen conv2d input gradient
+//     dW[co][ci]    = sum_pix dy[pix][co] * act(x)[pix][ci]                         -- ATen conv2d weight gradient
+//     (sum dz, sum dz*xhat) of the ConvBlock whose activated output gin belongs to     -- batch-norm backward, pass 1
+// in ONE sweep over the pixels.  Replaces the pair k_igemm<dgrad> + k_wgrad for ConvBlock(kernel_size=1)
+// (autograd mirror of mnasnet.py:48-62).  Why: both kernels stream the same (g, y) pair -- the BatchNorm/ReLU backward
+// "dy-on-load" operand -- and at these sizes both are HBM-bound; sharing the staged dy tile removes a third of their
+// combined traffic (e.g. 112x112 expand: 2*48 + 16 + 16 + 16 channels per pixel instead of (2*48 + 16 + 16) + (2*48 + 16)).
+//
+// One workgroup (4 waves) walks 64*PT-pixel tiles persistently:
+//   stage   dy tile [pix][co] (dy-on-load from g, y) and act(x) tile [pix][ci] (act-on-load), both pixel-major bf16 in LDS;
+//   dgrad   MFMA A = W^T rows [ci16][co32] (LDS, resident for the whole kernel), B = dy rows [pix16][co32]
+//           -> D[ci][pix]: a lane holds 4 consecutive ci of one pixel (lane-local epilogue, 8-byte stores);
+//   wgrad   MFMA A = dy^T [co16][pix32], B = act(x)^T [ci16][pix32], both read with the LDS transpose read
+//           (ds_read_b64_tr_b16) from the SAME pixel-major tiles; the (co16 x ci16) accumulator tiles are split
+//           over the 4 waves (each wave owns whole tiles: no cross-wave reduction) and live in registers for the
+//           whole kernel; written once per workgroup to wpartial[workgroup][co][ci] (mnas_wgrad_finalize sums them);
+//   reduce  per tile: 16-lane shuffle tree, then one LDS slot per (wave, channel) -- fixed order, no atomics.
+// Roofline: HBM.  MFMA work per tile is ~0.3 us against ~5 us of memory time.
+#include "mnas_common.h"
+
+typedef __attribute__((ext_vector_type(4))) short pw_s4_t;
+typedef __attribute__((address_space(3))) pw_s4_t* pw_lds_s4_ptr;
+
+struct PwBwdArgs {
+    int M, Ci, Co, Kd;       // Kd = Co rounded up to 32 (dgrad reduction length, row length of the packed weights)
+    MnasActIn x;
+    MnasGradIn dy;
+    const uint16_t* w;       // [round16(Ci)][Kd]
+    const void* resid;
+    void* gin;
+    float* wpartial;
+    float* red_partial;
+    const void* red_y;
+    const float* red_bn;
+};
+
+__device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
+    // rows row0 + (lane>>4)*8 + {0..7}, column col0 + (lane&15)   (see mnas_wgrad.hip)
+    const int i = lane & 15, g = lane >> 4;
+    const uint16_t* p = tile + (row0 + g * 8 + (i >> 2)) * ld + col0 + (i & 3) * 4;
+    const pw_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pw_lds_s4_ptr)p);
+    const pw_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pw_lds_s4_ptr)(p + 4 * ld));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int NTO, int NTI, int PT>
+__global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BP = 64 * PT;
+    constexpr int COP = NTO * 16, CIP = NTI * 16;
+    constexpr bool OWN_O = NTO >= NTI;                       // waves split the cout tiles (else the cin tiles)
+    constexpr int NOWN = OWN_O ? (NTO + 3) / 4 : (NTI + 3) / 4;
+    constexpr int NOTH = OWN_O ? NTI : NTO;
+    constexpr int ND = (BP * (COP / 8) + 255) / 256;         // dy staging slots per thread (upper bound)
+    constexpr int NX = (BP * (CIP / 8) + 255) / 256;         // x staging slots per thread
+    const int ldd = a.Kd + 8, ldw = a.Kd + 8, lda = CIP + 8;
+    float* lds_cd = (float*)smem;                            // [5][COP]
+    float* lds_cx = lds_cd + 5 * COP;                        // [2][CIP]
+    float* lds_rc = lds_cx + 2 * CIP;                        // [4][CIP]
+    float* lds_st = lds_rc + 4 * CIP;                        // [4 waves][2][CIP]
+    uint16_t* lds_w = (uint16_t*)(lds_st + 8 * CIP);         // [CIP][ldw]
+    uint16_t* tile_d = lds_w + CIP * ldw;                    // [BP][ldd]
+    uint16_t* tile_a = tile_d + BP * ldd;                    // [BP][lda]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const bool hasx = a.x.scale != nullptr;
+    const bool do_red = a.red_partial != nullptr;
+
+    // ---- one-time setup: coefficient tables, resident weights, zeroed tiles / statistics
+    for (int i = tid; i < 5 * COP; i += 256) {
+        const int r = i / COP, c = i % COP;
+        lds_cd[i] = (c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
+    }
+    for (int i = tid; i < 2 * CIP; i += 256) {
+        const int r = i / CIP, c = i % CIP;
+        lds_cx[i] = (hasx && c < a.Ci) ? (r == 0 ? a.x.scale[c] : a.x.shift[c]) : 0.f;
+    }
+    for (int i = tid; i < 4 * CIP; i += 256) {
+        const int r = i / CIP, c = i % CIP;
+        float v = 0.f;
+        if (do_red && c < a.Ci) {
+            if (r == 0) v = a.red_bn[0 * a.Ci + c];
+            else if (r == 1) v = a.red_bn[1 * a.Ci + c];
+            else if (r == 2) v = a.red_bn[6 * a.Ci + c];
+            else v = -a.red_bn[5 * a.Ci + c] * a.red_bn[6 * a.Ci + c];
+        }
+        lds_rc[i] = v;
+    }
+    for (int i = tid; i < 8 * CIP; i += 256) lds_st[i] = 0.f;
+    {
+        const int kc8n = a.Kd >> 3;
+        for (int q = tid; q < CIP * kc8n; q += 256) {
+            const int r = q / kc8n, kc8 = q - r * kc8n;
+            *(uint4*)(lds_w + r * ldw + kc8 * 8) = *(const uint4*)(a.w + (size_t)r * a.Kd + kc8 * 8);
+        }
+        const int nz = (BP * ldd + BP * lda) / 8;            // both tiles are contiguous; row strides are multiples of 8
+        for (int i = tid; i < nz; i += 256) ((uint4*)tile_d)[i] = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- staging plan (tile-invariant): slot -> (pixel in tile, 16-byte channel chunk)
+    const int cwd = a.Co >> 3, cwa = a.Ci >> 3;
+    int pd[ND], cd8[ND], pa[NX], ca8[NX];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int q = tid + 256 * i;
+        pd[i] = q / cwd; cd8[i] = q - pd[i] * cwd;
+        if (pd[i] >= BP) pd[i] = -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int q = tid + 256 * i;
+        pa[i] = q / cwa; ca8[i] = q - pa[i] * cwa;
+        if (pa[i] >= BP) pa[i] = -1;
+    }
+
+    f32x4_t acc_w[NOWN][NOTH];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+        for (int j = 0; j < NOTH; ++j) acc_w[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (a.M + BP - 1) / BP;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tile0 = t * BP;
+        __syncthreads();                                     // previous tile's fragments consumed (first pass: setup visible)
+        // ---- issue every load of the tile, then transform + write
+        uint4 vg[ND], vy[ND], vx[NX];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            vg[i] = make_uint4(0, 0, 0, 0); vy[i] = make_uint4(0, 0, 0, 0);
+            if (pd[i] >= 0 && tile0 + pd[i] < a.M) {
+                const size_t off = (size_t)(tile0 + pd[i]) * a.Co + cd8[i] * 8;
+                vg[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
+                vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            vx[i] = make_uint4(0, 0, 0, 0);
+            if (pa[i] >= 0 && tile0 + pa[i] < a.M)
+                vx[i] = *(const uint4*)((const uint16_t*)a.x.data + (size_t)(tile0 + pa[i]) * a.Ci + ca8[i] * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            if (pd[i] < 0) continue;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (tile0 + pd[i] < a.M) {
+                float cf[5][8];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    *(float4*)&cf[r][0] = *(const float4*)(lds_cd + r * COP + cd8[i] * 8);
+                    *(float4*)&cf[r][4] = *(const float4*)(lds_cd + r * COP + cd8[i] * 8 + 4);
+                }
+                float o[8];
+                dy8(vg[i], vy[i], cf[0], cf[1], cf[2], cf[3], cf[4], o);
+                v = pack8(o);
+            }
+            *(uint4*)(tile_d + pd[i] * ldd + cd8[i] * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (pa[i] < 0) continue;
+            uint4 v = vx[i];
+            if (tile0 + pa[i] >= a.M) v = make_uint4(0, 0, 0, 0);
+            else if (hasx) {
+                float s[8], sh[8];
+                *(float4*)&s[0] = *(const float4*)(lds_cx + ca8[i] * 8);
+                *(float4*)&s[4] = *(const float4*)(lds_cx + ca8[i] * 8 + 4);
+                *(float4*)&sh[0] = *(const float4*)(lds_cx + CIP + ca8[i] * 8);
+                *(float4*)&sh[4] = *(const float4*)(lds_cx + CIP + ca8[i] * 8 + 4);
+                v = act8(v, s, sh);
+            }
+            *(uint4*)(tile_a + pa[i] * lda + ca8[i] * 8) = v;
+        }
+        __syncthreads();
+
+        // the epilogue's global operands (raw output of the reduce target, residual gradient) for this lane's fragments:
+        // issued now, they land under the MFMA phases
+        uint2 ypre[PT][NTI], rpre[PT][NTI];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = tile0 + (wave * PT + pt) * 16 + l15;
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) {
+                const int ci = nt * 16 + lg * 4;
+                ypre[pt][nt] = make_uint2(0, 0); rpre[pt][nt] = make_uint2(0, 0);
+                if (m < a.M && ci < a.Ci) {
+                    const size_t o = (size_t)m * a.Ci + ci;
+                    if (do_red) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + o);
+                    if (a.resid) rpre[pt][nt] = *(const uint2*)((const uint16_t*)a.resid + o);
+                }
+            }
+        }
+        // ---- input gradient: D[ci][pix] = sum_co W^T[ci][co] * dy[pix][co]
+        f32x4_t acc_g[PT][NTI];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) acc_g[pt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int ksteps = a.Kd >> 5;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            bf16x8_t bfrag[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                bfrag[pt] = *(const bf16x8_t*)(tile_d + ((wave * PT + pt) * 16 + l15) * ldd + ks * 32 + lg * 8);
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) {
+                const bf16x8_t afrag = *(const bf16x8_t*)(lds_w + (nt * 16 + l15) * ldw + ks * 32 + lg * 8);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc_g[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[pt], acc_g[pt][nt], 0, 0, 0);
+            }
+        }
+        // ---- weight gradient: D[co][ci] += sum_pix dy^T[co][pix] * act(x)^T[ci][pix]; this wave's tiles only
+#pragma unroll
+        for (int ks = 0; ks < BP / 32; ++ks) {
+            bf16x8_t oth[NOTH];
+#pragma unroll
+            for (int j = 0; j < NOTH; ++j)
+                oth[j] = OWN_O ? pw_tr_frag(tile_a, lda, ks * 32, j * 16, lane) : pw_tr_frag(tile_d, ldd, ks * 32, j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < NOWN; ++i) {
+                const int own = wave + 4 * i;
+                if (own >= (OWN_O ? NTO : NTI)) continue;        // uniform per wave
+                const bf16x8_t mine = OWN_O ? pw_tr_frag(tile_d, ldd, ks * 32, own * 16, lane)
+                                            : pw_tr_frag(tile_a, lda, ks * 32, own * 16, lane);
+#pragma unroll
+                for (int j = 0; j < NOTH; ++j)
+                    acc_w[i][j] = OWN_O ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine, oth[j], acc_w[i][j], 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(oth[j], mine, acc_w[i][j], 0, 0, 0);
+            }
+        }
+        // ---- input-gradient epilogue: lane holds ci = nt*16 + lg*4 + {0..3} of pixel tile0 + (wave*PT+pt)*16 + l15
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = tile0 + (wave * PT + pt) * 16 + l15;
+            const bool mok = m < a.M;
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) {
+                const int ci = nt * 16 + lg * 4;
+                const bool ok = mok && ci < a.Ci;
+                float v[4] = {acc_g[pt][nt][0], acc_g[pt][nt][1], acc_g[pt][nt][2], acc_g[pt][nt][3]};
+                float d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    const size_t o = (size_t)m * a.Ci + ci;
+                    if (a.resid) {
+                        const uint2 rv = rpre[pt][nt];
+                        v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16(v[0], v[1]);
+                    pk.y = pack_bf16(v[2], v[3]);
+                    *(uint2*)((uint16_t*)a.gin + o) = pk;
+                    if (do_red) {
+                        // dz = g*[s*y+t>0] with g as stored (bf16), y = raw output of the reduce target; xhat = y*invstd - mean*invstd
+                        const uint2 yv = ypre[pt][nt];
+                        const float gq[4] = {bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y)};
+                        const float yq[4] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y)};
+                        const float4 cs = *(const float4*)(lds_rc + ci), ct = *(const float4*)(lds_rc + CIP + ci);
+                        const float4 cI = *(const float4*)(lds_rc + 2 * CIP + ci), cm = *(const float4*)(lds_rc + 3 * CIP + ci);
+                        const float rs_[4] = {cs.x, cs.y, cs.z, cs.w}, rt_[4] = {ct.x, ct.y, ct.z, ct.w};
+                        const float ri_[4] = {cI.x, cI.y, cI.z, cI.w}, rm_[4] = {cm.x, cm.y, cm.z, cm.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float dz = (fmaf(yq[r], rs_[r], rt_[r]) > 0.f) ? gq[r] : 0.f;
+                            d1[r] = dz;
+                            d2[r] = dz * fmaf(yq[r], ri_[r], rm_[r]);
+                        }
+                    }
+                }
+                if (do_red) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x1 = d1[r], x2 = d2[r];
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+                        if (l15 == 0) {                      // this lane is the only writer of (wave, channel)
+                            lds_st[(wave * 2 + 0) * CIP + ci + r] += x1;
+                            lds_st[(wave * 2 + 1) * CIP + ci + r] += x2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- weight-gradient partial of this workgroup: wpartial[blockIdx.x][co][ci]
+    float* wp = a.wpartial + (size_t)blockIdx.x * a.Co * a.Ci;
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+        const int own = wave + 4 * i;
+        if (own >= (OWN_O ? NTO : NTI)) continue;
+#pragma unroll
+        for (int j = 0; j < NOTH; ++j) {
+            const int to = OWN_O ? own : j, ti = OWN_O ? j : own;
+            const int ci = ti * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = to * 16 + lg * 4 + r;
+                if (co < a.Co && ci < a.Ci) wp[(size_t)co * a.Ci + ci] = acc_w[i][j][r];
+            }
+        }
+    }
+    if (do_red) {
+        __syncthreads();
+        for (int i = tid; i < 2 * CIP; i += 256) {
+            const int r = i / CIP, c = i % CIP;
+            const float v = ((lds_st[(0 * 2 + r) * CIP + c] + lds_st[(1 * 2 + r) * CIP + c]) + lds_st[(2 * 2 + r) * CIP + c]) +
+                            lds_st[(3 * 2 + r) * CIP + c];
+            if (c < a.Ci) a.red_partial[((size_t)r * a.Ci + c) * gridDim.x + blockIdx.x] = v;   // [2][Ci][P]
+        }
+    }
+}
+
+template <int NTO, int NTI, int PT>
+static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream) {
+    constexpr int BP = 64 * PT, COP = NTO * 16, CIP = NTI * 16;
+    const size_t lds = (size_t)(5 * COP + 14 * CIP) * sizeof(float) +
+                       ((size_t)CIP * (a.Kd + 8) + (size_t)BP * (a.Kd + 8) + (size_t)BP * (CIP + 8)) * 2;
+    if (lds > 160 * 1024) return MNAS_EINVAL;
+    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT>), dim3(nparts), dim3(256), lds, stream, a);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// Supported (cout tiles, cin tiles): the pointwise convs of the 112x112 / 56x56 / 28x28 stages of MNASNet-1.0
+// (16<->32/48, 24<->72, 40<->240 channels).  Other shapes: MNAS_EINVAL (use mnas_conv_gemm + mnas_conv_wgrad).
+extern "C" int mnas_pw_bwd_supported(int Ci, int Co) {
+    if ((Ci & 7) || (Co & 7) || Ci < 8 || Co < 8) return 0;
+    const int nto = (Co + 15) / 16, nti = (Ci + 15) / 16;
+    static const int ok[][2] = {{1, 2}, {1, 3}, {3, 1}, {5, 2}, {2, 5}, {15, 3}, {3, 15}};
+    for (auto& p : ok) if (p[0] == nto && p[1] == nti) return 1;
+    return 0;
+}
+
+extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
+    if (!c || c->M < 1 || c->nparts < 1 || c->nparts > 65535 || !mnas_pw_bwd_supported(c->Ci, c->Co)) return MNAS_EINVAL;
+    if (!c->x.data || !c->dy.g || !c->dy.y || !c->dy.coef || !c->w || !c->gin || !c->wpartial) return MNAS_EINVAL;
+    if (c->red_partial && (!c->red_bn || !c->red_y)) return MNAS_EINVAL;
+    PwBwdArgs a;
+    a.M = c->M; a.Ci = c->Ci; a.Co = c->Co; a.Kd = (c->Co + 31) / 32 * 32;
+    a.x = c->x; a.dy = c->dy; a.w = (const uint16_t*)c->w; a.resid = c->resid; a.gin = c->gin;
+    a.wpartial = c->wpartial; a.red_partial = c->red_partial; a.red_y = c->red_y; a.red_bn = c->red_bn;
+    const int nto = (c->Co + 15) / 16, nti = (c->Ci + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define MNAS_PWB(O_, I_, P_) if (nto == O_ && nti == I_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s);
+    MNAS_PWB(1, 2, 2) MNAS_PWB(1, 3, 2) MNAS_PWB(3, 1, 2) MNAS_PWB(5, 2, 2) MNAS_PWB(2, 5, 2) MNAS_PWB(15, 3, 1) MNAS_PWB(3, 15, 1)
+#undef MNAS_PWB
+    return MNAS_EINVAL;
+}

@@ -332,6 +332,20 @@ class Program:
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
                     ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
+            elif (ci.kind == "pw" and need_gin and M >= eng.pw_fused_min_pixels and lib.mnas_pw_bwd_supported(ci.cin, Co)
+                  and (eng.pw_fused_all or 2 * Co >= ci.cin)):
+                # large-pixel-count 1x1 conv: ONE sweep produces the input gradient, the weight-gradient partials and the
+                # fused reduce (both former kernels stream the same g, y; see csrc/mnas_pwbwd.hip).  Main stream.
+                gin = new((N, Hi, Wi, ci.cin))
+                nparts = max(1, min(1024 if M >= 800000 else 512, _cdiv(M, 128 if max(ci.cin, Co) <= 80 else 64)))
+                red = [None, None, None]
+                if rt is not None:
+                    red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
+                    ncols = nparts
+                ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts], [],
+                        a_in.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                                gin.data_ptr(), eng.scratch_wgrad2.data_ptr()] + red, 0)
+                ops.add(L.OP_WGRAD_FINALIZE, [nparts, Co, ci.cin, 1, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
             else:
                 K = ci.k * ci.k * ci.cin
                 slabs = _cdiv(Co, 64) * _cdiv(K, 64)
@@ -528,6 +542,11 @@ class Engine:
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
         self.dw_fused_k = (3,)           # depthwise kernel sizes whose backward runs as ONE fused sweep
+        # 1x1 convs with at least this many pixels use the fused backward (mnas_pw_bwd) when the conv widens or keeps the
+        # channel count moderately (2*Co >= Ci: measured 219 vs 399 us, 120 vs 199, 88 vs 141, 239 vs 285 at bs 256); the
+        # narrowing (project-type) convs are faster as two kernels (341 vs 331, 197 vs 195, 320 vs 175 us)
+        self.pw_fused_min_pixels = 100000
+        self.pw_fused_all = False          # tests: force the fused kernel for every supported shape
         self.side_stream = None
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_events = []         # [(tag, start_handle, stop_handle)]
@@ -555,6 +574,8 @@ class Engine:
                 K = ci.k * ci.k * ci.cin
                 slabs = _cdiv(ci.cout, 64) * _cdiv(K, 64)
                 wmax = max(wmax, max(1, _cdiv(1024, slabs)) * ci.cout * K)
+                if ci.kind == "pw" and self.lib.mnas_pw_bwd_supported(ci.cin, ci.cout):
+                    wmax = max(wmax, 1024 * ci.cout * ci.cin)      # one slab per workgroup of the fused 1x1 backward
             elif ci.kind == "dw":
                 ci.w_fwd = torch.empty(nbytes(L.PACK_DW, ci.cout, 1, ci.k, ci.k), dtype=torch.uint8, device=device)
                 wmax = max(wmax, 1024 * ci.k * ci.k * ci.cout)

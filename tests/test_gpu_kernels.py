@@ -484,3 +484,65 @@ def test_wgrad_finalize_split_ranges(nsplit, Co, Ci, taps, acc):
     L.check(lib.mnas_dw_wgrad_finalize(dpart.cuda().data_ptr(), nsplit, Co, k, dgrad.data_ptr(), acc, L.cur_stream()))
     dref = dpart.double().sum(0).t() + (dinit.double() if acc else 0)
     assert relerr(dgrad.cpu(), dref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused 1x1 backward (input gradient + weight gradient + BatchNorm-backward reduce of x's producer)
+PWB = [  # N,H,W,Ci,Co  -- every supported (cin tiles, cout tiles) pair; ragged pixel counts (tile tails)
+    (2, 12, 12, 32, 16), (3, 11, 9, 48, 16), (2, 13, 12, 16, 48), (2, 9, 9, 24, 72), (2, 10, 9, 72, 24),
+    (1, 9, 8, 40, 240), (1, 11, 7, 240, 40),
+]
+
+
+@pytest.mark.parametrize("shape", PWB)
+@pytest.mark.parametrize("variant", ["virt_red", "plain_resid", "virt"])
+@pytest.mark.parametrize("nparts", [1, 3])
+def test_pw_bwd_fused(shape, variant, nparts):
+    lib = L.load()
+    N, H, W, Ci, Co = shape
+    assert lib.mnas_pw_bwd_supported(Ci, Co) == 1
+    M = N * H * W
+    x = _x((N, Ci, H, W), 1)
+    virt = variant != "plain_resid"
+    bx = rand_bn_coefs(Ci, 22, O)                         # bnbuf of x's producer: rows 0/1 = scale/shift
+    a = bf16r(F.relu(x * bx[0].view(1, -1, 1, 1) + bx[1].view(1, -1, 1, 1))) if virt else x
+    g, y = _x((N, Co, H, W), 6), _x((N, Co, H, W), 7)
+    b = rand_bn_coefs(Co, 9, O)
+    dy = dy_ref(g, y, b)
+    w = bf16r(O.det_param("t.conv.weight", (Co, Ci, 1, 1), 2))
+    resid = _x((N, Ci, H, W), 5)
+    ref_gin = F.conv_transpose2d(dy, w) + (resid if variant == "plain_resid" else 0)
+    ref_dw = torch.nn.grad.conv2d_weight(a, (Co, Ci, 1, 1), dy)
+    xd, gd, yd, bd, bxd, rd = nhwc(x), nhwc(g), nhwc(y), b.cuda(), bx.cuda(), nhwc(resid)
+    gin = torch.full((N, H, W, Ci), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wpart = torch.full((nparts, Co, Ci), float("nan"), device="cuda")
+    redp = torch.full((2, Ci, nparts), float("nan"), device="cuda")
+    c = L.MnasPwBwd()
+    c.M, c.Ci, c.Co, c.nparts = M, Ci, Co, nparts
+    c.x = act_in(xd, bxd[0], bxd[1]) if virt else act_in(xd)
+    c.dy = grad_in(gd, yd, bd)
+    c.w, c.gin, c.wpartial = L.ptr(pack(w, L.PACK_DGRAD)), L.ptr(gin), L.ptr(wpart)
+    c.resid = L.ptr(rd) if variant == "plain_resid" else None
+    if variant == "virt_red":
+        c.red_partial, c.red_y, c.red_bn = L.ptr(redp), L.ptr(xd), L.ptr(bxd)
+    L.check(lib.mnas_pw_bwd(C.byref(c), L.cur_stream()), "pw_bwd")
+    assert relerr(from_nhwc(gin), ref_gin) < TOL_BF16
+    grad = torch.full((Co, Ci, 1, 1), float("nan"), device="cuda")
+    L.check(lib.mnas_wgrad_finalize(wpart.data_ptr(), nparts, Co, Ci, 1, grad.data_ptr(), 0, L.cur_stream()))
+    assert relerr(grad.cpu(), ref_dw) < TOL_F32
+    if variant == "virt_red":
+        gq = from_nhwc(gin)                               # the reduce sees g as stored (bf16)
+        s_, t_, mu_, is_ = (bx[i].view(1, -1, 1, 1) for i in (0, 1, 5, 6))
+        dz = (gq * ((s_ * x + t_) > 0)).double()
+        xhat = (x * is_ - mu_ * is_).double()
+        st = redp.cpu().double().sum(-1)
+        assert relerr(st[0], dz.sum((0, 2, 3))) < 1e-3
+        assert relerr(st[1], (dz * xhat).sum((0, 2, 3))) < 1e-3
+
+
+def test_pw_bwd_rejects_unsupported():
+    lib = L.load()
+    assert lib.mnas_pw_bwd_supported(96, 576) == 0 and lib.mnas_pw_bwd_supported(12, 16) == 0
+    c = L.MnasPwBwd()
+    c.M, c.Ci, c.Co, c.nparts = 64, 96, 576, 4
+    assert lib.mnas_pw_bwd(C.byref(c), L.cur_stream()) == 10001          # MNAS_EINVAL

@@ -175,11 +175,16 @@ def test_stage(name):
             assert rl2(sd[kk[len(name) + 1:]].cpu(), g[kk]) < 4e-2, kk
 
 
+@pytest.mark.parametrize("fused_pw", [False, True])
 @pytest.mark.parametrize("name", sorted(C.STAGES))
-def test_stage_well_conditioned(name):
+def test_stage_well_conditioned(name, fused_pw):
     """Projection BatchNorm weights x0.1 (residual branch small against the skip path, gain ~1): here the engine must
-    sit on the mirror tightly -- this is the test that pins the stage wiring (shared weights, residuals, stride-2)."""
+    sit on the mirror tightly -- this is the test that pins the stage wiring (shared weights, residuals, stride-2),
+    with the separate dgrad/wgrad kernels and with the fused 1x1 backward forced on."""
     m, prog, st, shp = _stage_setup(name, 0.1)
+    if fused_pw:
+        m._engine().pw_fused_min_pixels = 0
+        m._engine().pw_fused_all = True
     x0 = C.det_input(shp)
     x = x0.cuda().requires_grad_(True)
     y = m(x)
@@ -213,15 +218,23 @@ def test_stage_bit_reproducible(name):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("fused_pw", [False, True])
 @pytest.mark.parametrize("name", sorted(C.NETS))
-def test_net(name):
+def test_net(name, fused_pw):
+    """fused_pw=True forces the fused 1x1 backward (mnas_pw_bwd: input gradient + weight gradient + reduce in one sweep)
+    for every supported layer regardless of its pixel count; by default it only engages at >= 100k pixels (bench sizes)."""
     from mnasnet_pytorch_amd import Mnasnet
     g = load("nets")
     ccf, N, H, W, train, pg = C.NETS[name]
+    if fused_pw and (not train or pg == 1.0):
+        pytest.skip("the fused backward is compared on the well-conditioned training cases")
     m = Mnasnet(cut_channels_first=ccf)
     assert list(m.state_dict().keys()) == O.state_keys(ccf)
     m.load_state_dict(O.init_state(ccf, C.STATE_SEED, proj_gamma=pg))
     m = m.cuda().train(train)
+    if fused_pw:
+        m.features._engine().pw_fused_min_pixels = 0
+        m.features._engine().pw_fused_all = True
     x0 = C.det_input((N, 3, H, W))
     x = x0.cuda()
     prog, _ = O.build_program(ccf)
