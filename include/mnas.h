@@ -232,6 +232,14 @@ int mnas_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int HW
 #define MNAS_PACK_DGRAD 1   /* bf16 [Ci_pad16][Kpad32], k = tap*Co+co            (mnas_conv_gemm mode 1) */
 #define MNAS_PACK_DW    2   /* fp32 [k*k][C]                                      (mnas_dw_*)            */
 int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int kh, int kw, void* dst, void* stream);
+/* The same for many tensors in one launch: `descs` is a DEVICE array of n descriptors (taps = kh*kw; for MNAS_PACK_DW
+ * Ci is ignored).  Used once per forward for all layers of the network. */
+typedef struct MnasPackDesc {
+    const float* w;
+    void*   dst;
+    int32_t kind, Co, Ci, taps;
+} MnasPackDesc;
+int mnas_pack_weights_batch(const MnasPackDesc* descs, int n, void* stream);
 /* sizes in BYTES of the packed buffers */
 int64_t mnas_packed_bytes(int kind, int Co, int Ci, int kh, int kw);
 
@@ -257,6 +265,7 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_EVENT_RECORD 15    /* p[0] = event handle from mnas_event_create: hipEventRecord on the op's stream */
 #define MNAS_OP_EVENT_WAIT 16      /* p[0] = event handle: hipStreamWaitEvent(op's stream, event) */
 #define MNAS_OP_PW_BWD 17
+#define MNAS_OP_PACK_BATCH 18
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

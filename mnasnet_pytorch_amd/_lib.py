@@ -54,6 +54,11 @@ class MnasPwBwd(C.Structure):
                 ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p)]
 
 
+class MnasPackDesc(C.Structure):
+    _fields_ = [("w", c_void_p), ("dst", c_void_p), ("kind", C.c_int32), ("Co", C.c_int32), ("Ci", C.c_int32),
+                ("taps", C.c_int32)]
+
+
 class MnasStemFwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("Co", C.c_int32), ("nparts", C.c_int32), ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p),
@@ -71,7 +76,7 @@ class MnasOp(C.Structure):
 
 OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
-OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD = 12, 13, 14, 15, 16, 17
+OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
 PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
@@ -98,6 +103,7 @@ SYMBOLS = {
                              c_void_p]),
     "mnas_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mnas_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_pack_weights_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "mnas_packed_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "mnas_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),

@@ -21,6 +21,7 @@ extern "C" const char* mnas_arch(void) { return "gfx950"; }
 //  ADD_ACT          i: C,HW               d: rows                 p: a.data,a.scale,a.shift, b.data,b.scale,b.shift, out_bf16,out_nchw
 //  NCHW_TO_NHWC     i: N,C,HW                                     p: src,dst
 //  PACK_WEIGHTS     i: kind,Co,Ci,kh,kw                           p: w,dst
+//  PACK_BATCH       i: n                                          p: descs (device array of MnasPackDesc)
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -45,6 +46,8 @@ static int run_one(const MnasOp& o, void* stream) {
             a.partial = (float*)p[6];
             return mnas_conv_wgrad(&a, stream);
         }
+        case MNAS_OP_PACK_BATCH:
+            return mnas_pack_weights_batch((const MnasPackDesc*)p[0], i[0], stream);
         case MNAS_OP_PW_BWD: {
             MnasPwBwd a = {};
             a.M = i[0]; a.Ci = i[1]; a.Co = i[2]; a.nparts = i[3];

@@ -173,18 +173,24 @@ class Program:
             return t
 
         fwd = _OpList(eng, "fwd")
-        # ---- weight packing (once per forward; weights change every optimizer step)
+        # ---- weight packing (once per forward; weights change every optimizer step): one batched launch
+        descs = []
         for ci in eng.convs:
             w = ci.mod.conv.weight
             if ci.kind in ("pw", "dense"):
-                fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_FWD, ci.cout, ci.cin, ci.k, ci.k], [], [w.data_ptr(), ci.w_fwd.data_ptr()])
+                descs.append((w.data_ptr(), ci.w_fwd.data_ptr(), L.PACK_FWD, ci.cout, ci.cin, ci.k * ci.k))
                 if training:
-                    fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_DGRAD, ci.cout, ci.cin, ci.k, ci.k], [],
-                            [w.data_ptr(), ci.w_dgrad.data_ptr()])
+                    descs.append((w.data_ptr(), ci.w_dgrad.data_ptr(), L.PACK_DGRAD, ci.cout, ci.cin, ci.k * ci.k))
             elif ci.kind == "dw":
-                fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_DW, ci.cout, 1, ci.k, ci.k], [], [w.data_ptr(), ci.w_fwd.data_ptr()])
+                descs.append((w.data_ptr(), ci.w_fwd.data_ptr(), L.PACK_DW, ci.cout, 1, ci.k * ci.k))
             else:  # stem: [Co][27] viewed as a 1x1 conv over 27 "channels"
-                fwd.add(L.OP_PACK_WEIGHTS, [L.PACK_FWD, ci.cout, 27, 1, 1], [], [w.data_ptr(), ci.w_fwd.data_ptr()])
+                descs.append((w.data_ptr(), ci.w_fwd.data_ptr(), L.PACK_FWD, ci.cout, 27, 1))
+        host = (L.MnasPackDesc * len(descs))()
+        for n_, (wp, dp, kind, co, cin_, taps) in enumerate(descs):
+            host[n_].w, host[n_].dst, host[n_].kind, host[n_].Co, host[n_].Ci, host[n_].taps = wp, dp, kind, co, cin_, taps
+        raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
+        self.keep.append(raw)
+        fwd.add(L.OP_PACK_BATCH, [len(descs)], [], [raw.data_ptr()])
 
         steps = eng.steps
         first_kind = eng.info[id(steps[0][1] if steps[0][0] == "conv" else steps[0][1][0])].kind

@@ -546,3 +546,27 @@ def test_pw_bwd_rejects_unsupported():
     c = L.MnasPwBwd()
     c.M, c.Ci, c.Co, c.nparts = 64, 96, 576, 4
     assert lib.mnas_pw_bwd(C.byref(c), L.cur_stream()) == 10001          # MNAS_EINVAL
+
+
+def test_pack_weights_batch_matches_single():
+    """One batched launch packs what the per-tensor entry point packs (all three kinds, ragged shapes)."""
+    lib = L.load()
+    cases = [(L.PACK_FWD, 24, 16, 9), (L.PACK_DGRAD, 24, 16, 9), (L.PACK_FWD, 40, 240, 1), (L.PACK_DGRAD, 40, 240, 1),
+             (L.PACK_DW, 72, 1, 25), (L.PACK_FWD, 32, 27, 1)]
+    ws, singles, batched = [], [], []
+    host = (L.MnasPackDesc * len(cases))()
+    for n, (kind, Co, Ci, taps) in enumerate(cases):
+        k = int(round(taps ** 0.5))
+        shape = (Co, Ci, k, k) if k * k == taps else (Co, Ci, 1, taps)
+        w = O.det_uniform(shape, 50 + n).cuda().contiguous()
+        nbytes = lib.mnas_packed_bytes(kind, Co, Ci, 1, taps)
+        a = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        b = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+        L.check(lib.mnas_pack_weights(w.data_ptr(), kind, Co, Ci, 1, taps, a.data_ptr(), L.cur_stream()))
+        host[n].w, host[n].dst, host[n].kind, host[n].Co, host[n].Ci, host[n].taps = w.data_ptr(), b.data_ptr(), kind, Co, Ci, taps
+        ws.append(w); singles.append(a); batched.append(b)
+    dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    L.check(lib.mnas_pack_weights_batch(dev.data_ptr(), len(cases), L.cur_stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(singles, batched):
+        assert torch.equal(a, b)
