@@ -63,6 +63,65 @@ def conv_table(engine, N, H, W):
     return rows
 
 
+
+def class_key(opc, ints, L):
+    """Kernel-class name of one launch record (opcode + its integer fields)."""
+    names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_conv<fwd>", L.OP_DW_BWD: "k_dw_bwd",
+             L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
+             L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd"}
+    if opc == L.OP_CONV_GEMM:
+        return "k_igemm<dgrad>" if ints[0] == 1 else "k_igemm<fwd>"
+    if opc == L.OP_DW_BWD:          # i: N,H,W,C,k,nparts,phase (1 = input gradient, 2 = weight gradient launch)
+        return "k_dw_conv<dgrad>" if ints[6] == 1 else ("k_dw_wgrad" if ints[6] == 2 else "k_dw_bwd")
+    return names[opc]
+
+
+def launch_work(opc, ints, L):
+    """(algorithmic bytes, flops) of one launch: SURVEY 8(d) accounting -- each input and output tensor once, bf16."""
+    if opc == L.OP_CONV_GEMM:       # i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,...
+        _, N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:8]
+        e_in, e_out = N_ * Hi * Wi * Ci, N_ * Ho * Wo * Co
+        nbytes = 2 * ((2 * e_in + e_out) if ints[0] == 1 else (e_in + e_out))     # dgrad reads g AND y
+        flops = 2.0 * N_ * Ho * Wo * Co * Ci * ints[8] * ints[9] if ints[0] == 0 else \
+            2.0 * N_ * Hi * Wi * Ci * Co * ints[8] * ints[9]
+    elif opc == L.OP_PW_BWD:        # i: M,Ci,Co,nparts: reads g, y (Co) and x (Ci), writes gin (Ci)
+        M_, Ci, Co = ints[:3]
+        nbytes = 2 * M_ * (2 * Co + 2 * Ci)
+        flops = 2 * 2.0 * M_ * Co * Ci
+    elif opc == L.OP_CONV_WGRAD:    # i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw
+        N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:7]
+        nbytes = 2 * (N_ * Hi * Wi * Ci + 2 * N_ * Ho * Wo * Co)
+        flops = 2.0 * N_ * Ho * Wo * Co * Ci * ints[7] * ints[8]
+    elif opc in (L.OP_DW_FWD, L.OP_DW_BWD):
+        N_, H_, W_, C_, k_ = ints[:5]
+        e = N_ * H_ * W_ * C_
+        if opc == L.OP_DW_FWD:
+            nbytes, flops = 2 * 2 * e, 2.0 * e * k_ * k_
+        elif ints[6] == 0:
+            nbytes, flops = 2 * 4 * e, 4.0 * e * k_ * k_
+        else:       # each backward launch reads (g, y) and one more tensor / writes gin: 3 tensors
+            nbytes, flops = 2 * 3 * e, 2.0 * e * k_ * k_
+    elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT):
+        nbytes, flops = 0, 0.0      # pure overhead in SURVEY 8(d)'s accounting
+    else:                           # stem fwd / wgrad: fp32 image + bf16 output
+        N_, H_, W_, Ho, Wo, Co = ints[:6]
+        nbytes = N_ * 3 * H_ * W_ * 4 + 2 * N_ * Ho * Wo * Co * (1 if opc == L.OP_STEM_FWD else 2)
+        flops = 2.0 * N_ * Ho * Wo * Co * 27
+    return nbytes, flops
+
+
+def classify(profile, L):
+    """Aggregate engine.read_profile() records per kernel class: {key: [ms, bytes, flops, launches]} + per-launch detail."""
+    agg, detail = {}, []
+    for (tag, opc, ints), msv in profile:
+        key = class_key(opc, ints, L)
+        nbytes, flops = launch_work(opc, ints, L)
+        a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
+        a[0] += msv; a[1] += nbytes; a[2] += flops; a[3] += 1
+        detail.append((key, ints[:10], msv, nbytes))
+    return {"agg": agg, "detail": detail}
+
+
 def cpu_baseline(seconds):
     """The oracle's train step on the host cores (fp32, bs=32, head '512', Adam) -- kind 'port'."""
     from oracle import mnasnet_oracle as O
@@ -115,9 +174,8 @@ def main():
     if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
         eng.use_side_stream = False
     profile = (not args.no_roofline) and rank == 0
-    if profile:
-        eng.profile_opcodes = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE,
-                               L.OP_STEM_FWD, L.OP_STEM_WGRAD, L.OP_ADD_ACT, L.OP_PW_BWD}
+    ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
+               L.OP_ADD_ACT, L.OP_PW_BWD}
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size
@@ -133,9 +191,29 @@ def main():
     for _ in range(args.warmup):
         trainer.step(x, target)
     barrier()
+    # ---- roofline calibration (untimed, rank 0): bracket EVERY conv-kernel launch with HIP events for two steps, find the
+    # kernel class with the largest time, then bracket only that class inside the timed region (bracketing all ~190
+    # launches costs 7 % of the step rate; one class costs < 1 %)
+    calib, dom_key = None, None
+    if not args.no_roofline:                 # every rank runs the same extra steps (they contain collectives)
+        if profile:
+            eng.profile_opcodes = ALL_OPS
+            eng.reset_programs()
+        for _ in range(2):
+            trainer.step(x, target)
+        barrier()
+        if profile:
+            calib = classify(eng.read_profile(), L)
+            dom_key = max(calib["agg"].items(), key=lambda kv: kv[1][0])[0]
+            eng.profile_filter = lambda opc, ints: class_key(opc, ints, L) == dom_key
+            eng.reset_programs()
+        for _ in range(2):
+            trainer.step(x, target)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(x, target)
+    host_dt = time.perf_counter() - t0          # host-side enqueue time (no sync inside step)
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
@@ -155,77 +233,37 @@ def main():
     res = {
         "metric": "images/sec MNASNet-1.0 224^2 bf16 train step",
         "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes) fwd+bwd+Adam, "
                                "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (B, S, S),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss": round(lossv, 4)},
     }
-    # ---- roofline of the dominant kernel class ---------------------------------------------------
+    # ---- roofline of the dominant kernel class: events recorded inside the timed region (last timed step) -----------
     if profile:
-        names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_conv<fwd>", L.OP_DW_BWD: "k_dw_bwd",
-                 L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
-                 L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd"}
-        agg = {}
-        detail = []
-        for (tag, opc, ints), msv in eng.read_profile():
-            key = names[opc] + ("" if opc != L.OP_CONV_GEMM else ("<dgrad>" if ints[0] == 1 else "<fwd>"))
-            if opc == L.OP_DW_BWD:          # i: N,H,W,C,k,nparts,phase (1 = input gradient, 2 = weight gradient launch)
-                key = "k_dw_conv<dgrad>" if ints[6] == 1 else ("k_dw_wgrad" if ints[6] == 2 else "k_dw_bwd")
-            if opc == L.OP_CONV_GEMM:       # i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,...
-                _, N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:8]
-                e_in, e_out = N_ * Hi * Wi * Ci, N_ * Ho * Wo * Co
-                nbytes = 2 * ((2 * e_in + e_out) if ints[0] == 1 else (e_in + e_out))     # dgrad reads g AND y
-                flops = 2.0 * N_ * Ho * Wo * Co * Ci * ints[8] * ints[9] if ints[0] == 0 else \
-                    2.0 * N_ * Hi * Wi * Ci * Co * ints[8] * ints[9]
-            elif opc == L.OP_PW_BWD:        # i: M,Ci,Co,nparts: reads g, y (Co) and x (Ci), writes gin (Ci)
-                M_, Ci, Co = ints[:3]
-                nbytes = 2 * M_ * (2 * Co + 2 * Ci)
-                flops = 2 * 2.0 * M_ * Co * Ci
-            elif opc == L.OP_CONV_WGRAD:    # i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw
-                N_, Hi, Wi, Ci, Ho, Wo, Co = ints[:7]
-                nbytes = 2 * (N_ * Hi * Wi * Ci + 2 * N_ * Ho * Wo * Co)
-                flops = 2.0 * N_ * Ho * Wo * Co * Ci * ints[7] * ints[8]
-            elif opc in (L.OP_DW_FWD, L.OP_DW_BWD):
-                N_, H_, W_, C_, k_ = ints[:5]
-                e = N_ * H_ * W_ * C_
-                if opc == L.OP_DW_FWD:
-                    nbytes, flops = 2 * 2 * e, 2.0 * e * k_ * k_
-                elif ints[6] == 0:
-                    nbytes, flops = 2 * 4 * e, 4.0 * e * k_ * k_
-                else:       # each backward launch reads (g, y) and one more tensor / writes gin: 3 tensors
-                    nbytes, flops = 2 * 3 * e, 2.0 * e * k_ * k_
-            elif opc == L.OP_BN_BWD_REDUCE:
-                nbytes, flops = 0, 0.0     # pure overhead in SURVEY 8(d)'s accounting (reads g and y again)
-            elif opc == L.OP_ADD_ACT:
-                nbytes, flops = 0, 0.0
-            else:                           # stem fwd / wgrad: fp32 image + bf16 output
-                N_, H_, W_, Ho, Wo, Co = ints[:6]
-                nbytes = N_ * 3 * H_ * W_ * 4 + 2 * N_ * Ho * Wo * Co * (1 if opc == L.OP_STEM_FWD else 2)
-                flops = 2.0 * N_ * Ho * Wo * Co * 27
-            a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
-            a[0] += msv; a[1] += nbytes; a[2] += flops; a[3] += 1
-            detail.append((key, ints[:10], msv, nbytes))
-        # every step re-records the same event pairs, so what is read here is the LAST timed step
-        tot = sum(a[0] for a in agg.values())
-        name, (tms, nb, fl, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+        timed = classify(eng.read_profile(), L)
+        tms, nb, fl, cnt = timed["agg"][dom_key]
+        tot = sum(a[0] for a in calib["agg"].values())
         gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-        res["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        res["roofline"] = {"kernel": dom_key, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                            "launches_per_step": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
-                           "ms_per_step": round(tms, 3), "share_of_bracketed_time": round(tms / tot, 3),
-                           "note": "HIP events around every launch of this kernel class, last timed step; weight-gradient "
-                                   "kernels run on a second stream concurrently with the input-gradient chain, so a "
-                                   "launch's duration includes the bandwidth it shares with its neighbour"}
+                           "ms_per_step": round(tms, 3),
+                           "share_of_all_conv_kernel_time": round(calib["agg"][dom_key][0] / tot, 3),
+                           "note": "HIP events around every launch of this kernel class inside the timed region (last timed "
+                                   "step). Weight-gradient kernels run on a second stream concurrently with this chain, so a "
+                                   "launch's duration includes the bandwidth it shares with its neighbour; algorithmic bytes "
+                                   "per SURVEY 8(d) (inputs + outputs once, bf16)."}
         res["kernel_classes"] = {k: {"ms_per_step": round(v[0], 3), "algorithmic_GB": round(v[1] / 1e9, 3),
                                      "GBps": round(v[1] / max(v[0], 1e-9) / 1e6, 1), "TFLOP": round(v[2] / 1e12, 4),
                                      "TFLOPps": round(v[2] / max(v[0], 1e-9) / 1e9, 1), "launches": v[3]}
-                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+                                 for k, v in sorted(calib["agg"].items(), key=lambda kv: -kv[1][0])}
+        res["kernel_classes_note"] = "untimed calibration step with every conv-kernel launch bracketed (two streams overlapping)"
         res["bracketed_ms_per_step"] = round(tot, 3)
         if os.environ.get("MNAS_BENCH_DETAIL"):
-            for key, ints, msv, nb in detail:
+            for key, ints, msv, nb_ in calib["detail"]:
                 sys.stderr.write("%-18s %-48s %8.1f us %8.1f GB/s\n" % (key, ",".join(map(str, ints)), msv * 1e3,
-                                                                      nb / max(msv, 1e-9) / 1e6))
+                                                                      nb_ / max(msv, 1e-9) / 1e6))
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(res))

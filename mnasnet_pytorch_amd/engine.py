@@ -114,7 +114,8 @@ class _OpList:
 
     def add(self, opcode, ints=(), dbls=(), ptrs=(), stream=0):
         """stream: 0 = main (torch's current stream), 1 = the engine's side stream (weight-gradient work)"""
-        prof = self.eng is not None and self.eng.profile_opcodes and opcode in self.eng.profile_opcodes
+        prof = (self.eng is not None and self.eng.profile_opcodes and opcode in self.eng.profile_opcodes
+                and (self.eng.profile_filter is None or self.eng.profile_filter(opcode, tuple(ints))))
         if prof:
             ev0, ev1 = self.eng.new_event(), self.eng.new_event()
             self.items.append((L.OP_EVENT_RECORD, [], [], [ev0], stream))
@@ -555,6 +556,7 @@ class Engine:
         self.pw_fused_all = False          # tests: force the fused kernel for every supported shape
         self.side_stream = None
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
+        self.profile_filter = None       # optional predicate (opcode, ints) -> bool narrowing the bracketed launches
         self.profile_events = []         # [(tag, start_handle, stop_handle)]
 
     # ---- device state ---------------------------------------------------------------------------
@@ -617,6 +619,11 @@ class Engine:
         if self.lib is None or self.device != device or sig != self._sig:
             self._setup(device)
             self._sig = sig
+
+    def reset_programs(self):
+        """Drop the compiled launch lists (they embed the profiling brackets); rebuilt lazily on the next call."""
+        self.programs.clear()
+        self.profile_events = []
 
     def new_event(self):
         h = C.c_void_p()

@@ -94,6 +94,14 @@ def timeline_main(path, nlast):
     for k in ("<2us", "<5us", "<10us", "<50us", ">=50us"):
         if k in hist:
             print("# gaps %-6s n=%-5d total %.3f ms" % (k, hist[k][0], hist[k][1] / 1e6))
+    # dispatch sequence around the step boundary (the optimizer kernel): name, queue, start offset, duration
+    idx = [i for i, r in enumerate(rows) if r[2].startswith("k_adam")]
+    if idx:
+        i0 = idx[len(idx) // 2]
+        base = rows[i0][0]
+        print("# around a step boundary (us relative to k_adam start): queue start dur name")
+        for st, en, name, qq in rows[max(0, i0 - 6):i0 + 40]:
+            print("#   q%s %9.1f %8.1f  %s" % (qq, (st - base) / 1e3, (en - st) / 1e3, name[:70]))
     print("# largest gaps (us): after -> before")
     for g, a, b in sorted(gaps, key=lambda x: -x[0])[:25]:
         print("%9.1f  %s  ->  %s" % (g / 1e3, (a or "")[:60], (b or "")[:60]))
