@@ -121,6 +121,15 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < NOTH; ++j) acc_w[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // BatchNorm-backward partial sums: per lane in registers across all tiles when there are few cin tiles (one shuffle tree
+    // at the very end), per tile through LDS otherwise (15 cin tiles would need 120 registers)
+    constexpr bool REGSTAT = NTI <= 5;
+    float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
+#pragma unroll
+    for (int i = 0; i < (REGSTAT ? NTI : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rs1[i][r] = 0.f; rs2[i][r] = 0.f; }
+
     const int ntiles = (a.M + BP - 1) / BP;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tile0 = t * BP;
@@ -270,7 +279,11 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                         }
                     }
                 }
-                if (do_red) {
+                if (do_red && REGSTAT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { rs1[REGSTAT ? nt : 0][r] += d1[r]; rs2[REGSTAT ? nt : 0][r] += d2[r]; }
+                }
+                if (do_red && !REGSTAT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float x1 = d1[r], x2 = d2[r];
@@ -304,6 +317,20 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         }
     }
     if (do_red) {
+        if (REGSTAT) {
+#pragma unroll
+            for (int nt = 0; nt < (REGSTAT ? NTI : 1); ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x1 = rs1[nt][r], x2 = rs2[nt][r];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+                    if (l15 == 0) {
+                        lds_st[(wave * 2 + 0) * CIP + nt * 16 + lg * 4 + r] = x1;
+                        lds_st[(wave * 2 + 1) * CIP + nt * 16 + lg * 4 + r] = x2;
+                    }
+                }
+        }
         __syncthreads();
         for (int i = tid; i < 2 * CIP; i += 256) {
             const int r = i / CIP, c = i % CIP;
