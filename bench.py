@@ -173,8 +173,6 @@ def main():
     eng = trainer.engine
     if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
         eng.use_side_stream = False
-    if os.environ.get("MNAS_PW_ALL"):        # diagnosis only: fused 1x1 backward for every supported shape
-        eng.pw_fused_all = True
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
                L.OP_ADD_ACT, L.OP_PW_BWD}

@@ -67,6 +67,10 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     const int l15 = lane & 15, lg = lane >> 4;
     const bool hasx = a.x.scale != nullptr;
     const bool do_red = a.red_partial != nullptr;
+    // wide inputs (Ci > NTI*16) are cut into channel slices over grid.y: a workgroup stages the whole dy tile but only its
+    // slice of x, and produces that slice of gin / dW / the reduce (dy is the narrow tensor for these layers)
+    const int ci0 = blockIdx.y * CIP;
+    const int cis = min(CIP, a.Ci - ci0);                    // valid channels of this slice (multiple of 8)
 
     // ---- one-time setup: coefficient tables, resident weights, zeroed tiles / statistics
     for (int i = tid; i < 5 * COP; i += 256) {
@@ -75,16 +79,17 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     }
     for (int i = tid; i < 2 * CIP; i += 256) {
         const int r = i / CIP, c = i % CIP;
-        lds_cx[i] = (hasx && c < a.Ci) ? (r == 0 ? a.x.scale[c] : a.x.shift[c]) : 0.f;
+        lds_cx[i] = (hasx && c < cis) ? (r == 0 ? a.x.scale[ci0 + c] : a.x.shift[ci0 + c]) : 0.f;
     }
     for (int i = tid; i < 4 * CIP; i += 256) {
         const int r = i / CIP, c = i % CIP;
         float v = 0.f;
-        if (do_red && c < a.Ci) {
-            if (r == 0) v = a.red_bn[0 * a.Ci + c];
-            else if (r == 1) v = a.red_bn[1 * a.Ci + c];
-            else if (r == 2) v = a.red_bn[6 * a.Ci + c];
-            else v = -a.red_bn[5 * a.Ci + c] * a.red_bn[6 * a.Ci + c];
+        if (do_red && c < cis) {
+            const int cg = ci0 + c;
+            if (r == 0) v = a.red_bn[0 * a.Ci + cg];
+            else if (r == 1) v = a.red_bn[1 * a.Ci + cg];
+            else if (r == 2) v = a.red_bn[6 * a.Ci + cg];
+            else v = -a.red_bn[5 * a.Ci + cg] * a.red_bn[6 * a.Ci + cg];
         }
         lds_rc[i] = v;
     }
@@ -93,14 +98,14 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         const int kc8n = a.Kd >> 3;
         for (int q = tid; q < CIP * kc8n; q += 256) {
             const int r = q / kc8n, kc8 = q - r * kc8n;
-            *(uint4*)(lds_w + r * ldw + kc8 * 8) = *(const uint4*)(a.w + (size_t)r * a.Kd + kc8 * 8);
+            *(uint4*)(lds_w + r * ldw + kc8 * 8) = *(const uint4*)(a.w + (size_t)(ci0 + r) * a.Kd + kc8 * 8);
         }
         const int nz = (BP * ldd + BP * lda) / 8;            // both tiles are contiguous; row strides are multiples of 8
         for (int i = tid; i < nz; i += 256) ((uint4*)tile_d)[i] = make_uint4(0, 0, 0, 0);
     }
 
     // ---- staging plan (tile-invariant): slot -> (pixel in tile, 16-byte channel chunk)
-    const int cwd = a.Co >> 3, cwa = a.Ci >> 3;
+    const int cwd = a.Co >> 3, cwa = cis >> 3;
     int pd[ND], cd8[ND], pa[NX], ca8[NX];
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         for (int i = 0; i < NX; ++i) {
             vx[i] = make_uint4(0, 0, 0, 0);
             if (pa[i] >= 0 && tile0 + pa[i] < a.M)
-                vx[i] = *(const uint4*)((const uint16_t*)a.x.data + (size_t)(tile0 + pa[i]) * a.Ci + ca8[i] * 8);
+                vx[i] = *(const uint4*)((const uint16_t*)a.x.data + (size_t)(tile0 + pa[i]) * a.Ci + ci0 + ca8[i] * 8);
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             for (int nt = 0; nt < NTI; ++nt) {
                 const int ci = nt * 16 + lg * 4;
                 ypre[pt][nt] = make_uint2(0, 0); rpre[pt][nt] = make_uint2(0, 0);
-                if (m < a.M && ci < a.Ci) {
-                    const size_t o = (size_t)m * a.Ci + ci;
+                if (m < a.M && ci < cis) {
+                    const size_t o = (size_t)m * a.Ci + ci0 + ci;
                     if (do_red) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + o);
                     if (a.resid) rpre[pt][nt] = *(const uint2*)((const uint16_t*)a.resid + o);
                 }
@@ -249,11 +254,11 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTI; ++nt) {
                 const int ci = nt * 16 + lg * 4;
-                const bool ok = mok && ci < a.Ci;
+                const bool ok = mok && ci < cis;
                 float v[4] = {acc_g[pt][nt][0], acc_g[pt][nt][1], acc_g[pt][nt][2], acc_g[pt][nt][3]};
                 float d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
                 if (ok) {
-                    const size_t o = (size_t)m * a.Ci + ci;
+                    const size_t o = (size_t)m * a.Ci + ci0 + ci;
                     if (a.resid) {
                         const uint2 rv = rpre[pt][nt];
                         v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = to * 16 + lg * 4 + r;
-                if (co < a.Co && ci < a.Ci) wp[(size_t)co * a.Ci + ci] = acc_w[i][j][r];
+                if (co < a.Co && ci < cis) wp[(size_t)co * a.Ci + ci0 + ci] = acc_w[i][j][r];
             }
         }
     }
@@ -336,18 +341,18 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             const int r = i / CIP, c = i % CIP;
             const float v = ((lds_st[(0 * 2 + r) * CIP + c] + lds_st[(1 * 2 + r) * CIP + c]) + lds_st[(2 * 2 + r) * CIP + c]) +
                             lds_st[(3 * 2 + r) * CIP + c];
-            if (c < a.Ci) a.red_partial[((size_t)r * a.Ci + c) * gridDim.x + blockIdx.x] = v;   // [2][Ci][P]
+            if (c < cis) a.red_partial[((size_t)r * a.Ci + ci0 + c) * gridDim.x + blockIdx.x] = v;   // [2][Ci][P]
         }
     }
 }
 
 template <int NTO, int NTI, int PT>
-static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream) {
+static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int nslices = 1) {
     constexpr int BP = 64 * PT, COP = NTO * 16, CIP = NTI * 16;
     const size_t lds = (size_t)(5 * COP + 14 * CIP) * sizeof(float) +
                        ((size_t)CIP * (a.Kd + 8) + (size_t)BP * (a.Kd + 8) + (size_t)BP * (CIP + 8)) * 2;
     if (lds > 160 * 1024) return MNAS_EINVAL;
-    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT>), dim3(nparts), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT>), dim3(nparts, nslices), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -373,7 +378,8 @@ extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     const int nto = (c->Co + 15) / 16, nti = (c->Ci + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_PWB(O_, I_, P_) if (nto == O_ && nti == I_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s);
-    MNAS_PWB(1, 2, 2) MNAS_PWB(1, 3, 2) MNAS_PWB(3, 1, 2) MNAS_PWB(5, 2, 2) MNAS_PWB(2, 5, 2) MNAS_PWB(15, 3, 1) MNAS_PWB(3, 15, 1)
+    MNAS_PWB(1, 2, 2) MNAS_PWB(1, 3, 2) MNAS_PWB(3, 1, 2) MNAS_PWB(5, 2, 2) MNAS_PWB(2, 5, 2) MNAS_PWB(15, 3, 1)
 #undef MNAS_PWB
+    if (nto == 3 && nti == 15) return launch_pw_bwd<3, 5, 1>(a, c->nparts, s, 3);     // 240 -> 40: three 80-channel slices
     return MNAS_EINVAL;
 }

@@ -339,8 +339,7 @@ class Program:
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
                     ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
-            elif (ci.kind == "pw" and need_gin and M >= eng.pw_fused_min_pixels and lib.mnas_pw_bwd_supported(ci.cin, Co)
-                  and (eng.pw_fused_all or ci.cin <= 80)):
+            elif ci.kind == "pw" and need_gin and M >= eng.pw_fused_min_pixels and lib.mnas_pw_bwd_supported(ci.cin, Co):
                 # large-pixel-count 1x1 conv: ONE sweep produces the input gradient, the weight-gradient partials and the
                 # fused reduce (both former kernels stream the same g, y; see csrc/mnas_pwbwd.hip).  Main stream.
                 gin = new((N, Hi, Wi, ci.cin))
@@ -549,12 +548,10 @@ class Engine:
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
         self.dw_fused_k = (3,)           # depthwise kernel sizes whose backward runs as ONE fused sweep
-        # 1x1 convs with at least this many pixels and <= 80 input channels use the fused backward (mnas_pw_bwd): measured
-        # per launch at bs 256 against the dgrad + wgrad pair: 204 vs 399 us (16->48 @112^2), 241 vs 331 (48->16), 118 vs 285
-        # (32->16), 90 vs 199 (24->72 @56^2), 106 vs 195 (72->24), 81 vs 141 (40->240 @28^2); 240->40 stays two kernels
-        # (320 vs 175 us: 15 cin tiles need the per-tile statistics path and 90 KB of LDS)
+        # 1x1 convs with at least this many pixels use the fused backward (mnas_pw_bwd) when the shape is supported: measured
+        # per launch at bs 256 against the dgrad + wgrad pair: 201 vs 399 us (16->48 @112^2), 233 vs 331 (48->16), 119 vs 285
+        # (32->16), 90 vs 199 (24->72 @56^2), 105 vs 195 (72->24), 81 vs 141 (40->240 @28^2), 111 vs 175 (240->40)
         self.pw_fused_min_pixels = 100000
-        self.pw_fused_all = False          # tests: force the fused kernel for every supported shape
         self.side_stream = None
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_filter = None       # optional predicate (opcode, ints) -> bool narrowing the bracketed launches

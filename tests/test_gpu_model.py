@@ -184,7 +184,6 @@ def test_stage_well_conditioned(name, fused_pw):
     m, prog, st, shp = _stage_setup(name, 0.1)
     if fused_pw:
         m._engine().pw_fused_min_pixels = 0
-        m._engine().pw_fused_all = True
     x0 = C.det_input(shp)
     x = x0.cuda().requires_grad_(True)
     y = m(x)
@@ -234,7 +233,6 @@ def test_net(name, fused_pw):
     m = m.cuda().train(train)
     if fused_pw:
         m.features._engine().pw_fused_min_pixels = 0
-        m.features._engine().pw_fused_all = True
     x0 = C.det_input((N, 3, H, W))
     x = x0.cuda()
     prog, _ = O.build_program(ccf)
