@@ -122,6 +122,22 @@ def classify(profile, L):
     return {"agg": agg, "detail": detail}
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the newest committed PMC summary (profiles/*_pmc_per_class.json, made by
+    tools/profile_round.sh + tools/pmc_classes.py: FETCH_SIZE x2 + WRITE_SIZE in separate --pmc passes of this bench).
+    Counters cannot be collected from inside a timed run; None if no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_per_class.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return round(d["classes"][kernel_class]["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def cpu_baseline(seconds):
     """The oracle's train step on the host cores (fp32, bs=32, head '512', Adam) -- kind 'port'."""
     from oracle import mnasnet_oracle as O
@@ -245,8 +261,10 @@ def main():
         tms, nb, fl, cnt = timed["agg"][dom_key]
         tot = sum(a[0] for a in calib["agg"].values())
         gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dom_key)
         res["roofline"] = {"kernel": dom_key, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                           "algorithmic_bytes_per_launch": round(nb / cnt),
                            "launches_per_step": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
                            "ms_per_step": round(tms, 3),
                            "share_of_all_conv_kernel_time": round(calib["agg"][dom_key][0] / tot, 3),
