@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 
     // BatchNorm-backward partial sums: per lane in registers across all tiles when there are few cin tiles (one shuffle tree
     // at the very end), per tile through LDS otherwise (15 cin tiles would need 120 registers)
-    constexpr bool REGSTAT = NTI <= 5;
+    constexpr bool REGSTAT = NTI <= 6;
     float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
 #pragma unroll
     for (int i = 0; i < (REGSTAT ? NTI : 1); ++i)
@@ -357,15 +357,21 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
     return MNAS_OK;
 }
 
-// Supported (cout tiles, cin tiles): the pointwise convs of the 112x112 / 56x56 / 28x28 stages of MNASNet-1.0
-// (16<->32/48, 24<->72, 40<->240 channels).  Other shapes: MNAS_EINVAL (use mnas_conv_gemm + mnas_conv_wgrad).
-extern "C" int mnas_pw_bwd_supported(int Ci, int Co) {
-    if ((Ci & 7) || (Co & 7) || Ci < 8 || Co < 8) return 0;
+// Supported channel pairs: the pointwise convs of the 112x112 / 56x56 / 28x28 stages of MNASNet-1.0 (16<->32/48, 24<->72,
+// 40<->240 channels) and the narrowing convs of the 14x14 stage (480->80, 576->96; channel slices).  Other shapes:
+// MNAS_EINVAL (use mnas_conv_gemm + mnas_conv_wgrad).
+struct PwCfg { int nto, nti_total, nti_slice, nslices, pt; };
+static const PwCfg* pw_cfg(int Ci, int Co) {
+    if ((Ci & 7) || (Co & 7) || Ci < 8 || Co < 8) return nullptr;
     const int nto = (Co + 15) / 16, nti = (Ci + 15) / 16;
-    static const int ok[][2] = {{1, 2}, {1, 3}, {3, 1}, {5, 2}, {2, 5}, {15, 3}, {3, 15}};
-    for (auto& p : ok) if (p[0] == nto && p[1] == nti) return 1;
-    return 0;
+    static const PwCfg cfgs[] = {{1, 2, 2, 1, 2}, {1, 3, 3, 1, 2}, {3, 1, 1, 1, 2}, {5, 2, 2, 1, 2}, {2, 5, 5, 1, 2}, {15, 3, 3, 1, 1},
+                                 {3, 15, 5, 3, 1},      // 240 -> 40: three 80-channel slices
+                                 {5, 30, 5, 6, 1},      // 480 -> 80: six 80-channel slices
+                                 {6, 36, 6, 6, 1}};     // 576 -> 96: six 96-channel slices
+    for (auto& c : cfgs) if (c.nto == nto && c.nti_total == nti) return &c;
+    return nullptr;
 }
+extern "C" int mnas_pw_bwd_supported(int Ci, int Co) { return pw_cfg(Ci, Co) ? 1 : 0; }
 
 extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     if (!c || c->M < 1 || c->nparts < 1 || c->nparts > 65535 || !mnas_pw_bwd_supported(c->Ci, c->Co)) return MNAS_EINVAL;
@@ -375,11 +381,11 @@ extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     a.M = c->M; a.Ci = c->Ci; a.Co = c->Co; a.Kd = (c->Co + 31) / 32 * 32;
     a.x = c->x; a.dy = c->dy; a.w = (const uint16_t*)c->w; a.resid = c->resid; a.gin = c->gin;
     a.wpartial = c->wpartial; a.red_partial = c->red_partial; a.red_y = c->red_y; a.red_bn = c->red_bn;
-    const int nto = (c->Co + 15) / 16, nti = (c->Ci + 15) / 16;
+    const PwCfg* cfg = pw_cfg(c->Ci, c->Co);
     hipStream_t s = (hipStream_t)stream;
-#define MNAS_PWB(O_, I_, P_) if (nto == O_ && nti == I_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s);
+#define MNAS_PWB(O_, I_, P_) if (cfg->nto == O_ && cfg->nti_slice == I_ && cfg->pt == P_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s, cfg->nslices);
     MNAS_PWB(1, 2, 2) MNAS_PWB(1, 3, 2) MNAS_PWB(3, 1, 2) MNAS_PWB(5, 2, 2) MNAS_PWB(2, 5, 2) MNAS_PWB(15, 3, 1)
+    MNAS_PWB(3, 5, 1) MNAS_PWB(5, 5, 1) MNAS_PWB(6, 6, 1)
 #undef MNAS_PWB
-    if (nto == 3 && nti == 15) return launch_pw_bwd<3, 5, 1>(a, c->nparts, s, 3);     // 240 -> 40: three 80-channel slices
     return MNAS_EINVAL;
 }

@@ -490,7 +490,7 @@ def test_wgrad_finalize_split_ranges(nsplit, Co, Ci, taps, acc):
 # fused 1x1 backward (input gradient + weight gradient + BatchNorm-backward reduce of x's producer)
 PWB = [  # N,H,W,Ci,Co  -- every supported (cin tiles, cout tiles) pair; ragged pixel counts (tile tails)
     (2, 12, 12, 32, 16), (3, 11, 9, 48, 16), (2, 13, 12, 16, 48), (2, 9, 9, 24, 72), (2, 10, 9, 72, 24),
-    (1, 9, 8, 40, 240), (1, 11, 7, 240, 40),
+    (1, 9, 8, 40, 240), (1, 11, 7, 240, 40), (1, 9, 7, 480, 80), (1, 10, 7, 576, 96),
 ]
 
 
@@ -543,6 +543,7 @@ def test_pw_bwd_fused(shape, variant, nparts):
 def test_pw_bwd_rejects_unsupported():
     lib = L.load()
     assert lib.mnas_pw_bwd_supported(96, 576) == 0 and lib.mnas_pw_bwd_supported(12, 16) == 0
+    assert lib.mnas_pw_bwd_supported(576, 96) == 1 and lib.mnas_pw_bwd_supported(480, 80) == 1
     c = L.MnasPwBwd()
     c.M, c.Ci, c.Co, c.nparts = 64, 96, 576, 4
     assert lib.mnas_pw_bwd(C.byref(c), L.cur_stream()) == 10001          # MNAS_EINVAL
