@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (no sparsity), MI355X_MICROARCH.md
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
 
 
@@ -40,6 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--hw", type=str, default="", help="rectangular input HxW (BASELINE config 5 clusters: 384x512, 512x512, "
+                                                       "512x384); overrides --size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -195,7 +198,8 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size
-    x = torch.randn(B, 3, S, S, device=dev, generator=g)
+    Hh, Ww = (int(v) for v in args.hw.lower().split("x")) if args.hw else (S, S)
+    x = torch.randn(B, 3, Hh, Ww, device=dev, generator=g)
     target = torch.randint(0, 1000, (B,), device=dev, generator=g)
 
     def barrier():
@@ -252,7 +256,7 @@ def main():
         "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes) fwd+bwd+Adam, "
-                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (B, S, S),
+                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (B, Hh, Ww),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss": round(lossv, 4)},
     }
     # ---- roofline of the dominant kernel class: events recorded inside the timed region (last timed step) -----------
@@ -273,10 +277,14 @@ def main():
                                    "launch's duration includes the bandwidth it shares with its neighbour; algorithmic bytes "
                                    "per SURVEY 8(d) (inputs + outputs once, bf16)."}
         res["kernel_classes"] = {k: {"ms_per_step": round(v[0], 3), "algorithmic_GB": round(v[1] / 1e9, 3),
-                                     "GBps": round(v[1] / max(v[0], 1e-9) / 1e6, 1), "TFLOP": round(v[2] / 1e12, 4),
-                                     "TFLOPps": round(v[2] / max(v[0], 1e-9) / 1e9, 1), "launches": v[3]}
+                                     "GBps": round(v[1] / max(v[0], 1e-9) / 1e6, 1),
+                                     "hbm_frac": round(v[1] / max(v[0], 1e-9) / 1e6 / HBM_PEAK_GBS, 3),
+                                     "TFLOP": round(v[2] / 1e12, 4), "TFLOPps": round(v[2] / max(v[0], 1e-9) / 1e9, 1),
+                                     "mfma_frac": round(v[2] / max(v[0], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS, 4), "launches": v[3]}
                                  for k, v in sorted(calib["agg"].items(), key=lambda kv: -kv[1][0])}
-        res["kernel_classes_note"] = "untimed calibration step with every conv-kernel launch bracketed (two streams overlapping)"
+        res["kernel_classes_note"] = ("untimed calibration step with every conv-kernel launch bracketed (two streams overlapping); "
+                                      "hbm_frac = algorithmic GB/s / 8 TB/s, mfma_frac = algorithmic TFLOP/s / 2500 (dense bf16): every "
+                                      "class is HBM-bound unfused (SURVEY 8(d)), mfma_frac is reported for completeness")
         res["bracketed_ms_per_step"] = round(tot, 3)
         if os.environ.get("MNAS_BENCH_DETAIL"):
             for key, ints, msv, nb_ in calib["detail"]:

@@ -280,6 +280,17 @@ int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_at);
  * kernels of a layer concurrently with the input-gradient chain (they only share read-only inputs). */
 int mnas_run_ops_multi(const MnasOp* ops, int n, void* const* streams, int nstreams, int* failed_at);
 
+/* ---- scratch sizes (bytes) of the partial tables the launches above write; the library never allocates.
+ * kind MNAS_WS_CONV_STATS:  float[2][c][n]      (c = Co, n = nparts; also the fused-reduce tables)
+ * kind MNAS_WS_CONV_WGRAD:  float[n][c][k]      (n = nsplit, c = Co, k = kh*kw*Ci)
+ * kind MNAS_WS_PW_BWD:      float[n][c][k]      (n = nparts, c = Co, k = Ci)
+ * kind MNAS_WS_DW_WGRAD:    float[n][k][c]      (n = mnas_dw_rows(...), k = taps, c = C) */
+#define MNAS_WS_CONV_STATS 0
+#define MNAS_WS_CONV_WGRAD 1
+#define MNAS_WS_PW_BWD 2
+#define MNAS_WS_DW_WGRAD 3
+int64_t mnas_workspace_bytes(int kind, int n, int c, int k);
+
 /* ---- HIP events on the launch stream (measurement only: bench.py brackets single kernel launches inside
  * the timed region; torch.cuda.Event cannot be recorded from inside mnas_run_ops) ------------------------ */
 int mnas_event_create(void** event);

@@ -83,6 +83,7 @@ PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
 SYMBOLS = {
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),
+    "mnas_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "mnas_conv_gemm": (c_int, [C.POINTER(MnasConvGemm), c_void_p]),
     "mnas_conv_wgrad": (c_int, [C.POINTER(MnasConvWgrad), c_void_p]),
     "mnas_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -5,6 +5,17 @@
 extern "C" int mnas_version(void) { return 1; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 
+extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
+    if (n < 1 || c < 1) return -1;
+    switch (kind) {
+        case MNAS_WS_CONV_STATS: return (int64_t)2 * c * n * sizeof(float);
+        case MNAS_WS_CONV_WGRAD:
+        case MNAS_WS_PW_BWD:
+        case MNAS_WS_DW_WGRAD:   return k < 1 ? -1 : (int64_t)n * c * k * sizeof(float);
+        default: return -1;
+    }
+}
+
 // Field use per opcode (i = op.i, d = op.d, p = op.p):
 //  CONV_GEMM        i: mode,N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw,stride,pad,nparts
 //                   p: act.data,act.scale,act.shift, grad.g,grad.y,grad.coef, w,bias,resid,out,stats, red_y,red_bn

@@ -28,6 +28,11 @@ def test_library_exports_every_declared_symbol():
     assert lib.mnas_packed_bytes(_lib.PACK_FWD, 48, 16, 1, 1) == 48 * 32 * 2
     assert lib.mnas_packed_bytes(_lib.PACK_DGRAD, 48, 16, 1, 1) == 16 * 64 * 2
     assert lib.mnas_packed_bytes(_lib.PACK_DW, 72, 1, 5, 5) == 25 * 72 * 4
+    assert lib.mnas_workspace_bytes(0, 1024, 48, 0) == 2 * 48 * 1024 * 4        # conv statistics table
+    assert lib.mnas_workspace_bytes(2, 512, 240, 40) == 512 * 240 * 40 * 4      # fused 1x1 backward slabs
+    assert lib.mnas_workspace_bytes(9, 1, 1, 1) == -1
+    assert lib.mnas_pw_bwd_supported(48, 16) == 1 and lib.mnas_pw_bwd_supported(96, 576) == 0   # host-side query
+    assert ctypes.sizeof(_lib.MnasPackDesc) == 32
 
 
 def test_opcode_constants_match_header():
