@@ -1,6 +1,6 @@
 """Execution engine: compiles a subtree of the drop-in modules (mnasnet.py) into a static PROGRAM of HIP
 kernel launches (include/mnas.h) per (batch, height, width, mode) and runs it with ONE host->library call
-per forward / per backward segment (mnas_run_ops).
+per forward / per backward segment (mnas_run_ops_multi: main stream + a side stream for weight-gradient kernels).
 
 Mirrors, for this path, what autograd + ATen do for the reference:
     forward   Mnasnet.features(x)                /root/reference/src/models/mnasnet.py:211-213

@@ -1,4 +1,6 @@
-"""Micro-benchmark of mnas_pw_bwd vs the separate dgrad + wgrad kernels at bench sizes (prints us per launch)."""
+"""Micro-benchmark of mnas_pw_bwd at bench sizes (prints us per launch).  CAUTION: it re-runs one launch on the same
+buffers, so up to 256 MB of them stay in the Infinity Cache between iterations -- the numbers are 20-40 % better than
+in the training step (use MNAS_NO_SIDE=1 MNAS_BENCH_DETAIL=1 python bench.py for in-situ times).  Good for A/B only."""
 import ctypes as C, sys, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from mnasnet_pytorch_amd import _lib as L
