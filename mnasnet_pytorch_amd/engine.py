@@ -547,7 +547,10 @@ class Engine:
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
-        self.dw_fused_k = (3,)           # depthwise kernel sizes whose backward runs as ONE fused sweep
+        # depthwise kernel sizes whose backward runs as ONE fused sweep (input gradient + weight gradient + reduce).  5x5 too:
+        # with 2-row DMA groups the fused form gets full-width strips and beats the two launches (155 vs 210 us at 56x56)
+        # although it needs all 256 VGPRs; (3,) selects the split form (input gradient on main, weight gradient on side)
+        self.dw_fused_k = (3, 5)
         # 1x1 convs with at least this many pixels use the fused backward (mnas_pw_bwd) when the shape is supported: measured
         # per launch at bs 256 against the dgrad + wgrad pair: 201 vs 399 us (16->48 @112^2), 233 vs 331 (48->16), 119 vs 285
         # (32->16), 90 vs 199 (24->72 @56^2), 105 vs 195 (72->24), 81 vs 141 (40->240 @28^2), 111 vs 175 (240->40)

@@ -94,14 +94,19 @@ def test_convblock(name, train):
     assert int(m.bn.num_batches_tracked) == int(g[tag + "/bn.num_batches_tracked"])
 
 
+@pytest.mark.parametrize("dw_split", [False, True])
 @pytest.mark.parametrize("name", sorted(C.BLOCKS))
-def test_block(name):
+def test_block(name, dw_split):
+    """dw_split=True runs the depthwise backward as two launches (input gradient on the main stream, weight gradient on
+    the side stream) instead of the default fused sweep."""
     from mnasnet_pytorch_amd import MBConv_block
     g = load("blocks")
     c, t, k, N, H, W = C.BLOCKS[name]
     m = MBConv_block(c, t, k)
     fill(m, name)
     m = m.cuda().train()
+    if dw_split:
+        m._engine().dw_fused_k = ()
     x0 = C.det_input((N, c, H, W))
     x = x0.cuda().requires_grad_(True)
     y = m(x)
