@@ -20,9 +20,10 @@
 //   * BatchNorm partial statistics (forward), the fused BatchNorm-backward reduction of the producer of x and the
 //     k*k weight-gradient sums (backward) are accumulated in registers over the whole sweep and written once
 //     per workgroup (no atomics in HBM, deterministic);
-//   * backward is ONE launch for 3x3 (input gradient + weight gradient + reduce from the same three rings); the engine
-//     uses two launches for 5x5 (the fused form needs 2*k*k*2 persistent accumulators on top of the two register rings
-//     and spills: measured 25.5 vs 23.0 ms/step).
+//   * backward is ONE launch (phase 0: input gradient + weight gradient + reduce from the same three rings) for both
+//     kernel sizes; the 5x5 form holds 2*k*k*2 persistent accumulators on top of two register rings (256 VGPRs, 12
+//     spilled) and still beats the two-launch form (phase 1 + phase 2, kept for callers that want the weight gradient
+//     on another stream) once 2-row DMA groups give it full-width strips: 155 vs 118 + 92 us at 56x56x72, bs 256.
 // Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5 forward; backward moves 4 tensors for 2x the FMAs).
 #include "mnas_common.h"
 
