@@ -55,6 +55,15 @@ __device__ __forceinline__ void dy8(const uint4& graw, const uint4& yraw, const 
     }
 }
 
+// Barrier that PUBLISHES LDS-DMA data (global_load_lds): every wave first waits for its own outstanding DMA (vmcnt(0)),
+// then joins the barrier.  A bare __syncthreads() is not enough: hipcc only inserts the vmcnt wait in front of the wave's
+// own first LDS read AFTER the barrier, so a wave could read chunks whose DMA -- issued by ANOTHER wave -- had not landed
+// yet (seen as run-to-run differences / NaNs from stale LDS at full problem sizes, never in small tests).
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

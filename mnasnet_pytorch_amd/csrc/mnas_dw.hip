@@ -262,13 +262,13 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
 
         // Every input row is read from LDS exactly once (the vertical window lives in the register ring A), so the 8 ring
         // rows are two buffers of G = 4: the DMA of group s+1 is in flight while group s is computed.  One barrier per
-        // step: it publishes group s (hipcc drains vmcnt before s_barrier) and retires the readers of group s-1, whose
+        // step (dma_barrier: vmcnt(0) then s_barrier): it publishes group s and retires the readers of group s-1, whose
         // buffer the next DMA overwrites.
         __syncthreads();                             // previous item's last group consumed
         dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
-            __syncthreads();
+            dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
             if (s + 1 < nsteps) dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, r0 + G, x0, c0, wave, nwaves);
             if (!active) continue;
 #pragma unroll 1
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
         load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
-            __syncthreads();
+            dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
             if constexpr (REDG) {
 #pragma unroll
                 for (int j = 0; j < G; ++j)
