@@ -325,6 +325,61 @@ def test_net(name, fused_pw):
             assert abs(float(v.abs().sum()) - g[kk][1]) <= 5e-2 * g[kk][1], kk
 
 
+def test_net_full_size_bit_reproducible():
+    """Whole network at the bench resolution (bs 128, 224x224): three forward+backward passes on the same inputs give
+    bit-identical outputs and parameter gradients.  Any race between workgroups (LDS-DMA publication, cross-stream
+    ordering, partial-table reuse) shows up here as a difference; small shapes do not expose them."""
+    from mnasnet_pytorch_amd import Mnasnet
+    m = Mnasnet(cut_channels_first=False)
+    m.load_state_dict(O.init_state(False, C.STATE_SEED, proj_gamma=0.1))
+    m = m.cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(128, 3, 224, 224, device="cuda", generator=g)
+    snaps = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        y.square().mean().backward()
+        torch.cuda.synchronize()
+        snaps.append([y.detach().clone()] + [p.grad.clone() for p in m.parameters()])
+    names = ["y"] + [kk for kk, _ in m.named_parameters()]
+    for other in snaps[1:]:
+        for nm, a, b in zip(names, snaps[0], other):
+            assert torch.equal(a, b), nm
+            assert torch.isfinite(a).all(), nm
+
+
+def test_net_full_size_vs_mirror():
+    """Whole network (ccf=False, well-conditioned state) at 224x224 with batch 32 against the bf16 mirror on the host cores
+    (about a minute): the stem, all six stages at their real spatial sizes, the 7x7 stage and the stage-to-stage wiring."""
+    from mnasnet_pytorch_amd import Mnasnet
+    m = Mnasnet(cut_channels_first=False)
+    m.load_state_dict(O.init_state(False, C.STATE_SEED, proj_gamma=0.1))
+    m = m.cuda().train()
+    x0 = C.det_input((32, 3, 224, 224))
+    y = m(x0.cuda())
+    cot = C.cotangent(tuple(y.shape))
+    (y * cot.cuda()).sum().backward()
+    y_ = y.detach().cpu()
+    grads = {kk: p.grad.cpu() for kk, p in m.named_parameters()}
+    del y
+    torch.cuda.empty_cache()
+    prog, _ = O.build_program(False)
+    st = O.init_state(False, C.STATE_SEED, proj_gamma=0.1)
+    r = M.run(prog, st, x0, True, cot)
+    e_y = rl2(y_, r["y"])
+    coss = []
+    for kk, gv in grads.items():
+        if kk.endswith("conv.bias"):
+            continue
+        a, b = gv.double().flatten(), r["grads"][kk].double().flatten()
+        coss.append(float((a @ b) / (a.norm() * b.norm() + 1e-30)))
+        assert 0.5 < float(a.norm() / b.norm()) < 2.0, kk
+    print("full-size net: y vs mirror %.4f, grad cosine min %.4f median %.4f" % (e_y, min(coss), float(np.median(coss))))
+    assert e_y < 3e-2
+    assert min(coss) > 0.8 and np.median(coss) > 0.95
+
+
 def test_no_cpu_fallback():
     from mnasnet_pytorch_amd import Mnasnet
     m = Mnasnet()
