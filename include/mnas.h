@@ -10,7 +10,8 @@
  *   - takes plain pointers + sizes (no torch types), device pointers unless stated otherwise;
  *   - launches on the HIP stream passed as `stream` (a hipStream_t cast to void*), never synchronises,
  *     never allocates or frees, keeps no pointer after returning, has no global mutable state;
- *   - returns 0 (MNAS_OK) or a non-zero hipError_t / MNAS_E* code; never throws across the ABI.
+ *   - returns 0 (MNAS_OK) or a non-zero hipError_t / MNAS_E* code; never throws across the ABI;
+ *   - is bit-reproducible: no float atomics, every partial-sum table is reduced in a fixed order.
  *
  * Data layout in HBM
  *   activations / activation gradients : NHWC, bf16, dense, C % 8 == 0 (16-byte channel groups)
