@@ -378,6 +378,16 @@ def test_net_full_size_vs_mirror():
     print("full-size net: y vs mirror %.4f, grad cosine min %.4f median %.4f" % (e_y, min(coss), float(np.median(coss))))
     assert e_y < 3e-2
     assert min(coss) > 0.8 and np.median(coss) > 0.95
+    # BatchNorm bookkeeping of the step: running statistics and the update counters of every layer
+    sd = m.state_dict()
+    worst = 0.0
+    for kk, v in sd.items():
+        if kk.endswith("num_batches_tracked"):
+            assert int(v) == int(st[kk]), kk
+        elif "running_" in kk:
+            worst = max(worst, rl2(v.cpu(), st[kk]))
+    print("full-size net: running statistics vs mirror, worst relative L2 %.4f" % worst)
+    assert worst < 3e-2
 
 
 def test_no_cpu_fallback():
