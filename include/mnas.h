@@ -92,6 +92,9 @@ typedef struct MnasConvGemm {
     const float* red_bn;
 } MnasConvGemm;
 int mnas_conv_gemm(const MnasConvGemm* a, void* stream);
+/* Pixels per tile (64 or 128) mnas_conv_gemm uses for a problem with M output pixels, Co output channels and reduction
+ * length K (= kh*kw*Ci of that mode): callers size nparts in whole tiles with it (host-side, no launch). */
+int mnas_conv_gemm_tile_pixels(int M, int Co, int K);
 
 /* ---- weight gradient of the same convs: dW[co][tap][ci] = sum_pix dy[pix][co] * act(x)[src(pix,tap)][ci]
  * Replaces ATen conv2d weight-gradient.  x = (N,Hi,Wi,Ci) forward input, dy = (N,Ho,Wo,Co).

@@ -485,6 +485,43 @@ static int launch_igemm(const IgemmArgs& a_in, int nparts, int nblocks, hipStrea
                        : launch_igemm_k<MODE, NT, PT, 32>(a, nparts, nblocks, pipe, stream);
 }
 
+// cout tiling: NT*16 channels per workgroup column.  Up to 8 tiles: one block (the activation tile is staged
+// once).  Wider outputs: several blocks of 4 or 3 tiles, fewest padded tiles first (NT = 6/8 blocks need 150-250
+// VGPRs; measured 15-25 % slower on the 14x14 / 7x7 expand-type layers than re-staging the small-K activation tile;
+// with K >= 512 re-staging costs more than the registers and 6-tile blocks win by 5-20 %).
+// Pixel tiling: PT=2 (128-pixel tiles) when there are enough tiles to fill the chip twice over.
+static void igemm_tiling(int Co, int Kpad, int M, int* nt_out, int* nblocks_out, int* pt_out) {
+    const int tiles = (Co + 15) / 16;
+    int best_nt = 1, best_waste = 1 << 30, best_blocks = 1 << 30;
+    if (tiles <= 8) {
+        static const int opts1[] = {1, 2, 3, 4, 6, 8};
+        for (int nt : opts1) if (nt >= tiles) { best_nt = nt; best_blocks = 1; break; }
+    } else {
+        // long reductions (K >= 512: the activation tile is the expensive operand) keep 6-tile blocks
+        static const int opts_small_k[3] = {4, 3, 0}, opts_large_k[3] = {6, 4, 3};
+        for (int nt : (Kpad >= 512 ? opts_large_k : opts_small_k)) {
+            if (nt == 0) continue;
+            const int blocks = (tiles + nt - 1) / nt;
+            const int waste = blocks * nt - tiles;
+            if (waste < best_waste || (waste == best_waste && blocks < best_blocks)) {
+                best_nt = nt; best_waste = waste; best_blocks = blocks;
+            }
+        }
+    }
+    *nt_out = best_nt;
+    *nblocks_out = best_blocks;
+    *pt_out = ((int64_t)M * best_blocks >= (int64_t)128 * 1024) ? 2 : 1;
+}
+
+// Pixels per tile (64 or 128) mnas_conv_gemm will use for this problem: lets the caller size `nparts` (persistent
+// workgroups along the pixel dimension) in whole tiles.  M = output pixels, K = kh*kw*Ci of the mode's reduction.
+extern "C" int mnas_conv_gemm_tile_pixels(int M, int Co, int K) {
+    if (M < 1 || Co < 1 || K < 1) return -1;
+    int nt, nblocks, pt;
+    igemm_tiling(Co, (K + 31) / 32 * 32, M, &nt, &nblocks, &pt);
+    return 64 * pt;
+}
+
 extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (!c || (c->mode != 0 && c->mode != 1)) return MNAS_EINVAL;
     if ((c->Ci & 7) || (c->Co & 7) || c->nparts < 1 || c->nparts > 65535) return MNAS_EINVAL;
@@ -511,30 +548,8 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
     if (c->mode == 1 && (!c->grad.g || !c->grad.y || !c->grad.coef)) return MNAS_EINVAL;
 
-    // cout tiling: NT*16 channels per workgroup column.  Up to 8 tiles: one block (the activation tile is staged
-    // once).  Wider outputs: several blocks of 4 or 3 tiles, fewest padded tiles first (NT = 6/8 blocks need 150-250
-    // VGPRs; measured 15-25 % slower on the 14x14 / 7x7 expand-type layers than re-staging the small-K activation tile;
-    // with K >= 512 re-staging costs more than the registers and 6-tile blocks win by 5-20 %).
-    const int tiles = (c->Co + 15) / 16;
-    int best_nt = 1, best_waste = 1 << 30, best_blocks = 1 << 30;
-    if (tiles <= 8) {
-        static const int opts1[] = {1, 2, 3, 4, 6, 8};
-        for (int nt : opts1) if (nt >= tiles) { best_nt = nt; best_blocks = 1; break; }
-    } else {
-        // long reductions (K >= 512: the activation tile is the expensive operand) keep 6-tile blocks
-        static const int opts_small_k[3] = {4, 3, 0}, opts_large_k[3] = {6, 4, 3};
-        for (int nt : (a.Kpad >= 512 ? opts_large_k : opts_small_k)) {
-            if (nt == 0) continue;
-            const int blocks = (tiles + nt - 1) / nt;
-            const int waste = blocks * nt - tiles;
-            if (waste < best_waste || (waste == best_waste && blocks < best_blocks)) {
-                best_nt = nt; best_waste = waste; best_blocks = blocks;
-            }
-        }
-    }
-    const int nblocks = best_blocks;
-    // PT=2 (128-pixel tiles) when there are enough tiles to fill the chip twice over
-    const int pt = ((int64_t)a.M * nblocks >= (int64_t)128 * 1024) ? 2 : 1;
+    int best_nt, nblocks, pt;
+    igemm_tiling(c->Co, a.Kpad, a.M, &best_nt, &nblocks, &pt);
     if (pt == 1 && a.Kpad >= 256 && (best_nt == 2 || best_nt == 3 || best_nt == 6)) a.kch = 128;
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_IG(MODE_, NT_) \
