@@ -101,3 +101,23 @@ def test_bench_shape_one_step_finite():
     t = torch.randint(0, 1000, (32,), device="cuda", generator=g)
     l0 = float(tr.step(x, t)); l1 = float(tr.step(x, t)); l2 = float(tr.step(x, t))
     assert np.isfinite([l0, l1, l2]).all() and l2 < l0
+
+
+def test_trainer_steps_bit_reproducible_at_bench_resolution():
+    """Two Trainers built from the same state take four optimizer steps on the same 64x3x224x224 batch: losses and final
+    parameters are bit-identical (two HIP streams, fused Adam, flat gradient buffer -- no run-to-run variation)."""
+    from mnasnet_pytorch_amd.train_step import Trainer
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(64, 3, 224, 224, device="cuda", generator=g)
+    target = torch.randint(0, 10, (64,), device="cuda", generator=g)
+    runs = []
+    for _ in range(2):
+        m = build("512", proj_gamma=0.1).train()
+        _no_dropout(m)
+        t = Trainer(m, lr=1e-3)
+        losses = [t.step(x, target).clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses), t.flat_p.clone()))
+    assert torch.isfinite(runs[0][0]).all()
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
