@@ -85,7 +85,7 @@ extern "C" int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, dou
                                     int64_t* num_batches_tracked, float momentum, float eps, int training,
                                     float* bnbuf, void* stream) {
     if (C <= 0 || (training && (!partial || nparts <= 0))) return MNAS_EINVAL;
-    if (training && nparts > 256 && C <= 1024)
+    if (training && nparts > 256)
         hipLaunchKernelGGL(k_bn_fwd_finalize<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
                            count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training,
                            bnbuf);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
 extern "C" int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count, float* bnbuf, float* dgamma,
                                     float* dbeta, int accumulate, void* stream) {
     if (C <= 0 || nparts <= 0) return MNAS_EINVAL;
-    if (nparts > 256 && C <= 1024)
+    if (nparts > 256)
         hipLaunchKernelGGL(k_bn_bwd_finalize<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nparts, C,
                            count, bnbuf, dgamma, dbeta, accumulate);
     else

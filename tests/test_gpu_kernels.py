@@ -22,7 +22,7 @@ def _x(shape, seed):
 
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("C_,nparts,count", [(16, 7, 100.0), (48, 64, 3211264.0), (1152, 33, 12544.0),
-                                             (24, 1031, 802816.0), (48, 2048, 3211264.0)])   # block-per-channel path
+                                             (24, 1031, 802816.0), (48, 2048, 3211264.0), (1152, 300, 12544.0)])   # block-per-channel path
 def test_bn_fwd_finalize(C_, nparts, count):
     lib = L.load()
     u = O.det_uniform((2, C_, nparts), 3)
@@ -446,7 +446,7 @@ def test_run_ops_batch():
     assert lib.mnas_run_ops(ops, 3, L.cur_stream(), C.byref(failed)) != 0 and failed.value == 1
 
 
-@pytest.mark.parametrize("C_,nparts", [(16, 1024), (40, 257), (1152, 64)])
+@pytest.mark.parametrize("C_,nparts", [(16, 1024), (40, 257), (1152, 64), (1152, 513)])
 def test_bn_bwd_finalize_long_rows(C_, nparts):
     """Both finalize shapes (wave per channel / block per channel) against an fp64 sum of the same partial table."""
     lib = L.load()
