@@ -346,7 +346,7 @@ class Program:
                 # large-pixel-count 1x1 conv: ONE sweep produces the input gradient, the weight-gradient partials and the
                 # fused reduce (both former kernels stream the same g, y; see csrc/mnas_pwbwd.hip).  Main stream.
                 gin = new((N, Hi, Wi, ci.cin))
-                nparts = max(1, min(1024 if M >= 800000 else (512 if M >= 100000 else 256), _cdiv(M, 128 if max(ci.cin, Co) <= 80 else 64)))
+                nparts = max(1, min(1024 if M >= 800000 else (512 if M >= 100000 else 128), _cdiv(M, 128 if max(ci.cin, Co) <= 80 else 64)))
                 red = [None, None, None]
                 if rt is not None:
                     red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
