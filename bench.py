@@ -31,7 +31,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (no sparsity), MI355X_MICROARCH.md
-MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
 
 
 def parse():
@@ -168,7 +167,21 @@ def cpu_baseline(seconds):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks as a CHILD torch.distributed.run (nothing has touched the GPU
+        # in this process yet; never exec from a process that has) and hand its exit code back
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or run "
+                 "plain `python bench.py --gpus %d`)" % (args.gpus, world, args.gpus, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1

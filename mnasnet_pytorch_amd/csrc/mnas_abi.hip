@@ -2,6 +2,17 @@
 // segment instead of ~450 ctypes calls per training step).
 #include "mnas_common.h"
 
+#include <cstdlib>
+#define MNAS_NT_DEFAULT 0
+int mnas_nt_mask() {
+    static int mask = -1;
+    if (mask < 0) {
+        const char* e = getenv("MNAS_NT");
+        mask = e ? atoi(e) : MNAS_NT_DEFAULT;
+    }
+    return mask;
+}
+
 extern "C" int mnas_version(void) { return 1; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 

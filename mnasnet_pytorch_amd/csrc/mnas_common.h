@@ -64,6 +64,30 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
+// Stores of the large activation / gradient tensors.  nt = nontemporal (streaming) store: the written tensor is not read
+// again by this kernel; measured on MI355X (tools/probe/bw.hip) a 1-read : 3-write stream sustains 3.3 TB/s with plain
+// stores and 4.5-5.0 TB/s with nontemporal ones (1:1 4.7 -> 5.1; read-heavy mixes unchanged).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_u1(void* p, uint32_t v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, (uint32_t*)p); else *(uint32_t*)p = v;
+}
+__device__ __forceinline__ void st_u2(void* p, uint2 v, bool nt) {
+    if (nt) __builtin_nontemporal_store((u32x2_t){v.x, v.y}, (u32x2_t*)p); else *(uint2*)p = v;
+}
+__device__ __forceinline__ void st_u4(void* p, uint4 v, bool nt) {
+    if (nt) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, (u32x4_t*)p); else *(uint4*)p = v;
+}
+// MNAS_NT environment bit mask (diagnosis / A-B runs; unset = the tuned default): which kernel classes store nontemporally
+#define MNAS_NT_IGEMM_FWD 1
+#define MNAS_NT_IGEMM_DGRAD 2
+#define MNAS_NT_DW_FWD 4
+#define MNAS_NT_DW_BWD 8
+#define MNAS_NT_PW_BWD 16
+#define MNAS_NT_ADD_ACT 32
+#define MNAS_NT_STEM 64
+int mnas_nt_mask();
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -40,6 +40,7 @@ struct DwArgs {
     int strips_x, cblocks, items, geff;     // geff: workgroups that take items (multiple of cblocks)
     int rc, nb;                             // 16-byte chunks per ring row; DMA blocks (64 chunks) per row
     float score;                            // geometry score of dw_pick (host only)
+    int nt;                                 // nontemporal output stores
 };
 
 static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a) {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
                             const f2 v = A[0][ox];
                             s1 += v;
                             s2 = f2fma(v, v, s2);
-                            outp[((size_t)oy * a.W + ox) * a.C / 2] = pack_bf16(v.x, v.y);
+                            st_u1(outp + ((size_t)oy * a.W + ox) * a.C / 2, pack_bf16(v.x, v.y), a.nt);
                         }
                     }
                 }
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                     for (int ox = 0; ox < DW_BW; ++ox) {
                         if (gx0 + ox < a.W) {
                             const uint32_t pk = pack_bf16(A[0][ox].x, A[0][ox].y);
-                            gin[obase + ((size_t)oy * a.W + ox) * a.C / 2] = pk;
+                            st_u1(gin + obase + ((size_t)oy * a.W + ox) * a.C / 2, pk, a.nt);
                             if (RED) {
                                 const f2 gq = f2bf(pk), yq = f2bf(xraw[ox]);
                                 const f2 z = f2fma(yq, cs, ct);
@@ -596,6 +597,7 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     DwArgs a;
     int g;
     if (!dw_choose(c->N, c->H, c->W, c->C, c->k, -1, &a, &g) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
+    a.nt = (mnas_nt_mask() & MNAS_NT_DW_FWD) ? 1 : 0;
     size_t lds = (size_t)2 * g * a.rc * 16;
     const size_t red_need = (size_t)a.sx * 2 * 2 * a.cpw * sizeof(float);          // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
@@ -619,6 +621,7 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     DwArgs a;
     int g;
     if (!dw_choose(c->N, c->H, c->W, c->C, c->k, c->phase, &a, &g) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
+    a.nt = (mnas_nt_mask() & MNAS_NT_DW_BWD) ? 1 : 0;
     size_t lds = (size_t)nrings * 2 * g * a.rc * 16;
     const size_t red_need = (size_t)a.sx * (want_wg ? c->k * c->k : 2) * 2 * a.cpw * sizeof(float);   // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;

@@ -199,7 +199,7 @@ extern "C" int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, dou
 // out = act(a) + act(b): the MBConv_block residual (mnasnet.py:133) and the features-output conversion
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_add_act(MnasActIn a, MnasActIn b, int64_t rows, int C, uint4* __restrict__ out,
-                                                 float* __restrict__ out_nchw, int HW) {
+                                                 float* __restrict__ out_nchw, int HW, int nt) {
     const int G = C >> 3;
     const int R = 256 / G;
     const int tid = threadIdx.x;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_add_act(MnasActIn a, MnasActIn b, int64
 #pragma unroll
             for (int j = 0; j < 8; ++j) fa[j] += fb[j];
         }
-        if (out) out[r * G + cg] = pack8(fa);
+        if (out) st_u4(out + r * G + cg, pack8(fa), nt);
         if (out_nchw) {
             const int64_t n = r / HW, hw = r % HW;
 #pragma unroll
@@ -251,7 +251,7 @@ extern "C" int mnas_add_act(const MnasActIn* a, const MnasActIn* b, int64_t rows
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_add_act, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a, bb, rows, C,
-                       (uint4*)out_bf16, out_nchw_f32, HW);
+                       (uint4*)out_bf16, out_nchw_f32, HW, (mnas_nt_mask() & MNAS_NT_ADD_ACT) ? 1 : 0);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }

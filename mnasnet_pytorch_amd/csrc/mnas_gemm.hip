@@ -33,6 +33,7 @@ struct IgemmArgs {
     float* stats;
     const void* red_y;       // MODE 1: fused BN-backward reduce target (raw output of the ConvBlock whose g we produce)
     const float* red_bn;
+    int nt;                  // nontemporal output stores
 };
 
 template <int MODE, int NT, int PT, int KCH, bool PIPE, bool PAR2>
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                 uint2 pk;
                 pk.x = pack_bf16(v[0], v[1]);
                 pk.y = pack_bf16(v[2], v[3]);
-                *(uint2*)((uint16_t*)a.out + o) = pk;
+                st_u2((uint16_t*)a.out + o, pk, a.nt);
                 if (do_red) {
                     // fused BN-backward reduce for the layer whose activated output this gradient belongs to:
                     // dz = g*[s*y+t>0] (g as stored, i.e. bf16-rounded), xhat = y*invstd - mean*invstd
@@ -538,6 +539,7 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     a.act = c->act; a.grad = c->grad;
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = c->resid; a.out = c->out; a.stats = c->stats;
     a.red_y = (c->mode == 1) ? c->red_y : nullptr; a.red_bn = c->red_bn;
+    a.nt = (mnas_nt_mask() & (c->mode == 1 ? MNAS_NT_IGEMM_DGRAD : MNAS_NT_IGEMM_FWD)) ? 1 : 0;
     // stride-2 3x3 input gradient over even output sizes: parity-class tiling (see k_igemm)
     a.s2 = (c->mode == 1 && c->kh == 3 && c->kw == 3 && c->stride == 2 && c->pad == 1 && !(c->Ho & 1) && !(c->Wo & 1)) ? 1 : 0;
     a.Mc = c->N * (c->Ho / 2) * (c->Wo / 2);
@@ -575,6 +577,7 @@ extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     a.grad.g = nullptr; a.grad.y = nullptr; a.grad.coef = nullptr;
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = nullptr; a.out = c->out; a.stats = c->stats;
     a.red_y = nullptr; a.red_bn = nullptr;
+    a.nt = (mnas_nt_mask() & MNAS_NT_STEM) ? 1 : 0;
     a.s2 = 0; a.Mc = 0; a.tpc = 0;
     const int tiles = (c->Co + 15) / 16;
     hipStream_t s = (hipStream_t)stream;

@@ -33,6 +33,7 @@ struct PwBwdArgs {
     float* red_partial;
     const void* red_y;
     const float* red_bn;
+    int nt;                  // nontemporal gin stores
 };
 
 __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                     uint2 pk;
                     pk.x = pack_bf16(v[0], v[1]);
                     pk.y = pack_bf16(v[2], v[3]);
-                    *(uint2*)((uint16_t*)a.gin + o) = pk;
+                    st_u2((uint16_t*)a.gin + o, pk, a.nt);
                     if (do_red) {
                         // dz = g*[s*y+t>0] with g as stored (bf16), y = raw output of the reduce target; xhat = y*invstd - mean*invstd
                         const uint2 yv = ypre[pt][nt];
@@ -381,6 +382,7 @@ extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     a.M = c->M; a.Ci = c->Ci; a.Co = c->Co; a.Kd = (c->Co + 31) / 32 * 32;
     a.x = c->x; a.dy = c->dy; a.w = (const uint16_t*)c->w; a.resid = c->resid; a.gin = c->gin;
     a.wpartial = c->wpartial; a.red_partial = c->red_partial; a.red_y = c->red_y; a.red_bn = c->red_bn;
+    a.nt = (mnas_nt_mask() & MNAS_NT_PW_BWD) ? 1 : 0;
     const PwCfg* cfg = pw_cfg(c->Ci, c->Co);
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_PWB(O_, I_, P_) if (cfg->nto == O_ && cfg->nti_slice == I_ && cfg->pt == P_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s, cfg->nslices);

@@ -10,7 +10,8 @@ fused into the consumers' loads, BatchNorm statistics fused into the producers' 
 allocated once per shape, no Python per-layer dispatch on the step path.
 
 Autograd contract: parameters are inputs of one autograd.Function, so loss.backward() reaches
-us; weight/BN gradients are written by the kernels straight into a flat fp32 buffer whose slices ARE the
+us (tensor hooks registered on parameters -- register_hook / post-accumulate-grad hooks -- do NOT fire: the gradients
+bypass AccumulateGrad; DDP-style hook-driven reducers must use train_step.Trainer's stage-done callback instead); weight/BN gradients are written by the kernels straight into a flat fp32 buffer whose slices ARE the
 parameters' ``.grad`` (None -> attached, already ours -> accumulated, foreign tensor -> added into it), the
 same observable behaviour as autograd's AccumulateGrad, without ~110 tiny copy kernels.  Shared blocks
 accumulate their ``layers`` contributions; ``conv.bias.grad`` is exactly zero (train-mode BatchNorm cancels
@@ -479,6 +480,26 @@ class Program:
 
 
 L_BN_ROWS = 8
+_MAX_PROGRAMS_PER_SHAPE = 4     # forwards kept alive simultaneously per (N,H,W,mode): beyond this the caller is leaking graphs
+
+
+class _Lease:
+    """Ties a Program's activation buffers to the autograd graph of ONE forward.  The program is handed back when
+    backward has consumed it OR when the graph is dropped without a backward (exception between forward and backward,
+    LR finder, BatchNorm recalibration pass, ...): ``ctx`` dies with the graph and takes this object with it."""
+    __slots__ = ("prog", "consumed", "__weakref__")
+
+    def __init__(self, prog):
+        self.prog, self.consumed = prog, False
+        prog.busy = True
+
+    def release(self):
+        if self.prog is not None:
+            self.prog.busy = False
+            self.prog = None
+
+    def __del__(self):
+        self.release()
 
 
 class _EngineFn(torch.autograd.Function):
@@ -488,25 +509,28 @@ class _EngineFn(torch.autograd.Function):
         training = eng.root.training
         prog = eng.program(x.shape[0], x.shape[2], x.shape[3], training, need_dx)
         out = prog.run_forward(x)
-        if training and track:
-            prog.busy = True
-            ctx.prog = prog
-            ctx.eng = eng
-        else:
-            ctx.prog = None
+        ctx.eng = eng
+        ctx.lease = _Lease(prog) if (training and track) else None
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        prog, eng = ctx.prog, ctx.eng
-        if prog is None:
+        lease, eng = ctx.lease, ctx.eng
+        if lease is None:
             raise RuntimeError("backward through an eval-mode / no-grad engine forward")
+        if lease.consumed or lease.prog is None:
+            # the activation buffers belong to a per-shape program that later forwards reuse: a second backward
+            # (retain_graph=True) would read overwritten activations
+            raise RuntimeError("the HIP engine keeps activations for ONE backward per forward; run the forward again "
+                               "(retain_graph=True is not supported through mnasnet_pytorch_amd modules)")
+        prog = lease.prog
         try:
             accumulate = eng.prepare_grads()
             dx = prog.run_backward(gout.contiguous().float(), eng.on_stage_done)
             eng.finish_grads(accumulate)
         finally:
-            prog.busy = False
+            lease.consumed = True
+            lease.release()
         return (None, None, dx) + (None,) * len(eng.params)
 
 
@@ -562,6 +586,10 @@ class Engine:
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_filter = None       # optional predicate (opcode, ints) -> bool narrowing the bracketed launches
         self.profile_events = []         # [(tag, start_handle, stop_handle)]
+        self._events = []                # every HIP event handle the compiled programs own (destroyed with them)
+        first = self.steps[0][1] if self.steps[0][0] == "conv" else self.steps[0][1][0]
+        self.in_channels_hint = self.info[id(first)].cin
+        self.starts_with_stem = self.info[id(first)].kind == "stem"
 
     # ---- device state ---------------------------------------------------------------------------
     def _signature(self):
@@ -573,8 +601,10 @@ class Engine:
 
     def _setup(self, device):
         self.lib = L.load()
+        if self.device is not None:
+            self.reset_programs()
         self.device = device
-        self.programs.clear()
+        self._validate_modules()
         if self.side_stream is None or self.side_stream.device != device:
             self.side_stream = torch.cuda.Stream(device=device)
         nbytes = self.lib.mnas_packed_bytes
@@ -609,6 +639,34 @@ class Engine:
                 o, n = ci.gslice[j]
                 self.grad_views.append(self.flat_grad[o:o + n].view(p.shape))
 
+    def _validate_modules(self):
+        """The kernels read every parameter / buffer as dense fp32: anything else (model.half(), .bfloat16(),
+        .double(), a non-contiguous view) must fail loudly instead of producing garbage."""
+        for ci in self.convs:
+            conv, bn = ci.mod.conv, ci.mod.bn
+            named = [("conv.weight", conv.weight), ("conv.bias", conv.bias), ("bn.weight", bn.weight), ("bn.bias", bn.bias),
+                     ("bn.running_mean", bn.running_mean), ("bn.running_var", bn.running_var)]
+            for name, t in named:
+                if t is None:
+                    raise NotImplementedError("ConvBlock without %s" % name)
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise TypeError("mnasnet_pytorch_amd: %s must be contiguous float32 (got %s%s); the HIP path keeps fp32 "
+                                    "master weights / statistics and bf16 activations internally -- do not call .half() / "
+                                    ".bfloat16() / .double() on the model" %
+                                    (name, t.dtype, "" if t.is_contiguous() else ", non-contiguous"))
+            if bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype != torch.int64:
+                raise TypeError("bn.num_batches_tracked must be int64")
+
+    def _check_modes(self):
+        """One mode per call: the launch list is compiled for root.training.  A submodule in a different mode (frozen-BN
+        fine-tuning: ``bn.eval()`` under a training root) is not silently ignored."""
+        mode = self.root.training
+        for m in self.root.modules():
+            if m.training != mode:
+                raise NotImplementedError(
+                    "mixed train/eval modes inside one engine subtree (%s.training=%s, root.training=%s): per-submodule "
+                    "BatchNorm freezing is not supported by the HIP engine" % (type(m).__name__, m.training, mode))
+
     def bind_grad_buffer(self, buf: Optional[torch.Tensor]):
         """Make the kernels write gradients into ``buf`` (fp32, ``grad_numel`` elements, engine layout: later
         stages first) instead of an engine-owned buffer -- used by train_step.Trainer so that ONE flat buffer
@@ -625,14 +683,30 @@ class Engine:
             self._sig = sig
 
     def reset_programs(self):
-        """Drop the compiled launch lists (they embed the profiling brackets); rebuilt lazily on the next call."""
+        """Drop the compiled launch lists (they embed the profiling brackets); rebuilt lazily on the next call.
+        The HIP events they own are destroyed (after a device sync: a launch list may still be in flight)."""
+        if any(p.busy for lst in self.programs.values() for p in lst):
+            raise RuntimeError("reset_programs() while a forward is waiting for its backward")
         self.programs.clear()
         self.profile_events = []
+        if self._events:
+            torch.cuda.synchronize(self.device)
+            for h in self._events:
+                self.lib.mnas_event_destroy(h)
+            self._events = []
 
     def new_event(self):
         h = C.c_void_p()
         L.check(self.lib.mnas_event_create(C.byref(h)), "event_create")
+        self._events.append(h.value)
         return h.value
+
+    def __del__(self):
+        try:
+            for h in self._events:
+                self.lib.mnas_event_destroy(h)
+        except Exception:       # interpreter shutdown
+            pass
 
     def read_profile(self):
         """[(tag, ms)] for every bracketed op launch since the programs were built (call after a sync)."""
@@ -652,6 +726,11 @@ class Engine:
         for p in lst:
             if not p.busy:
                 return p
+        if len(lst) >= _MAX_PROGRAMS_PER_SHAPE:
+            raise RuntimeError(
+                "%d forwards of shape %s are alive at once (their autograd graphs are still referenced and no backward "
+                "has run): each holds a full set of activation buffers.  Drop the old outputs / call backward, or run "
+                "under torch.no_grad()." % (len(lst), (N, self.in_channels_hint, H, W)))
         p = Program(self, N, H, W, training, need_dx)
         lst.append(p)
         return p
@@ -695,7 +774,13 @@ class Engine:
             raise ValueError("expected NCHW input")
         if any(p.device != x.device for p in self.params):
             raise RuntimeError("module parameters and input are on different devices")
+        track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params))
+        if track and x.requires_grad and self.starts_with_stem and self.root.training:
+            # the stem's input gradient (fp32 NCHW image gradient) is not part of the training path (train.py:427:
+            # images do not require grad): fail loudly instead of returning a missing gradient
+            raise NotImplementedError("gradient w.r.t. the input image is not implemented by the HIP engine (the stem's "
+                                      "dgrad is skipped); pass the image with requires_grad=False")
         x = x.float().contiguous()          # train.py:427 input.float()
         self.ensure_setup(x.device)
-        track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params))
+        self._check_modes()
         return _EngineFn.apply(self, track, x, *self.params)

@@ -49,17 +49,103 @@ class FlatBuckets:
         self.handles = []
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` (train.py:219-221) over ONE flat fp32 buffer: a single fused launch (``mnas_adam_step``) instead
+    of ~110 per-tensor updates.  It is a real ``torch.optim.Optimizer``:
+
+    * ``param_groups[0]['lr']`` (and betas / eps / weight_decay) are read at every step, so the schedulers of the
+      reference (MultiStepLR, ExponentialLR, ReduceLROnPlateau, CyclicLR.batch_step: train.py:284-337) and the
+      ``optimizer.state_dict()['param_groups'][0]['lr']`` read-back (train.py:450) work unchanged;
+    * ``state_dict()`` / ``load_state_dict()`` carry the moments and the step count (train.py:382 checkpoints them);
+    * parameters with ``requires_grad == False`` (``FineTuneModelPool.freeze()``, classifiers.py:95-99) are left
+      untouched: the update runs over the contiguous runs of trainable elements only, so weight decay cannot move a
+      frozen weight.
+    """
+
+    def __init__(self, params, flat_p, flat_g, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        params = list(params)
+        n = sum(p.numel() for p in params)
+        if flat_p.numel() != n or flat_g.numel() != n:
+            raise ValueError("flat buffers must hold exactly the parameters handed to FlatAdam")
+        off = 0
+        self._ranges = []                 # element range of every parameter inside the flat buffers
+        for p in params:
+            if p.data_ptr() != flat_p.data_ptr() + 4 * off:
+                raise ValueError("parameters must be views of flat_p in order")
+            self._ranges.append((off, off + p.numel()))
+            off += p.numel()
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat_p, self.flat_g = flat_p, flat_g
+        self.flat_m = torch.zeros_like(flat_p)
+        self.flat_v = torch.zeros_like(flat_p)
+        self.step_count = 0
+        self.grad_scale = grad_scale      # 1/world_size: the all-reduce sums, Adam sees the mean (DataParallel semantics)
+        self._lib = L.load()
+        self._runs_key, self._runs = None, []
+
+    def _trainable_runs(self):
+        ps = self.param_groups[0]["params"]
+        key = tuple(p.requires_grad for p in ps)
+        if key != self._runs_key:
+            runs = []
+            for (a, b), rg in zip(self._ranges, key):
+                if not rg or a == b:
+                    continue
+                if runs and runs[-1][1] == a:
+                    runs[-1][1] = b
+                else:
+                    runs.append([a, b])
+            self._runs_key, self._runs = key, runs
+        return self._runs
+
+    def zero_grad(self, set_to_none: bool = False):
+        """The gradients are views of the flat buffer: zero it in one launch (never set to None)."""
+        self.flat_g.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        g = self.param_groups[0]
+        self.step_count += 1
+        for a, b in self._trainable_runs():
+            L.check(self._lib.mnas_adam_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a,
+                                             self.flat_m.data_ptr() + 4 * a, self.flat_v.data_ptr() + 4 * a, b - a,
+                                             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                             float(g["weight_decay"]), self.step_count, float(self.grad_scale),
+                                             L.cur_stream()), "adam_step")
+        return loss
+
+    def state_dict(self):
+        g = self.param_groups[0]
+        return {"state": {"step": self.step_count, "exp_avg": self.flat_m.clone(), "exp_avg_sq": self.flat_v.clone()},
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} | {"params": list(range(len(g["params"])))}]}
+
+    def load_state_dict(self, sd):
+        st = sd["state"]
+        if st["exp_avg"].numel() != self.flat_m.numel():
+            raise ValueError("optimizer state has %d elements, this model %d" % (st["exp_avg"].numel(), self.flat_m.numel()))
+        self.step_count = int(st["step"])
+        self.flat_m.copy_(st["exp_avg"].to(self.flat_m.device))
+        self.flat_v.copy_(st["exp_avg_sq"].to(self.flat_v.device))
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+
+
 class Trainer:
     """Owns flat parameter / gradient / Adam-moment buffers for ``model`` (a FineTuneModelPool or anything with
-    a ``features`` engine module plus ordinary PyTorch head parameters) and runs train.py's step."""
+    a ``features`` engine module plus ordinary PyTorch head parameters) and runs train.py's step.
+    ``trainer.optimizer`` is a :class:`FlatAdam` (a ``torch.optim.Optimizer``): hand it to the reference's schedulers and
+    checkpoint it with ``optimizer.state_dict()`` exactly as train.py does."""
 
     def __init__(self, model: nn.Module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  criterion: Optional[nn.Module] = None, distributed: bool = False, process_group=None,
                  early_bucket_stage: int = 5):
         self.model = model
-        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss()   # train.py:277
-        self.step_count = 0
         self.lib = L.load()
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -69,15 +155,13 @@ class Trainer:
         self.engine = feats._engine()
         eng_params = list(self.engine.params)
         eng_ids = {id(p) for p in eng_params}
-        head = [p for p in model.parameters() if id(p) not in eng_ids and p.requires_grad]
+        head = [p for p in model.parameters() if id(p) not in eng_ids]
         self.head_params = head
         n_head = sum(p.numel() for p in head)
         n_eng = self.engine.grad_numel
         n = n_head + n_eng
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         # ---- parameters become views of flat_p (same element order as the gradient layout)
         off = 0
         with torch.no_grad():
@@ -95,8 +179,8 @@ class Trainer:
         self.engine.bind_grad_buffer(self.flat_g[n_head:])
         self.engine.ensure_setup(dev)
         for p, v in zip(self.engine.params, self.engine.grad_views):
-            if p.requires_grad:
-                p.grad = v                                            # "already ours" -> engine accumulates
+            p.grad = v                                                # "already ours" -> engine accumulates
+        # flat order = head parameters, then the engine's (later stages first): FlatAdam checks the views line up
         # ---- data parallel
         self.distributed = distributed
         self.world = 1
@@ -113,6 +197,36 @@ class Trainer:
             self._early_stage = min(stages_early) if stages_early else None
             self.engine.on_stage_done = self._on_stage_done
         self._launched0 = False
+        self.optimizer = FlatAdam(head + eng_params, self.flat_p, self.flat_g, lr=lr, betas=betas, eps=eps,
+                                  weight_decay=weight_decay, grad_scale=1.0 / self.world)
+
+    # convenience mirrors of the optimizer's hyper-parameters / state
+    @property
+    def lr(self):
+        return self.optimizer.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, v):
+        self.optimizer.param_groups[0]["lr"] = v
+
+    @property
+    def step_count(self):
+        return self.optimizer.step_count
+
+    @property
+    def flat_m(self):
+        return self.optimizer.flat_m
+
+    @property
+    def flat_v(self):
+        return self.optimizer.flat_v
+
+    def state_dict(self):
+        """{'optimizer': FlatAdam.state_dict()} -- what train.py:382 stores under 'optimizer'."""
+        return {"optimizer": self.optimizer.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.optimizer.load_state_dict(sd["optimizer"])
 
     # engine callback: backward of features.<stage> has been enqueued
     def _on_stage_done(self, stage: int):
@@ -131,7 +245,7 @@ class Trainer:
 
     def step(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """One iteration of train.py:427-440.  Returns the loss tensor (no host sync)."""
-        self.flat_g.zero_()                                  # optimizer.zero_grad()
+        self.optimizer.zero_grad()                           # train.py:438
         self._launched0 = False
         out = self.model(x.float())
         loss = self.criterion(out, target)
@@ -141,9 +255,5 @@ class Trainer:
                 self.buckets.launch(0)
             self.buckets.launch(1)
             self.buckets.wait()
-        self.step_count += 1
-        L.check(self.lib.mnas_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                        self.flat_v.data_ptr(), self.flat_p.numel(), self.lr, self.betas[0],
-                                        self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world,
-                                        L.cur_stream()), "adam_step")
+        self.optimizer.step()                                # train.py:440
         return loss.detach()

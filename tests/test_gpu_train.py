@@ -121,3 +121,98 @@ def test_trainer_steps_bit_reproducible_at_bench_resolution():
     assert torch.isfinite(runs[0][0]).all()
     assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1])
+
+
+# ---- engine / optimizer contract (round-2 advisor findings) ------------------------------------------------------------
+def test_dropped_graph_releases_its_program():
+    """A train-mode forward whose graph is dropped without backward (exception, LR finder, BN recalibration) hands its
+    activation buffers back: repeated forwards reuse ONE program instead of allocating a new set each call."""
+    m = build("512").train()
+    x = C.det_input((2, 3, 64, 64)).cuda()
+    eng = m.features._engine()
+    for _ in range(6):
+        out = m(x)
+        del out
+    progs = [p for lst in eng.programs.values() for p in lst]
+    assert len(progs) == 1 and not progs[0].busy
+    # two graphs alive at once get two programs; both are released by their backward
+    a, b = m(x), m(x)
+    assert len([p for lst in eng.programs.values() for p in lst]) == 2
+    (a.sum() + b.sum()).backward()
+    assert not any(p.busy for lst in eng.programs.values() for p in lst)
+
+
+def test_second_backward_raises():
+    m = build("512").train()
+    _no_dropout(m)
+    out = m(C.det_input((2, 3, 64, 64)).cuda())
+    loss = out.sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="ONE backward per forward"):
+        loss.backward()
+
+
+def test_too_many_live_forwards_raise():
+    m = build("512").train()
+    x = C.det_input((2, 3, 64, 64)).cuda()
+    keep = [m(x) for _ in range(4)]
+    with pytest.raises(RuntimeError, match="alive at once"):
+        m(x)
+    del keep
+
+
+def test_image_gradient_request_raises():
+    m = build("512").train()
+    x = C.det_input((2, 3, 64, 64)).cuda().requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="input image"):
+        m(x)
+
+
+def test_wrong_dtype_and_mixed_modes_fail_loudly():
+    x = C.det_input((2, 3, 64, 64)).cuda()
+    m = build("512").train()
+    m.features.half()
+    with pytest.raises(TypeError, match="float32"):
+        m.features(x)
+    m2 = build("512").train()
+    m2.features[0].bn.eval()                     # frozen-BN fine-tuning is not silently ignored
+    with pytest.raises(NotImplementedError, match="mixed train/eval"):
+        m2(x)
+
+
+def test_flat_adam_is_a_torch_optimizer():
+    """Schedulers drive it, param_groups[0]['lr'] reads back (train.py:450), state_dict round-trips the moments, and a
+    frozen parameter is not moved even with weight decay."""
+    from mnasnet_pytorch_amd.train_step import FlatAdam, Trainer
+    x = C.det_input((4, 3, 64, 64)).cuda()
+    target = torch.tensor([1, 3, 5, 7]).cuda()
+    m = build("512", proj_gamma=0.1).train(); _no_dropout(m)
+    tr = Trainer(m, lr=1e-3, weight_decay=1e-2)
+    opt = tr.optimizer
+    assert isinstance(opt, torch.optim.Optimizer) and isinstance(opt, FlatAdam)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
+    tr.step(x, target); sched.step()
+    assert abs(opt.state_dict()["param_groups"][0]["lr"] - 1e-4) < 1e-12 and abs(tr.lr - 1e-4) < 1e-12
+    plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0)
+    plateau.step(1.0); plateau.step(2.0)
+    assert abs(tr.lr - 5e-5) < 1e-12
+    # frozen features: only the head moves
+    m.freeze()
+    w0 = m.features[0].conv.weight.detach().clone()
+    h0 = m.classifier[1].weight.detach().clone()
+    tr.step(x, target)
+    assert torch.equal(m.features[0].conv.weight.detach(), w0)
+    assert not torch.equal(m.classifier[1].weight.detach(), h0)
+    m.unfreeze()
+    # checkpoint round trip: a second trainer resumed from the state dicts continues bit-identically
+    sd_model = {k: v.clone() for k, v in m.state_dict().items()}
+    sd_opt = tr.state_dict()
+    l_a = float(tr.step(x, target))
+    m2 = build("512", proj_gamma=0.1).train(); _no_dropout(m2)
+    m2.load_state_dict(sd_model)
+    tr2 = Trainer(m2, lr=123.0)
+    tr2.load_state_dict(sd_opt)
+    assert abs(tr2.lr - tr.lr) < 1e-12 and tr2.step_count == tr.step_count - 1
+    l_b = float(tr2.step(x, target))
+    assert l_a == l_b
+    assert torch.equal(tr.flat_p, tr2.flat_p)
