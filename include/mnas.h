@@ -95,6 +95,10 @@ int mnas_conv_gemm(const MnasConvGemm* a, void* stream);
 /* Pixels per tile (64 or 128) mnas_conv_gemm uses for a problem with M output pixels, Co output channels and reduction
  * length K (= kh*kw*Ci of that mode): callers size nparts in whole tiles with it (host-side, no launch). */
 int mnas_conv_gemm_tile_pixels(int M, int Co, int K);
+/* Preferred nparts for a launch (host-side, no launch): > 0 where the kernel sizes its own persistent grid (the 1x1
+ * forward: DMA-pipelined kernel, csrc/mnas_pwf.hip), -1 = caller's choice in whole tiles (mnas_conv_gemm_tile_pixels).
+ * taps = kh*kw. */
+int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps);
 
 /* ---- weight gradient of the same convs: dW[co][tap][ci] = sum_pix dy[pix][co] * act(x)[src(pix,tap)][ci]
  * Replaces ATen conv2d weight-gradient.  x = (N,Hi,Wi,Ci) forward input, dy = (N,Ho,Wo,Co).

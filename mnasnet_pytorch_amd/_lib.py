@@ -86,6 +86,7 @@ SYMBOLS = {
     "mnas_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "mnas_conv_gemm": (c_int, [C.POINTER(MnasConvGemm), c_void_p]),
     "mnas_conv_gemm_tile_pixels": (c_int, [c_int, c_int, c_int]),
+    "mnas_conv_gemm_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mnas_conv_wgrad": (c_int, [C.POINTER(MnasConvWgrad), c_void_p]),
     "mnas_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mnas_pw_bwd": (c_int, [C.POINTER(MnasPwBwd), c_void_p]),

@@ -13,6 +13,15 @@ int mnas_nt_mask() {
     return mask;
 }
 
+int mnas_pwf_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("MNAS_PWF");
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
+
 extern "C" int mnas_version(void) { return 1; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 

@@ -523,6 +523,13 @@ extern "C" int mnas_conv_gemm_tile_pixels(int M, int Co, int K) {
     return 64 * pt;
 }
 
+// Preferred number of pixel-workgroups (nparts) for a launch: > 0 for the kernels that size their own persistent grid
+// (the DMA-pipelined 1x1 forward), -1 = "caller's choice" (k_igemm: whole tiles, see mnas_conv_gemm_tile_pixels).
+extern "C" int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps) {
+    if (mode == 0 && taps == 1 && mnas_pwf_enabled()) return mnas_pwf_parts(M, Ci, Co);
+    return -1;
+}
+
 extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (!c || (c->mode != 0 && c->mode != 1)) return MNAS_EINVAL;
     if ((c->Ci & 7) || (c->Co & 7) || c->nparts < 1 || c->nparts > 65535) return MNAS_EINVAL;
@@ -549,6 +556,8 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;   // strided / padded 1x1 does not occur in this network
     if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
     if (c->mode == 1 && (!c->grad.g || !c->grad.y || !c->grad.coef)) return MNAS_EINVAL;
+    if (c->mode == 0 && a.is_pw && !c->resid && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
+        return mnas_pwf_forward(c, stream);
 
     int best_nt, nblocks, pt;
     igemm_tiling(c->Co, a.Kpad, a.M, &best_nt, &nblocks, &pt);

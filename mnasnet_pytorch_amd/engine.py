@@ -220,7 +220,9 @@ class Program:
             bn = bnbuf(ci.cout)
             conv, bnm = ci.mod.conv, ci.mod.bn
             bias = conv.bias.data_ptr() if conv.bias is not None else None
-            nparts = max(1, min(1024, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
+            nparts = lib.mnas_conv_gemm_parts(0, M, ci.cin, ci.cout, ci.k * ci.k) if ci.kind in ("pw", "dense") else -1
+            if nparts < 1:
+                nparts = max(1, min(1024, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
             stats = eng.scratch_stats.data_ptr() if training else None
             if ci.kind == "stem":
                 j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts], [],
