@@ -3,7 +3,7 @@
 #include "mnas_common.h"
 
 #include <cstdlib>
-#define MNAS_NT_DEFAULT 0
+#define MNAS_NT_DEFAULT MNAS_NT_PWF
 int mnas_nt_mask() {
     static int mask = -1;
     if (mask < 0) {

@@ -86,6 +86,7 @@ __device__ __forceinline__ void st_u4(void* p, uint4 v, bool nt) {
 #define MNAS_NT_PW_BWD 16
 #define MNAS_NT_ADD_ACT 32
 #define MNAS_NT_STEM 64
+#define MNAS_NT_PWF 128
 int mnas_nt_mask();
 // DMA-pipelined 1x1 forward (mnas_pwf.hip): mnas_conv_gemm dispatches mode 0 / 1x1 here unless MNAS_PWF=0
 int mnas_pwf_enabled();

@@ -329,7 +329,7 @@ int mnas_pwf_forward(const MnasConvGemm* c, void* stream) {
     a.Kpad = (c->Ci + 31) / 32 * 32;
     a.kc = p.kc; a.nkc = p.nkc; a.nch = p.kc / 8;
     a.co_pad16 = (c->Co + 15) / 16 * 16;
-    a.nt_store = (mnas_nt_mask() & MNAS_NT_IGEMM_FWD) ? 1 : 0;
+    a.nt_store = (mnas_nt_mask() & MNAS_NT_PWF) ? 1 : 0;
     { const char* e = getenv("MNAS_PWF_ABL"); a.abl = e ? atoi(e) : 0; }
     a.act = c->act; a.w = (const uint16_t*)c->w; a.bias = c->bias; a.out = c->out; a.stats = c->stats;
     hipStream_t s = (hipStream_t)stream;
