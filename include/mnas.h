@@ -166,6 +166,40 @@ int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
 int mnas_dw_geometry(int N, int H, int W, int C, int k, int which, int* out);
 int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which);
 
+/* ---- fused expand (1x1, Cin -> C) + depthwise forward: the first two ConvBlocks of MBConv_block (mnasnet.py:116-125) in
+ * one kernel; the t-times expanded tensor is computed into the LDS row rings on the matrix cores and is only written to HBM
+ * when y1 != NULL.  The expand conv's BatchNorm (scale, shift) must be known BEFORE the launch: mnas_gram +
+ * mnas_gram_bn_finalize derive them from the covariance of the block input (y = W a + b is linear in a = act(x)).
+ * Supported: Cin <= 96, C/2-channel-pair blocks of at most 128 channels; otherwise MNAS_EINVAL (use mnas_conv_gemm +
+ * mnas_dw_fwd).  stats: float[2][C][rows], rows = mnas_dw_exp_rows(N,H,W,C,k,Cin,nparts). */
+typedef struct MnasDwExpFwd {
+    int32_t N, H, W, C, k;   /* C = expanded channels (depthwise width) */
+    int32_t Cin, nparts, reserved;
+    MnasActIn x;             /* block input (N,H,W,Cin), act-on-load */
+    const void*  w1;         /* expand weights, MNAS_PACK_FWD [C_pad16][Cin_pad32] */
+    const float* b1;         /* expand bias [C] or NULL */
+    const float* bn1_scale;  /* [C]: BatchNorm of the expand conv (bnbuf rows 0, 1) */
+    const float* bn1_shift;
+    const float* w;          /* depthwise weights fp32 [k*k][C] */
+    const float* bias;       /* depthwise bias [C] or NULL */
+    void*  y1;               /* bf16 (N,H,W,C) raw expand output, or NULL */
+    void*  out;              /* bf16 (N,H,W,C) raw depthwise output */
+    float* stats;
+} MnasDwExpFwd;
+int mnas_dw_exp_fwd(const MnasDwExpFwd* a, void* stream);
+int mnas_dw_exp_rows(int N, int H, int W, int C, int k, int Cin, int nparts);
+
+/* ---- BatchNorm statistics of a 1x1 conv from the second moments of its INPUT (csrc/mnas_gram.hip) ----
+ * mnas_gram: gpart[s][C][C] = sum over the pixels of split s of a a^T, spart[s][C] = sum a, a = act(x) (M pixels, C channels).
+ * mnas_gram_bn_finalize: for y = W a + b (W: fp32 [Co][C], used bf16-rounded like the conv kernels do): batch mean / variance
+ * of y -> bnbuf rows 0,1,5,6, running statistics and num_batches_tracked, exactly as mnas_bn_fwd_finalize(training=1).
+ * scratch: double[C*C + C]. */
+int mnas_gram(const MnasActIn* x, int64_t M, int C, int nsplit, float* gpart, float* spart, void* stream);
+int mnas_gram_bn_finalize(const float* gpart, const float* spart, int nsplit, int C, int Co, double count,
+                          const float* w, const float* bias, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                          float eps, double* scratch, float* bnbuf, void* stream);
+
 typedef struct MnasDwBwd {
     int32_t N, H, W, C, k;
     int32_t nparts;
@@ -274,6 +308,9 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_EVENT_WAIT 16      /* p[0] = event handle: hipStreamWaitEvent(op's stream, event) */
 #define MNAS_OP_PW_BWD 17
 #define MNAS_OP_PACK_BATCH 18
+#define MNAS_OP_GRAM 19
+#define MNAS_OP_GRAM_BN 20
+#define MNAS_OP_DW_EXP_FWD 21
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

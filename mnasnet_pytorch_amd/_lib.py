@@ -48,6 +48,13 @@ class MnasDwBwd(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class MnasDwExpFwd(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
+                ("Cin", C.c_int32), ("nparts", C.c_int32), ("reserved", C.c_int32), ("x", MnasActIn), ("w1", c_void_p),
+                ("b1", c_void_p), ("bn1_scale", c_void_p), ("bn1_shift", c_void_p), ("w", c_void_p), ("bias", c_void_p),
+                ("y1", c_void_p), ("out", c_void_p), ("stats", c_void_p)]
+
+
 class MnasPwBwd(C.Structure):
     _fields_ = [("M", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32), ("nparts", C.c_int32), ("x", MnasActIn),
                 ("dy", MnasGradIn), ("w", c_void_p), ("resid", c_void_p), ("gin", c_void_p), ("wpartial", c_void_p),
@@ -77,6 +84,7 @@ class MnasOp(C.Structure):
 OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
 OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
+OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD = 19, 20, 21
 PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
@@ -93,6 +101,11 @@ SYMBOLS = {
     "mnas_pw_bwd_supported": (c_int, [c_int, c_int]),
     "mnas_dw_fwd": (c_int, [C.POINTER(MnasDwFwd), c_void_p]),
     "mnas_dw_bwd": (c_int, [C.POINTER(MnasDwBwd), c_void_p]),
+    "mnas_dw_exp_fwd": (c_int, [C.POINTER(MnasDwExpFwd), c_void_p]),
+    "mnas_dw_exp_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mnas_gram": (c_int, [C.POINTER(MnasActIn), c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mnas_gram_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "mnas_dw_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mnas_dw_geometry": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_int)]),
     "mnas_dw_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

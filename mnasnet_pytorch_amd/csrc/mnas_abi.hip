@@ -53,6 +53,9 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  NCHW_TO_NHWC     i: N,C,HW                                     p: src,dst
 //  PACK_WEIGHTS     i: kind,Co,Ci,kh,kw                           p: w,dst
 //  PACK_BATCH       i: n                                          p: descs (device array of MnasPackDesc)
+//  GRAM             i: C,nsplit           d: M                    p: x.data,x.scale,x.shift, gpart,spart
+//  GRAM_BN          i: nsplit,C,Co        d: count,momentum,eps   p: gpart,spart,w,bias,gamma,beta,rmean,rvar,nbt,scratch,bnbuf
+//  DW_EXP_FWD       i: N,H,W,C,k,Cin,nparts  p: x.data,x.scale,x.shift, w1,b1,bn1_scale,bn1_shift, w,bias,y1,out,stats
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -87,6 +90,22 @@ static int run_one(const MnasOp& o, void* stream) {
             a.w = p[6]; a.resid = p[7]; a.gin = p[8]; a.wpartial = (float*)p[9];
             a.red_partial = (float*)p[10]; a.red_y = p[11]; a.red_bn = (const float*)p[12];
             return mnas_pw_bwd(&a, stream);
+        }
+        case MNAS_OP_GRAM: {
+            MnasActIn x = {p[0], (const float*)p[1], (const float*)p[2]};
+            return mnas_gram(&x, (int64_t)o.d[0], i[0], i[1], (float*)p[3], (float*)p[4], stream);
+        }
+        case MNAS_OP_GRAM_BN:
+            return mnas_gram_bn_finalize((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], o.d[0], (const float*)p[2],
+                                         (const float*)p[3], (const float*)p[4], (const float*)p[5], (float*)p[6], (float*)p[7],
+                                         (int64_t*)p[8], (float)o.d[1], (float)o.d[2], (double*)p[9], (float*)p[10], stream);
+        case MNAS_OP_DW_EXP_FWD: {
+            MnasDwExpFwd a = {};
+            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.k = i[4]; a.Cin = i[5]; a.nparts = i[6];
+            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
+            a.w1 = p[3]; a.b1 = (const float*)p[4]; a.bn1_scale = (const float*)p[5]; a.bn1_shift = (const float*)p[6];
+            a.w = (const float*)p[7]; a.bias = (const float*)p[8]; a.y1 = p[9]; a.out = p[10]; a.stats = (float*)p[11];
+            return mnas_dw_exp_fwd(&a, stream);
         }
         case MNAS_OP_WGRAD_FINALIZE:
             return mnas_wgrad_finalize((float*)p[0], i[0], i[1], i[2], i[3], (float*)p[1], i[4], stream);

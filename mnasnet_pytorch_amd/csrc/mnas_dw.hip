@@ -43,7 +43,15 @@ struct DwArgs {
     int nt;                                 // nontemporal output stores
 };
 
-static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a) {
+// exp_kpad > 0: geometry for the fused expand+depthwise forms (the workgroup also holds the expand conv's weight block
+// [2*cpw rounded to 16][exp_kpad+8] bf16, bias and input coefficients in LDS; channel blocks of at most 128 channels = 8 MFMA
+// tiles; at most DW_EXP_MAXPG 16-pixel groups of the G x iw ring patch per wave)
+#define DW_EXP_MAXPG 4
+static size_t dw_exp_lds(int cpw, int exp_kpad) {
+    const int rows = (2 * cpw + 15) / 16 * 16;
+    return (size_t)rows * (exp_kpad + 8) * 2 + (size_t)rows * 4 + (size_t)2 * exp_kpad * 4;
+}
+static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a, int exp_kpad = 0) {
     const int cps = C / 2;
     // Search (channel pairs per workgroup, column strips).  Whole pixel when it fits (cps <= 72), otherwise channel
     // blocks of >= 32 pairs (>= 128-byte runs per pixel).  Score = lane utilisation x occupancy / halo.
@@ -56,7 +64,14 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArg
         const int cgn = cpw / 4;
         for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
             const int tw = sx * DW_BW, iw = tw + k - 1;
-            const size_t lds = (size_t)nrings * rr * iw * cpw * 4;
+            size_t lds = (size_t)nrings * rr * iw * cpw * 4;
+            if (exp_kpad > 0) {
+                if (cpw > 64) continue;
+                lds += dw_exp_lds(cpw, exp_kpad);
+                const int nth_ = ((sx * cpw + 63) / 64) * 64;
+                const int npg = ((rr / 2) * iw + 15) / 16;
+                if ((npg + nth_ / 64 - 1) / (nth_ / 64) > DW_EXP_MAXPG) continue;
+            }
             // two workgroups per CU either way (160 KB LDS): wide strips (78 KB) measured 8-10 % faster than 60 KB for
             // every launch form except the 5x5 weight-gradient sweep (3 rings), which is 14 % slower with them
             const size_t cap = (k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024;
@@ -321,6 +336,221 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     }
 }
 
+
+// ---- forward, fused with the preceding 1x1 expand conv (MBConv_block, mnasnet.py:116-125) ------------------------------
+// The ring rows are not copied from HBM: they are COMPUTED from the block input x (Cin channels, the small tensor) on the
+// matrix cores: y1[pixel][c0..c0+cblk) = W1 act(x)[pixel] + b1 for the G x iw patch of the next row group, written to the
+// ring as the same bf16 image the DMA would have delivered.  The expand conv's BatchNorm coefficients (`in.scale/shift`,
+// applied when the depthwise window is read) are known before this kernel runs: mnas_gram + mnas_gram_bn_finalize derive
+// them from the covariance of x.  The x fragments (8 consecutive input channels of one pixel = 16 contiguous bytes in
+// NHWC) go straight from global memory to registers one row group ahead; W1's block is LDS-resident.  With e.y1 == NULL the
+// expanded tensor never reaches HBM; otherwise the workgroup also stores the rows it owns (backward of the unfused form).
+struct DwExp {
+    const uint16_t* x;       // block input (N,H,W,Cin) bf16
+    const float* xs;         // act-on-load coefficients of x ([Cin]) or NULL
+    const float* xt;
+    const uint16_t* w1;      // MNAS_PACK_FWD weights of the expand conv: [C rounded to 16][Kpad]
+    const float* b1;         // [C] or NULL
+    uint32_t* y1;            // raw expand output (N,H,W,C) or NULL
+    int Cin, Kpad;
+};
+
+template <int KS, int G, int KST>
+__global__ __launch_bounds__(256, 2) void k_dw_fwd_exp(DwArgs a, DwExp e, MnasActIn in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, uint32_t* __restrict__ out,
+                                                       float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
+    const int cblk = 2 * a.cpw;
+    const int ntb = (cblk + 15) >> 4;                     // MFMA cout tiles of the channel block
+    const int ldw = e.Kpad + 8;
+    uint32_t* ring = (uint32_t*)smem;                     // [2G][rc*4 dwords]
+    uint16_t* lds_w1 = (uint16_t*)(ring + (size_t)(2 * G) * a.rc * 4);      // [ntb*16][ldw]
+    float* lds_b1 = (float*)(lds_w1 + (size_t)ntb * 16 * ldw);             // [ntb*16]
+    float* lds_xc = lds_b1 + ntb * 16;                                      // [2][Kpad]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int cp = tid % a.cpw, sxi = tid / a.cpw;
+    const bool active = sxi < a.sx;
+    const bool has_coef = in.scale != nullptr, has_xc = e.xs != nullptr;
+    const f2 zero2 = {0.f, 0.f};
+    f2 s1 = zero2, s2 = zero2;
+    f2 wt[KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
+    const int nsteps = (a.H + 2 * PAD + G - 1) / G;
+    const int ps = a.cpw;
+    const int npg = (G * a.iw + 15) >> 4;                 // 16-pixel groups of the G x iw patch
+
+    // ---- per-workgroup constants: its channel block never changes (geff is a multiple of cblocks)
+    const int c0 = ((int)blockIdx.x % a.cblocks) * cblk;
+    {
+        const int ch = c0 + 2 * cp;
+        const bool ch_ok = ch < a.C;
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+            wt[t].x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
+            wt[t].y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
+        }
+        b2.x = (bias && ch_ok) ? bias[ch] : 0.f;
+        b2.y = (bias && ch_ok) ? bias[ch + 1] : 0.f;
+        if (has_coef && ch_ok) { cs.x = in.scale[ch]; cs.y = in.scale[ch + 1]; ct.x = in.shift[ch]; ct.y = in.shift[ch + 1]; }
+        const int kc8n = e.Kpad >> 3, cpad16 = (a.C + 15) / 16 * 16;
+        for (int q = tid; q < ntb * 16 * kc8n; q += blockDim.x) {
+            const int r = q / kc8n, k8 = q - r * kc8n;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < cblk && c0 + r < cpad16) v = *(const uint4*)(e.w1 + (size_t)(c0 + r) * e.Kpad + k8 * 8);
+            *(uint4*)(lds_w1 + r * ldw + k8 * 8) = v;
+        }
+        for (int i = tid; i < ntb * 16; i += blockDim.x) lds_b1[i] = (e.b1 && i < cblk && c0 + i < a.C) ? e.b1[c0 + i] : 0.f;
+        for (int i = tid; i < 2 * e.Kpad; i += blockDim.x) {
+            const int r = i / e.Kpad, c = i - r * e.Kpad;
+            lds_xc[i] = (has_xc && c < e.Cin) ? (r == 0 ? e.xs[c] : e.xt[c]) : 0.f;
+        }
+    }
+    // ---- expand plan: this wave's pixel groups pg = wave + nwaves*i; lane l15 <-> patch pixel pi = pg*16 + l15 = (r, xx)
+    int pr_[DW_EXP_MAXPG], px_[DW_EXP_MAXPG];
+#pragma unroll
+    for (int i = 0; i < DW_EXP_MAXPG; ++i) {
+        const int pi = (wave + nwaves * i) * 16 + l15;
+        pr_[i] = pi / a.iw; px_[i] = pi - pr_[i] * a.iw;
+        if (wave + nwaves * i >= npg || pi >= G * a.iw) pr_[i] = -1;
+    }
+    uint4 xf[DW_EXP_MAXPG][KST];
+    __syncthreads();
+
+    for (int item = blockIdx.x; item < a.items; item += a.geff) {
+        int n, x0, c0i;
+        dw_item(a, item, n, x0, c0i);
+        const int ch = c0 + 2 * cp;
+        const bool ch_ok = ch < a.C;
+        const int gx0 = x0 + sxi * DW_BW;
+        unsigned colmask = 0;
+#pragma unroll
+        for (int xx = 0; xx < WIN_W; ++xx) { const int gx = gx0 - PAD + xx; colmask |= (gx >= 0 && gx < a.W) ? (1u << xx) : 0u; }
+        f2 A[KS][DW_BW];
+#pragma unroll
+        for (int i = 0; i < KS; ++i)
+#pragma unroll
+            for (int j = 0; j < DW_BW; ++j) A[i][j] = b2;
+        uint32_t* outp = out + (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
+        const uint32_t* colp = ring + (size_t)sxi * DW_BW * ps + cp;
+
+        // x fragments of the row group starting at image row r0 (registers; consumed by expand_rows one step later)
+        auto load_x = [&](int r0) {
+#pragma unroll
+            for (int i = 0; i < DW_EXP_MAXPG; ++i) {
+                const int gy = r0 + pr_[i], gx = x0 - PAD + px_[i];
+                const bool ok = pr_[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const uint16_t* src = e.x + (((size_t)n * a.H + gy) * a.W + gx) * e.Cin + lg * 8;
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks)
+                    xf[i][ks] = (ok && ks * 32 + lg * 8 < e.Cin) ? *(const uint4*)(src + ks * 32) : make_uint4(0, 0, 0, 0);
+            }
+        };
+        // y1 rows [r0, r0+G) of the patch -> ring (and, for the pixels this workgroup owns, HBM)
+        auto expand_rows = [&](int r0) {
+#pragma unroll
+            for (int i = 0; i < DW_EXP_MAXPG; ++i) {
+                if (wave + nwaves * i >= npg) break;                      // uniform per wave
+                const int gy = r0 + pr_[i], gx = x0 - PAD + px_[i];
+                const bool ok = pr_[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                bf16x8_t bfrag[KST];
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    uint4 v = xf[i][ks];
+                    if (has_xc && ok) {
+                        const int k = ks * 32 + lg * 8;
+                        float sc[8], sh[8];
+                        *(float4*)&sc[0] = *(const float4*)(lds_xc + k);
+                        *(float4*)&sc[4] = *(const float4*)(lds_xc + k + 4);
+                        *(float4*)&sh[0] = *(const float4*)(lds_xc + e.Kpad + k);
+                        *(float4*)&sh[4] = *(const float4*)(lds_xc + e.Kpad + k + 4);
+                        v = act8(v, sc, sh);
+                        if (k >= e.Cin) v = make_uint4(0, 0, 0, 0);
+                    }
+                    bfrag[ks] = *(const bf16x8_t*)&v;
+                }
+                const bool own = ok && px_[i] >= PAD && px_[i] < PAD + a.sx * DW_BW;
+                uint32_t* ringp = ring + (size_t)dw_slot<2 * G>(gy) * a.rc * 4 + (size_t)px_[i] * a.cgn * 4 + (lg >> 1) * 4 + (lg & 1) * 2;
+                for (int nt = 0; nt < ntb; ++nt) {
+                    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KST; ++ks) {
+                        const bf16x8_t afrag = *(const bf16x8_t*)(lds_w1 + (nt * 16 + l15) * ldw + ks * 32 + lg * 8);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[ks], acc, 0, 0, 0);
+                    }
+                    const int cl = nt * 16 + lg * 4;                      // first of this lane's 4 channels inside the block
+                    const float4 bb = *(const float4*)(lds_b1 + cl);
+                    uint2 pk;
+                    pk.x = pack_bf16(acc[0] + bb.x, acc[1] + bb.y);
+                    pk.y = pack_bf16(acc[2] + bb.z, acc[3] + bb.w);
+                    if (ok && cl < cblk) {
+                        *(uint2*)(ringp + nt * 8) = pk;
+                        if (e.y1 && own && c0 + cl < a.C)
+                            st_u2(e.y1 + (((size_t)n * a.H + gy) * a.W + gx) * a.C / 2 + (c0 + cl) / 2, pk, a.nt);
+                    }
+                }
+            }
+        };
+
+        __syncthreads();                             // previous item's last group consumed
+        load_x(-PAD);
+        expand_rows(-PAD);
+        if (nsteps > 1) load_x(-PAD + G);
+        for (int s = 0; s < nsteps; ++s) {
+            const int r0 = -PAD + s * G;
+            __syncthreads();                         // group s is in the ring; readers of group s-1 are done with the other buffer
+            if (s + 1 < nsteps) {
+                expand_rows(r0 + G);
+                if (s + 2 < nsteps) load_x(r0 + 2 * G);
+            }
+            if (!active) continue;
+#pragma unroll 1
+            for (int j = 0; j < G; ++j) {
+                const int iy = r0 + j;
+                const int oy = iy - PAD;
+                if (iy >= 0 && iy < a.H) {
+                    f2 xr[WIN_W];
+                    dw_read_act<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
+#pragma unroll
+                    for (int i = 0; i < KS; ++i)
+#pragma unroll
+                        for (int ox = 0; ox < DW_BW; ++ox)
+#pragma unroll
+                            for (int kx = 0; kx < KS; ++kx)
+                                A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
+                }
+                if (oy >= 0 && oy < a.H && ch_ok) {
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) {
+                        if (gx0 + ox < a.W) {
+                            const f2 v = A[0][ox];
+                            s1 += v;
+                            s2 = f2fma(v, v, s2);
+                            st_u1(outp + ((size_t)oy * a.W + ox) * a.C / 2, pack_bf16(v.x, v.y), a.nt);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i + 1 < KS; ++i)
+#pragma unroll
+                    for (int ox = 0; ox < DW_BW; ++ox) A[i][ox] = A[i + 1][ox];
+#pragma unroll
+                for (int ox = 0; ox < DW_BW; ++ox) A[KS - 1][ox] = b2;
+            }
+        }
+    }
+    if (stats) {
+        const int rows = a.geff / a.cblocks, col = blockIdx.x / a.cblocks;
+        const f2 sv[2] = {s1, s2};
+        const bool any = (int)blockIdx.x < a.items;
+        dw_block_reduce<2>((float*)ring, sv, cp, sxi, a.sx, cblk, active, [&](int r, int cl, float v) {
+            const int c = c0 + cl;
+            if (c < a.C) stats[((size_t)r * a.C + c) * rows + col] = any ? v : 0.f;
+        });
+    }
+}
+
 // ---- backward: input gradient (DG), weight gradient (WG), fused BN-backward reduce of the producer of x (RED) ----
 // Per image row iy (rows iy of g,y and iy-PAD.. of x are in the rings):
 //   xr = dy row iy, k+3 columns  -> DG: scattered into the register ring A of KS partial gin rows (flipped filter);
@@ -553,10 +783,10 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 static int dw_rings(int form) { return form < 0 ? 1 : (form == 1 ? 2 : 3); }      // form: -1 forward, else phase
 // Pick rows-per-group G in {4, 2} and the strip geometry for a launch form: 2-row groups halve the ring footprint (wider
 // strips / more channels per workgroup) at the price of a barrier every 2 rows instead of 4 (priced at 7 %).
-static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g) {
+static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g, int exp_kpad = 0) {
     DwArgs a4, a2;
     const int nrings = dw_rings(form);
-    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2);
+    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4, exp_kpad), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2, exp_kpad);
     if (!ok4 && !ok2) return false;
     if (ok2 && (!ok4 || 0.93f * a2.score > a4.score)) { *a = a2; *g = 2; }
     else { *a = a4; *g = 4; }
@@ -607,6 +837,45 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     if (c->k == 3) { if (g == 4) MNAS_DWF(3, 4); else MNAS_DWF(3, 2); }
     else { if (g == 4) MNAS_DWF(5, 4); else MNAS_DWF(5, 2); }
 #undef MNAS_DWF
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// Fused expand (1x1, Cin -> C) + depthwise forward.  Geometry differs from the plain forward (LDS also holds the expand
+// weights): rows of the statistics table = mnas_dw_exp_rows(...).  Supported: Cin <= 96 (three MFMA k-steps); returns
+// MNAS_EINVAL otherwise (callers fall back to mnas_conv_gemm + mnas_dw_fwd).
+extern "C" int mnas_dw_exp_rows(int N, int H, int W, int C, int k, int Cin, int nparts) {
+    if (Cin < 8 || (Cin & 7) || Cin > 96) return -1;
+    DwArgs a;
+    int g;
+    if (!dw_choose(N, H, W, C, k, -1, &a, &g, (Cin + 31) / 32 * 32) || !dw_finish(&a, nparts)) return -1;
+    return a.geff / a.cblocks;
+}
+
+extern "C" int mnas_dw_exp_fwd(const MnasDwExpFwd* c, void* stream) {
+    if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1 || c->Cin < 8 || (c->Cin & 7) || c->Cin > 96) return MNAS_EINVAL;
+    if (!c->x.data || !c->w1 || !c->w || !c->out) return MNAS_EINVAL;
+    DwArgs a;
+    int g;
+    const int kpad = (c->Cin + 31) / 32 * 32;
+    if (!dw_choose(c->N, c->H, c->W, c->C, c->k, -1, &a, &g, kpad) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
+    a.nt = (mnas_nt_mask() & MNAS_NT_DW_FWD) ? 1 : 0;
+    DwExp e;
+    e.x = (const uint16_t*)c->x.data; e.xs = c->x.scale; e.xt = c->x.shift;
+    e.w1 = (const uint16_t*)c->w1; e.b1 = c->b1; e.y1 = (uint32_t*)c->y1; e.Cin = c->Cin; e.Kpad = kpad;
+    MnasActIn in = {nullptr, c->bn1_scale, c->bn1_shift};
+    size_t lds = (size_t)2 * g * a.rc * 16 + dw_exp_lds(a.cpw, kpad);
+    const size_t red_need = (size_t)a.sx * 2 * 2 * a.cpw * sizeof(float);
+    if (lds < red_need) lds = red_need;
+    hipStream_t s = (hipStream_t)stream;
+    const int kst = kpad / 32;
+#define MNAS_DWE(K_, G_, T_) hipLaunchKernelGGL((k_dw_fwd_exp<K_, G_, T_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, e, in, c->w, \
+                                               c->bias, (uint32_t*)c->out, c->stats)
+#define MNAS_DWE_T(K_, G_) do { if (kst == 1) MNAS_DWE(K_, G_, 1); else if (kst == 2) MNAS_DWE(K_, G_, 2); else MNAS_DWE(K_, G_, 3); } while (0)
+    if (c->k == 3) { if (g == 4) MNAS_DWE_T(3, 4); else MNAS_DWE_T(3, 2); }
+    else { if (g == 4) MNAS_DWE_T(5, 4); else MNAS_DWE_T(5, 2); }
+#undef MNAS_DWE_T
+#undef MNAS_DWE
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }

@@ -245,6 +245,48 @@ class Program:
             records.append(("conv", ci, a_in, out, Hi, Wi))
             return out
 
+        def block_fwd_fused(e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
+            """expand (1x1) + depthwise of an MBConv_block in ONE kernel (csrc/mnas_dw.hip, EXP forms): the expand conv's
+            BatchNorm statistics come from the covariance of the block input (csrc/mnas_gram.hip), so the expanded tensor
+            is produced straight into the depthwise kernel's LDS rings.  It is still written to HBM in training (backward
+            reads it); in eval mode it never leaves the chip.  Returns the depthwise output, or None if unsupported."""
+            M = N * Hi * Wi
+            C_, k = d_ci.cout, d_ci.k
+            nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * C_, 256 * 16 * 2)))
+            rows = lib.mnas_dw_exp_rows(N, Hi, Wi, C_, k, e_ci.cin, nlaunch)
+            if rows < 1:
+                return None
+            econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
+            bn_e, bn_d = bnbuf(C_), bnbuf(C_)
+            if training:
+                nsplit = max(1, min(512, _cdiv(M, 2048)))
+                fwd.add(L.OP_GRAM, [e_ci.cin, nsplit], [float(M)], a_in.act_ptrs() + [eng.scratch_gram.data_ptr(), eng.scratch_gram_s.data_ptr()])
+                fwd.add(L.OP_GRAM_BN, [nsplit, e_ci.cin, C_], [float(M), ebn.momentum, ebn.eps],
+                        [eng.scratch_gram.data_ptr(), eng.scratch_gram_s.data_ptr(), econv.weight.data_ptr(),
+                         econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
+                         ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
+                         eng.scratch_gram_d.data_ptr(), bn_e.data_ptr()])
+            else:
+                fwd.add(L.OP_BN_FWD_FINALIZE, [1, C_, 0], [float(M), ebn.momentum, ebn.eps],
+                        [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
+                         ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
+            y1 = new((N, Hi, Wi, C_)) if training else None
+            y2 = new((N, Hi, Wi, C_))
+            stats = eng.scratch_stats.data_ptr() if training else None
+            fwd.add(L.OP_DW_EXP_FWD, [N, Hi, Wi, C_, k, e_ci.cin, nlaunch], [],
+                    a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                                       bn_e.data_ptr(), bn_e.data_ptr() + 4 * C_, d_ci.w_fwd.data_ptr(),
+                                       dconv.bias.data_ptr() if dconv.bias is not None else None,
+                                       y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
+            fwd.add(L.OP_BN_FWD_FINALIZE, [rows, C_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
+                    [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
+                     dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
+            h1 = _Act(y1, bn_e, Hi, Wi, C_)
+            h2 = _Act(y2, bn_d, Hi, Wi, C_)
+            records.append(("conv", e_ci, a_in, h1, Hi, Wi))
+            records.append(("conv", d_ci, h1, h2, Hi, Wi))
+            return h2
+
         step_records = []
         for op, m, stage in steps:
             start = len(records)
@@ -255,9 +297,16 @@ class Program:
                 step_records.append(("conv", stage, start, None, None))
             else:
                 a_in = cur
-                h = cur
-                for cb in m:
-                    h = conv_fwd(eng.info[id(cb)], h, Hc, Wc)
+                h = None
+                cis = [eng.info[id(cb)] for cb in m]
+                if eng.fuse_expand and len(cis) == 3 and cis[0].kind == "pw" and cis[1].kind == "dw" and cis[2].kind == "pw":
+                    h = block_fwd_fused(cis[0], cis[1], a_in, Hc, Wc)
+                    if h is not None:
+                        h = conv_fwd(cis[2], h, Hc, Wc)
+                if h is None:
+                    h = cur
+                    for ci_ in cis:
+                        h = conv_fwd(ci_, h, Hc, Wc)
                 r = new((N, Hc, Wc, a_in.C))
                 fwd.add(L.OP_ADD_ACT, [a_in.C, Hc * Wc], [float(N * Hc * Wc)],
                         a_in.act_ptrs() + h.act_ptrs() + [r.data_ptr(), None])
@@ -576,6 +625,11 @@ class Engine:
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        # MBConv_block: expand + depthwise forward in ONE kernel (statistics from the input's covariance, csrc/mnas_gram.hip).
+        # Validated bit-identical to the unfused pair, but measured SLOWER at bs 256 (14.7 vs 13.05 ms/step): the depthwise
+        # sweeps are latency/issue-bound, not HBM-bound, so removing the expanded tensor's read does not pay for the MFMA stage
+        # and the halved occupancy (166-250 VGPRs); see DESIGN.md.  Kept as an opt-in (eval mode never writes the expanded tensor).
+        self.fuse_expand = False
         # depthwise kernel sizes whose backward runs as ONE fused sweep (input gradient + weight gradient + reduce).  5x5 too:
         # with 2-row DMA groups the fused form gets full-width strips and beats the two launches (155 vs 210 us at 56x56)
         # although it needs all 256 VGPRs; (3,) selects the split form (input gradient on main, weight gradient on side)
@@ -631,6 +685,10 @@ class Engine:
         self.scratch_wgrad = torch.empty(wmax, dtype=torch.float32, device=device)
         self.scratch_wgrad2 = torch.empty(wmax, dtype=torch.float32, device=device)
         self.scratch_red = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)   # fused BN-bwd partials
+        cmax = max(ci.cin for ci in self.convs)
+        self.scratch_gram = torch.empty(512 * cmax * cmax, dtype=torch.float32, device=device)         # mnas_gram partials
+        self.scratch_gram_s = torch.empty(512 * cmax, dtype=torch.float32, device=device)
+        self.scratch_gram_d = torch.empty(cmax * cmax + cmax, dtype=torch.float64, device=device)
         if self._ext_grad is not None:
             self.flat_grad = self._ext_grad
         else:
