@@ -183,6 +183,39 @@ __device__ __forceinline__ void dw_read_act(const uint32_t* rowp, int ps, bool h
     }
 }
 
+// The same without the per-column select: the FORWARD sweep fills the out-of-image columns of its ring with a value that
+// activates to zero (dw_fill_edges), so the row body carries no selects (the sweeps are VALU-issue bound: SQ_ACTIVE_INST_VALU x
+// waves per SIMD = 75-100 %, profiles/r02_sq_counters.txt; the selects were 12-16 % of the 5x5 row body).
+template <int WIN_W>
+__device__ __forceinline__ void dw_read_act_nm(const uint32_t* rowp, int ps, bool has_coef, f2 s, f2 t, f2 (&xr)[WIN_W]) {
+#pragma unroll
+    for (int xx = 0; xx < WIN_W; ++xx) {
+        f2 v = f2bf(rowp[xx * ps]);
+        if (has_coef) {
+            v = f2fma(v, s, t);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);       // v_max_f32(qNaN, 0) = 0 (IEEE maxNum)
+        }
+        xr[xx] = v;
+    }
+}
+// Ring chunks of image columns outside [0, W) are never written by the DMA: give them, in every ring row, the bf16 pattern
+// that reads as 0 after act-on-read -- a quiet NaN when relu(s*x+t) is applied (max(fma(NaN,s,t), 0) = 0 whatever the
+// sign of s), plain zero for a materialised input.  Once per item (the columns depend on the strip only).
+template <int RR>
+__device__ __forceinline__ void dw_fill_edges(const DwArgs& a, const DwDma& p, uint32_t* ring, int wave, int nwaves, int lane,
+                                              bool has_coef) {
+    const uint32_t f = has_coef ? 0x7fc07fc0u : 0u;
+    const uint4 f4 = make_uint4(f, f, f, f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int b = wave + j * nwaves, q = b * 64 + lane;
+        if (b < a.nb && q < a.rc && !p.ok[j]) {
+#pragma unroll
+            for (int r = 0; r < RR; ++r) ((uint4*)ring)[(size_t)r * a.rc + q] = f4;
+        }
+    }
+}
+
 // window row of dy = c1*(g*[s*y+t>0]) + c2*y + c3, zero outside the image columns.  cf = {s,t,c1,c2,c3}
 template <int WIN_W>
 __device__ __forceinline__ void dw_read_dy(const uint32_t* growp, const uint32_t* yrowp, int ps, const f2 (&cf)[5],
@@ -264,9 +297,6 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         DwDma plan;
         dw_dma_plan<KS>(a, plan, wave, nwaves, lane, x0, c0);
         const int gx0 = x0 + sxi * DW_BW;
-        unsigned colmask = 0;
-#pragma unroll
-        for (int xx = 0; xx < WIN_W; ++xx) { const int gx = gx0 - PAD + xx; colmask |= (gx >= 0 && gx < a.W) ? (1u << xx) : 0u; }
         // register ring of KS partial output rows: A[i] = output row (iy - PAD + i) while input row iy is processed
         f2 A[KS][DW_BW];
 #pragma unroll
@@ -281,6 +311,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         // step (dma_barrier: vmcnt(0) then s_barrier): it publishes group s and retires the readers of group s-1, whose
         // buffer the next DMA overwrites.
         __syncthreads();                             // previous item's last group consumed
+        dw_fill_edges<2 * G>(a, plan, ring, wave, nwaves, lane, has_coef);
         dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
@@ -293,7 +324,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
                 const int oy = iy - PAD;             // A[0] is complete after this row
                 if (iy >= 0 && iy < a.H) {           // uniform: rows outside the image contribute nothing
                     f2 xr[WIN_W];
-                    dw_read_act<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
+                    dw_read_act_nm<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, xr);
 #pragma unroll
                     for (int i = 0; i < KS; ++i)
 #pragma unroll
