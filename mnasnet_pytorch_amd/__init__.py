@@ -8,5 +8,7 @@ ReLU arithmetic runs in hand-written HIP kernels behind the C ABI in include/mna
 from . import _lib  # noqa: F401
 from .mnasnet import ConvBlock, MBConv, MBConv_block, Mnasnet, SepConv  # noqa: F401
 from .classifiers import FineTuneModelPool, load_model  # noqa: F401
+from .sampler import ClusterRandomSampler, DistributedClusterSampler  # noqa: F401
 
-__all__ = ["Mnasnet", "ConvBlock", "SepConv", "MBConv_block", "MBConv", "load_model", "FineTuneModelPool"]
+__all__ = ["Mnasnet", "ConvBlock", "SepConv", "MBConv_block", "MBConv", "load_model", "FineTuneModelPool",
+           "ClusterRandomSampler", "DistributedClusterSampler"]
