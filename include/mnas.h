@@ -266,6 +266,11 @@ int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count,
  * with rows = N*HW (the features output handed to AdaptiveAvgPool2d, classifiers.py:109). */
 int mnas_add_act(const MnasActIn* a, const MnasActIn* b, int64_t rows, int C, void* out_bf16,
                  float* out_nchw_f32, int HW, void* stream);
+/* Global average pool fused with the last BatchNorm+ReLU: out[n][c] (fp32) = mean over the HW pixels of act(a)[n][.][c]
+ * (classifiers.py:49,109: AdaptiveAvgPool2d(1) on the features output, which is then never materialised), and its backward:
+ * g[n][hw][c] (bf16 NHWC) = gpool[n][c] / HW. */
+int mnas_pool_act(const MnasActIn* a, int N, int HW, int C, float* out, void* stream);
+int mnas_pool_bwd(const float* gpool, int N, int HW, int C, void* g_bf16, void* stream);
 /* bf16 NHWC <- fp32 NCHW  (incoming gradient of the features output) */
 int mnas_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int HW, void* stream);
 
@@ -311,6 +316,8 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_GRAM 19
 #define MNAS_OP_GRAM_BN 20
 #define MNAS_OP_DW_EXP_FWD 21
+#define MNAS_OP_POOL_ACT 22
+#define MNAS_OP_POOL_BWD 23
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

@@ -42,6 +42,7 @@ class FineTuneModelPool(nn.Module):
                                             nn.Dropout(), nn.Linear(512, num_classes))
         else:
             raise ValueError("Finetuning not supported on this architecture yet")
+        self.fuse_pool = True        # see forward()
         self.mean = (0.485, 0.456, 0.406)
         self.std = (0.229, 0.224, 0.225)
 
@@ -55,7 +56,17 @@ class FineTuneModelPool(nn.Module):
         for p in self.features.parameters():
             p.requires_grad = True
 
+    def _pool_is_global_average(self):
+        if len(self.pooling) != 1 or not isinstance(self.pooling[0], nn.AdaptiveAvgPool2d):
+            return False
+        return self.pooling[0].output_size in (1, (1, 1))
+
     def forward(self, x):
-        f = self.features(x)
-        f = self.pooling(f)
+        # classifiers.py:107-111.  features -> AdaptiveAvgPool2d(1) -> flatten is ONE engine call: the pool is fused with the
+        # last BatchNorm+ReLU (mnas_pool_act) and the N x 320 x H/32 x W/32 fp32 feature map is never materialised; backward
+        # starts from the pooled gradient (mnas_pool_bwd).  Any other pooling module takes the two-step path.
+        if self.fuse_pool and hasattr(self.features, "_engine") and self._pool_is_global_average():
+            f = self.features._engine().forward(x, pooled=True)
+        else:
+            f = self.pooling(self.features(x))
         return self.classifier(f.view(f.size(0), -1))

@@ -56,6 +56,8 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  GRAM             i: C,nsplit           d: M                    p: x.data,x.scale,x.shift, gpart,spart
 //  GRAM_BN          i: nsplit,C,Co        d: count,momentum,eps   p: gpart,spart,w,bias,gamma,beta,rmean,rvar,nbt,scratch,bnbuf
 //  DW_EXP_FWD       i: N,H,W,C,k,Cin,nparts  p: x.data,x.scale,x.shift, w1,b1,bn1_scale,bn1_shift, w,bias,y1,out,stats
+//  POOL_ACT         i: N,HW,C                                     p: a.data,a.scale,a.shift, out
+//  POOL_BWD         i: N,HW,C                                     p: gpool, g
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -155,6 +157,12 @@ static int run_one(const MnasOp& o, void* stream) {
             MnasActIn b = {p[3], (const float*)p[4], (const float*)p[5]};
             return mnas_add_act(&a, &b, (int64_t)o.d[0], i[0], p[6], (float*)p[7], i[1], stream);
         }
+        case MNAS_OP_POOL_ACT: {
+            MnasActIn a = {p[0], (const float*)p[1], (const float*)p[2]};
+            return mnas_pool_act(&a, i[0], i[1], i[2], (float*)p[3], stream);
+        }
+        case MNAS_OP_POOL_BWD:
+            return mnas_pool_bwd((const float*)p[0], i[0], i[1], i[2], p[1], stream);
         case MNAS_OP_NCHW_TO_NHWC:
             return mnas_nchw_f32_to_nhwc_bf16((const float*)p[0], p[1], i[0], i[1], i[2], stream);
         case MNAS_OP_PACK_WEIGHTS:

@@ -256,6 +256,74 @@ extern "C" int mnas_add_act(const MnasActIn* a, const MnasActIn* b, int64_t rows
     return MNAS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Global average pool of the features output, fused with the last ConvBlock's BatchNorm+ReLU: out[n][c] = mean_hw act(a)
+// (classifiers.py:49,109: AdaptiveAvgPool2d(1) on features(x)) -- the 16 MB fp32 NCHW feature map is never written.
+// One workgroup per image; thread = (channel group of 8, row lane); row lanes combined through LDS in fixed order.
+// Backward: g[n][hw][c] = gpool[n][c] / HW as bf16 NHWC (the gradient of the features output the engine's backward starts from).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool_act(MnasActIn a, int HW, int C, float* __restrict__ out) {
+    extern __shared__ float red[];            // [R][C]
+    const int G = C >> 3, R = 256 / G;
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const int cg = tid % G, rl = tid / G;
+    if (tid < R * G) {
+        float sa[8], ta[8], acc[8];
+        const bool ha = a.scale != nullptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sa[j] = ha ? a.scale[cg * 8 + j] : 1.f;
+            ta[j] = ha ? a.shift[cg * 8 + j] : 0.f;
+            acc[j] = 0.f;
+        }
+        const uint4* p = (const uint4*)a.data + (size_t)n * HW * G;
+        for (int r = rl; r < HW; r += R) {
+            float f[8];
+            unpack8(p[(size_t)r * G + cg], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += ha ? fmaxf(fmaf(f[j], sa[j], ta[j]), 0.f) : f[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[rl * C + cg * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float v = red[c];
+        for (int rl2 = 1; rl2 < R; ++rl2) v += red[rl2 * C + c];
+        out[(size_t)n * C + c] = v / (float)HW;
+    }
+}
+extern "C" int mnas_pool_act(const MnasActIn* a, int N, int HW, int C, float* out, void* stream) {
+    if (!a || !a->data || !out || N < 1 || HW < 1 || C <= 0 || (C & 7) || C > 2048) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_pool_act, dim3(N), dim3(256), (size_t)(256 / (C >> 3)) * C * sizeof(float), (hipStream_t)stream, *a, HW,
+                       C, out);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+__global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ gpool, int HW, int C, uint4* __restrict__ g,
+                                                  int64_t total) {
+    const int G = C >> 3;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(i % G);
+        const int64_t n = i / ((int64_t)G * HW);
+        const float* src = gpool + n * C + cg * 8;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = src[j] * inv;
+        g[i] = pack8(f);
+    }
+}
+extern "C" int mnas_pool_bwd(const float* gpool, int N, int HW, int C, void* g_bf16, void* stream) {
+    if (!gpool || !g_bf16 || N < 1 || HW < 1 || C <= 0 || (C & 7)) return MNAS_EINVAL;
+    const int64_t total = (int64_t)N * HW * (C >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pool_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpool, HW, C, (uint4*)g_bf16, total);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ src, uint4* __restrict__ dst, int N,
                                                       int C, int HW) {
     const int G = C >> 3;

@@ -160,8 +160,9 @@ class _OpList:
 class Program:
     """All buffers + launch lists for one (N, H, W, training, need_dx) configuration."""
 
-    def __init__(self, eng: "Engine", N, H, W, training, need_dx):
+    def __init__(self, eng: "Engine", N, H, W, training, need_dx, pooled=False):
         self.eng, self.N, self.H, self.W, self.training, self.need_dx = eng, N, H, W, training, need_dx
+        self.pooled = pooled
         self.busy = False
         dev = eng.device
         self.keep = []                      # tensors owned by this program
@@ -312,11 +313,17 @@ class Program:
                         a_in.act_ptrs() + h.act_ptrs() + [r.data_ptr(), None])
                 cur = _Act(r, None, Hc, Wc, a_in.C)
                 step_records.append(("block", stage, start, a_in, cur))
-        # ---- features output: fp32 NCHW (classifiers.py:109 consumes it)
-        self.out_shape = (N, cur.C, cur.H, cur.W)
-        j = fwd.add(L.OP_ADD_ACT, [cur.C, cur.H * cur.W], [float(N * cur.H * cur.W)],
-                    cur.act_ptrs() + [None, None, None, None, None])
-        self.patch_out = (j, 7)
+        # ---- features output: fp32 NCHW (classifiers.py:109 consumes it), or, pooled, its global average [N][C]
+        # (AdaptiveAvgPool2d(1) fused with the last BatchNorm+ReLU: the feature map is never written)
+        if pooled:
+            self.out_shape = (N, cur.C)
+            j = fwd.add(L.OP_POOL_ACT, [N, cur.H * cur.W, cur.C], [], cur.act_ptrs() + [None])
+            self.patch_out = (j, 3)
+        else:
+            self.out_shape = (N, cur.C, cur.H, cur.W)
+            j = fwd.add(L.OP_ADD_ACT, [cur.C, cur.H * cur.W], [float(N * cur.H * cur.W)],
+                        cur.act_ptrs() + [None, None, None, None, None])
+            self.patch_out = (j, 7)
         self.fwd_ops, self.fwd_n = fwd.build()
         self.final = cur
 
@@ -337,7 +344,10 @@ class Program:
 
         last_stage = step_records[-1][1]
         g_final = new((N, cur.H, cur.W, cur.C))
-        j = seg(last_stage).add(L.OP_NCHW_TO_NHWC, [N, cur.C, cur.H * cur.W], [], [None, g_final.data_ptr()])
+        if pooled:
+            j = seg(last_stage).add(L.OP_POOL_BWD, [N, cur.H * cur.W, cur.C], [], [None, g_final.data_ptr()])
+        else:
+            j = seg(last_stage).add(L.OP_NCHW_TO_NHWC, [N, cur.C, cur.H * cur.W], [], [None, g_final.data_ptr()])
         self.patch_gout = (last_stage, j, 0)
 
         def conv_bwd(ops: _OpList, rec, g, resid, need_gin, g_reduced=False, red_target=None):
@@ -555,10 +565,10 @@ class _Lease:
 
 class _EngineFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, track, x, *params):
+    def forward(ctx, eng, track, pooled, x, *params):
         need_dx = track and x.requires_grad
         training = eng.root.training
-        prog = eng.program(x.shape[0], x.shape[2], x.shape[3], training, need_dx)
+        prog = eng.program(x.shape[0], x.shape[2], x.shape[3], training, need_dx, pooled)
         out = prog.run_forward(x)
         ctx.eng = eng
         ctx.lease = _Lease(prog) if (training and track) else None
@@ -582,7 +592,7 @@ class _EngineFn(torch.autograd.Function):
         finally:
             lease.consumed = True
             lease.release()
-        return (None, None, dx) + (None,) * len(eng.params)
+        return (None, None, None, dx) + (None,) * len(eng.params)
 
 
 class Engine:
@@ -780,8 +790,8 @@ class Engine:
     def gptr(self, ci: _ConvInfo, j: int):
         return self.flat_grad.data_ptr() + 4 * ci.gslice[j][0]
 
-    def program(self, N, H, W, training, need_dx) -> Program:
-        key = (N, H, W, training, need_dx)
+    def program(self, N, H, W, training, need_dx, pooled=False) -> Program:
+        key = (N, H, W, training, need_dx, pooled)
         lst = self.programs.setdefault(key, [])
         for p in lst:
             if not p.busy:
@@ -791,7 +801,7 @@ class Engine:
                 "%d forwards of shape %s are alive at once (their autograd graphs are still referenced and no backward "
                 "has run): each holds a full set of activation buffers.  Drop the old outputs / call backward, or run "
                 "under torch.no_grad()." % (len(lst), (N, self.in_channels_hint, H, W)))
-        p = Program(self, N, H, W, training, need_dx)
+        p = Program(self, N, H, W, training, need_dx, pooled)
         lst.append(p)
         return p
 
@@ -826,7 +836,8 @@ class Engine:
                 p.grad.add_(v)          # a foreign .grad tensor: add into it, like AccumulateGrad
 
     # ---- entry point ------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pooled: bool = False) -> torch.Tensor:
+        """pooled=True returns the global average of the features, [N, C] fp32 (AdaptiveAvgPool2d(1) + flatten fused in)."""
         if not x.is_cuda:
             raise RuntimeError("mnasnet_pytorch_amd runs on MI355X only: got a %s tensor; there is no CPU/eager "
                                "fallback (use oracle/ in tests for a CPU reference)" % x.device)
@@ -843,4 +854,4 @@ class Engine:
         x = x.float().contiguous()          # train.py:427 input.float()
         self.ensure_setup(x.device)
         self._check_modes()
-        return _EngineFn.apply(self, track, x, *self.params)
+        return _EngineFn.apply(self, track, bool(pooled), x, *self.params)

@@ -216,3 +216,32 @@ def test_flat_adam_is_a_torch_optimizer():
     l_b = float(tr2.step(x, target))
     assert l_a == l_b
     assert torch.equal(tr.flat_p, tr2.flat_p)
+
+
+def test_fused_pool_matches_two_step_path():
+    """FineTuneModelPool.forward with the global average pool fused into the engine (mnas_pool_act / mnas_pool_bwd) ==
+    the two-step path features -> AdaptiveAvgPool2d(1): logits to 1e-5 (fp32 mean, different summation order), every
+    gradient to 2e-3 relative L2 (the backward differs only in where g/HW is rounded to bf16)."""
+    x = C.det_input((4, 3, 96, 64)).cuda()
+    target = torch.tensor([1, 3, 5, 7]).cuda()
+    res = []
+    for fuse in (True, False):
+        m = build("512", proj_gamma=0.1).train(); _no_dropout(m)
+        m.fuse_pool = fuse
+        out = m(x)
+        torch.nn.CrossEntropyLoss()(out, target).backward()
+        res.append((out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    assert rl2(res[0][0].cpu(), res[1][0].cpu()) < 1e-5
+    for k in res[0][1]:
+        if k.endswith("conv.bias"):
+            continue
+        a, b = res[0][1][k], res[1][1][k]
+        assert rl2(a.cpu(), b.cpu()) < 2e-3 or float((a - b).abs().max()) < 1e-7, k
+    # eval mode too
+    m = build("512").eval()
+    with torch.no_grad():
+        m.fuse_pool = True
+        a = m(x)
+        m.fuse_pool = False
+        b = m(x)
+    assert rl2(a.cpu(), b.cpu()) < 1e-5
