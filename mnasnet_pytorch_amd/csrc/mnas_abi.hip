@@ -22,6 +22,15 @@ int mnas_pwf_enabled() {
     return on;
 }
 
+int mnas_pws_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("MNAS_PWS");
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
+
 extern "C" int mnas_version(void) { return 1; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 

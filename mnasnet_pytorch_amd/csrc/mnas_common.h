@@ -92,6 +92,10 @@ int mnas_nt_mask();
 int mnas_pwf_enabled();
 int mnas_pwf_parts(int M, int Ci, int Co);
 int mnas_pwf_forward(const MnasConvGemm* c, void* stream);
+// K-streaming 1x1 GEMM (mnas_pws.hip): long-K forward / input gradient on the small-M stages, unless MNAS_PWS=0
+int mnas_pws_enabled();
+int mnas_pws_parts(int mode, int M, int K, int N);
+int mnas_pws_run(const MnasConvGemm* c, void* stream);
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

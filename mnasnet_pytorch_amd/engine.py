@@ -427,7 +427,9 @@ class Program:
                 if need_gin:
                     gin = new((N, Hi, Wi, ci.cin))
                     Min = N * Hi * Wi
-                    nparts = max(1, min(1024, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
+                    nparts = lib.mnas_conv_gemm_parts(1, Min, Co, ci.cin, ci.k * ci.k)
+                    if nparts < 1:
+                        nparts = max(1, min(1024, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
                     red = [None, None, None]
                     if rt is not None:
                         red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
