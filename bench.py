@@ -71,7 +71,7 @@ def class_key(opc, ints, L):
     names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_conv<fwd>", L.OP_DW_BWD: "k_dw_bwd",
              L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
              L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd", L.OP_GRAM: "k_gram", L.OP_DW_EXP_FWD: "k_dw_fwd_exp",
-             L.OP_POOL_ACT: "k_pool", L.OP_POOL_BWD: "k_pool"}
+             L.OP_POOL_ACT: "k_pool", L.OP_POOL_BWD: "k_pool", L.OP_DY_MAT: "k_dy_mat"}
     if opc == L.OP_CONV_GEMM:
         return "k_igemm<dgrad>" if ints[0] == 1 else "k_igemm<fwd>"
     if opc == L.OP_DW_BWD:          # i: N,H,W,C,k,nparts,phase (1 = input gradient, 2 = weight gradient launch)
@@ -109,7 +109,7 @@ def launch_work(opc, ints, L):
         px = N_ * H_ * W_
         nbytes = 2 * (px * Ci + px * C_) + 2 * 2 * px * C_
         flops = 2.0 * px * C_ * Ci + 2.0 * px * C_ * k_ * k_
-    elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT, L.OP_GRAM, L.OP_POOL_ACT, L.OP_POOL_BWD):
+    elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT, L.OP_GRAM, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT):
         nbytes, flops = 0, 0.0      # pure overhead in SURVEY 8(d)'s accounting
     else:                           # stem fwd / wgrad: fp32 image + bf16 output
         N_, H_, W_, Ho, Wo, Co = ints[:6]
@@ -211,13 +211,15 @@ def main():
     eng = trainer.engine
     if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
         eng.use_side_stream = False
+    if os.environ.get("MNAS_NO_DYMAT"):      # diagnosis only: dense 3x3 backward forms dy on load (two reads + transform per gather)
+        eng.materialize_dy = False
     if os.environ.get("MNAS_FUSE"):          # diagnosis only: fused expand + depthwise forward kernels (measured slower)
         eng.fuse_expand = True
     if os.environ.get("MNAS_DW5_SPLIT"):     # diagnosis only: two-launch backward for the 5x5 depthwise layers
         eng.dw_fused_k = (3,)
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
-               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD}
+               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT}
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size

@@ -48,7 +48,7 @@ typedef struct MnasActIn {
     const float* shift;   /* [C] or NULL */
 } MnasActIn;
 
-/* "dy-on-load" input: dy = c1*(g*[s*y+t>0]) + c2*y + c3, coef = bnbuf rows 0..4 */
+/* "dy-on-load" input: dy = c1*(g*[s*y+t>0]) + c2*y + c3, coef = bnbuf rows 0..4.  y == NULL && coef == NULL: g IS dy. */
 typedef struct MnasGradIn {
     const void*  g;       /* bf16 NHWC: dL/d(activated output) */
     const void*  y;       /* bf16 NHWC: saved raw conv output */
@@ -256,6 +256,10 @@ int mnas_bn_fwd_finalize(const float* partial, int nparts, int C, double count,
  * dz = g*[s*y+t>0], xhat = (y-mean)*invstd.  g,y: bf16 [rows][C]. */
 int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnbuf, int64_t rows, int C,
                        int nparts, float* partial, void* stream);
+/* out[rows][C] (bf16) = dy-on-load of (g, y, coef), materialised once.  mnas_conv_gemm(mode 1) and mnas_conv_wgrad accept the
+ * result as a PLAIN gradient: grad.g = out, grad.y = grad.coef = NULL (no transform on load).  Used for the dense 3x3 convs,
+ * whose kernels gather every dy element 2.25-10 times. */
+int mnas_dy_materialize(const MnasGradIn* d, int64_t rows, int C, void* out_bf16, void* stream);
 /* dgamma (+)= sum dz*xhat ; dbeta (+)= sum dz ; bnbuf rows 2..4 = c1,c2,c3 */
 int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count,
                          float* bnbuf, float* dgamma, float* dbeta, int accumulate, void* stream);
@@ -318,6 +322,7 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_DW_EXP_FWD 21
 #define MNAS_OP_POOL_ACT 22
 #define MNAS_OP_POOL_BWD 23
+#define MNAS_OP_DY_MAT 24
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

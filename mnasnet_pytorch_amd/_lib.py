@@ -84,7 +84,7 @@ class MnasOp(C.Structure):
 OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
 OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
-OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD = 19, 20, 21, 22, 23
+OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
 PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
@@ -114,6 +114,7 @@ SYMBOLS = {
     "mnas_bn_fwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_float, c_float, c_int, c_void_p, c_void_p]),
     "mnas_bn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_dy_materialize": (c_int, [C.POINTER(MnasGradIn), c_int64, c_int, c_void_p, c_void_p]),
     "mnas_bn_bwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mnas_add_act": (c_int, [C.POINTER(MnasActIn), C.POINTER(MnasActIn), c_int64, c_int, c_void_p, c_void_p, c_int,
                              c_void_p]),

@@ -67,6 +67,7 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  DW_EXP_FWD       i: N,H,W,C,k,Cin,nparts  p: x.data,x.scale,x.shift, w1,b1,bn1_scale,bn1_shift, w,bias,y1,out,stats
 //  POOL_ACT         i: N,HW,C                                     p: a.data,a.scale,a.shift, out
 //  POOL_BWD         i: N,HW,C                                     p: gpool, g
+//  DY_MAT           i: C                  d: rows                 p: g,y,coef,out
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -169,6 +170,10 @@ static int run_one(const MnasOp& o, void* stream) {
         case MNAS_OP_POOL_ACT: {
             MnasActIn a = {p[0], (const float*)p[1], (const float*)p[2]};
             return mnas_pool_act(&a, i[0], i[1], i[2], (float*)p[3], stream);
+        }
+        case MNAS_OP_DY_MAT: {
+            MnasGradIn d = {p[0], p[1], (const float*)p[2]};
+            return mnas_dy_materialize(&d, (int64_t)o.d[0], i[0], p[3], stream);
         }
         case MNAS_OP_POOL_BWD:
             return mnas_pool_bwd((const float*)p[0], i[0], i[1], i[2], p[1], stream);

@@ -160,6 +160,41 @@ extern "C" int mnas_bn_bwd_reduce(const void* g, const void* y, const float* bnb
     return MNAS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// dy = c1*(g*[s*y+t>0]) + c2*y + c3 materialised as bf16 (rows x C).  The dense 3x3 convs gather every dy element 9 times
+// (stride 1) / 2.25 times (stride 2) in their input gradient and once more in their weight gradient: forming dy on load
+// there means two tensor reads and the 5-coefficient transform per gathered 16 bytes, and those launches are VALU-issue
+// bound (k_igemm<dgrad, stride 2> at 112x112: 26 k VALU instructions per wave).  One elementwise pass over the (small,
+// post-stride) tensor instead.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dy_mat(const uint4* __restrict__ g, const uint4* __restrict__ y,
+                                                const float* __restrict__ coef, int64_t rows, int C, uint4* __restrict__ out) {
+    const int G = C >> 3, R = 256 / G;
+    const int tid = threadIdx.x;
+    if (tid >= R * G) return;
+    const int cg = tid % G, rl = tid / G;
+    float cf[5][8];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cf[r][j] = coef[(size_t)r * C + cg * 8 + j];
+    for (int64_t r = (int64_t)blockIdx.x * R + rl; r < rows; r += (int64_t)gridDim.x * R) {
+        float o[8];
+        dy8(g[r * G + cg], y[r * G + cg], cf[0], cf[1], cf[2], cf[3], cf[4], o);
+        out[r * G + cg] = pack8(o);
+    }
+}
+extern "C" int mnas_dy_materialize(const MnasGradIn* d, int64_t rows, int C, void* out_bf16, void* stream) {
+    if (!d || !d->g || !d->y || !d->coef || !out_bf16 || rows < 1 || C <= 0 || (C & 7) || C > 2048) return MNAS_EINVAL;
+    const int R = 256 / (C >> 3);
+    int64_t blocks = (rows + R - 1) / R;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_dy_mat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)d->g, (const uint4*)d->y,
+                       d->coef, rows, C, (uint4*)out_bf16);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 // dgamma, dbeta and the dy-on-load coefficients:
 //   dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) = c1*dz + c2*y + c3
 template <int TPC>

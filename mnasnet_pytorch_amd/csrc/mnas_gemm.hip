@@ -34,7 +34,20 @@ struct IgemmArgs {
     const void* red_y;       // MODE 1: fused BN-backward reduce target (raw output of the ConvBlock whose g we produce)
     const float* red_bn;
     int nt;                  // nontemporal output stores
+    float rcp_hw, rcp_wo, rcp_ci;   // reciprocals for igemm_fdiv (0 = use the exact integer division)
 };
+
+// floor(n / d) for 0 <= n < 2^24, d > 0 with a float reciprocal and one correction step (7 instructions instead of the ~25
+// of the integer division sequence): the im2col address decode of the dense 3x3 / stride-2 forms runs it twice per staged
+// 16-byte slot; k_igemm<dgrad, stride 2> at 112x112 spent 26 k VALU instructions per wave, most of them here.
+__device__ __forceinline__ int igemm_fdiv(int n, int d, float rcp) {
+    if (rcp == 0.f) return n / d;
+    int q = (int)((float)n * rcp);
+    const int r = n - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
 
 template <int MODE, int NT, int PT, int KCH, bool PIPE, bool PAR2>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
@@ -57,10 +70,11 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     const int l15 = lane & 15, lg = lane >> 4;
     const int n0 = blockIdx.y * NT * 16;
     const int nkc = (a.Kpad + kch - 1) / kch;
-    const bool has_coef = (MODE == 1) || (MODE == 0 && a.act.scale != nullptr);
+    const bool has_coef = (MODE == 1 && a.grad.coef != nullptr) || (MODE == 0 && a.act.scale != nullptr);
+    const bool has_y = MODE == 1 && a.grad.y != nullptr;        // false: grad.g is a materialised dy (mnas_dy_materialize)
     const float* coef_src[CROWS];
     if (MODE != 1) { coef_src[0] = a.act.scale; coef_src[1] = a.act.shift; }
-    else {
+    else if (has_coef) {
 #pragma unroll
         for (int r = 0; r < CROWS; ++r) coef_src[r] = a.grad.coef + (size_t)r * a.Ci;
     }
@@ -129,12 +143,12 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         const bool kok = k < (par2 ? c_K : a.Ktot);
         int ci = k, th = 0, tw = 0;
         if (par2) {
-            const int tj = k / a.Ci;
+            const int tj = igemm_fdiv(k, a.Ci, a.rcp_ci);
             ci = k - tj * a.Ci;
             const int thj = tj / c_ntw, twj = tj - thj * c_ntw;
             th = c_ph ? 2 * thj : 1; tw = c_pw ? 2 * twj : 1;
         } else if (!a.is_pw && MODE != 2) {
-            const int tap = k / a.Ci;
+            const int tap = igemm_fdiv(k, a.Ci, a.rcp_ci);
             ci = k - tap * a.Ci;
             th = tap / a.kw; tw = tap - th * a.kw;
         }
@@ -150,8 +164,8 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                 // weight order), 3x3 stride 2 pad 1; Hi,Wi = image dims
                 if (m < a.M) {
                     const int hw = a.Ho * a.Wo;
-                    const int n = m / hw, rem = m - n * hw;
-                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    const int n = igemm_fdiv(m, hw, a.rcp_hw), rem = m - n * hw;
+                    const int oh = igemm_fdiv(rem, a.Wo, a.rcp_wo), ow = rem - oh * a.Wo;
                     const float* x = (const float*)a.act.data;
                     float f[8];
 #pragma unroll
@@ -169,14 +183,14 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
             if (par2) {
                 if (m < a.Mc && kok) {
                     const int w2 = a.Wo >> 1, hw2 = (a.Ho >> 1) * w2;
-                    const int n = m / hw2, rem = m - n * hw2;
-                    const int oh2 = rem / w2, ow2 = rem - oh2 * w2;
+                    const int n = igemm_fdiv(m, hw2, a.rcp_hw), rem = m - n * hw2;
+                    const int oh2 = igemm_fdiv(rem, w2, a.rcp_wo), ow2 = rem - oh2 * w2;
                     const int ih = (2 * oh2 + c_ph + 1 - th) >> 1, iw = (2 * ow2 + c_pw + 1 - tw) >> 1;   // exact: parity matches
                     if (ih < a.Hi && iw < a.Wi) {
                         const size_t src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + ci;
                         okm |= 1u << i;
                         v0[i] = *(const uint4*)((const uint16_t*)a.grad.g + src);
-                        v1[i] = *(const uint4*)((const uint16_t*)a.grad.y + src);
+                        if (has_y) v1[i] = *(const uint4*)((const uint16_t*)a.grad.y + src);
                     }
                 }
                 continue;
@@ -188,8 +202,8 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                     src = (size_t)m * a.Ci + k;
                 } else {
                     const int hw = a.Ho * a.Wo;
-                    const int n = m / hw, rem = m - n * hw;
-                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    const int n = igemm_fdiv(m, hw, a.rcp_hw), rem = m - n * hw;
+                    const int oh = igemm_fdiv(rem, a.Wo, a.rcp_wo), ow = rem - oh * a.Wo;
                     int ih, iw;
                     if (MODE == 0) {
                         ih = oh * a.stride + th - a.pad;
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                         v0[i] = *(const uint4*)((const uint16_t*)a.act.data + src);
                     } else {
                         v0[i] = *(const uint4*)((const uint16_t*)a.grad.g + src);
-                        v1[i] = *(const uint4*)((const uint16_t*)a.grad.y + src);
+                        if (has_y) v1[i] = *(const uint4*)((const uint16_t*)a.grad.y + src);
                     }
                 }
             }
@@ -290,8 +304,8 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         if constexpr (!par2) return ml < a.M ? ml : -1;
         if (ml >= a.Mc) return -1;
         const int w2 = a.Wo >> 1, hw2 = (a.Ho >> 1) * w2;
-        const int n = ml / hw2, rem = ml - n * hw2;
-        const int oh2 = rem / w2, ow2 = rem - oh2 * w2;
+        const int n = igemm_fdiv(ml, hw2, a.rcp_hw), rem = ml - n * hw2;
+        const int oh2 = igemm_fdiv(rem, w2, a.rcp_wo), ow2 = rem - oh2 * w2;
         return (n * a.Ho + 2 * oh2 + e_ph) * a.Wo + 2 * ow2 + e_pw;
     };
     if (PIPE && (int)blockIdx.x < ntiles) {
@@ -551,6 +565,14 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = c->resid; a.out = c->out; a.stats = c->stats;
     a.red_y = (c->mode == 1) ? c->red_y : nullptr; a.red_bn = c->red_bn;
     a.nt = (mnas_nt_mask() & (c->mode == 1 ? MNAS_NT_IGEMM_DGRAD : MNAS_NT_IGEMM_FWD)) ? 1 : 0;
+    {   // the decode divides by the OUTPUT plane (half plane for the parity-class form); exact division beyond 2^24 pixels
+        const int s2f = (c->mode == 1 && c->kh == 3 && c->kw == 3 && c->stride == 2 && c->pad == 1 && !(c->Ho & 1) && !(c->Wo & 1));
+        const int wd = s2f ? c->Wo / 2 : c->Wo, hwd = s2f ? (c->Ho / 2) * wd : c->Ho * c->Wo;
+        const bool small = (int64_t)a.M < (1 << 24);
+        a.rcp_hw = small ? 1.0f / (float)hwd : 0.f;
+        a.rcp_wo = small ? 1.0f / (float)wd : 0.f;
+        a.rcp_ci = 1.0f / (float)c->Ci;
+    }
     // stride-2 3x3 input gradient over even output sizes: parity-class tiling (see k_igemm)
     a.s2 = (c->mode == 1 && c->kh == 3 && c->kw == 3 && c->stride == 2 && c->pad == 1 && !(c->Ho & 1) && !(c->Wo & 1)) ? 1 : 0;
     a.Mc = c->N * (c->Ho / 2) * (c->Wo / 2);
@@ -559,7 +581,7 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (a.taps != 1 && c->Ci > 1024) return MNAS_EINVAL;
     if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;   // strided / padded 1x1 does not occur in this network
     if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
-    if (c->mode == 1 && (!c->grad.g || !c->grad.y || !c->grad.coef)) return MNAS_EINVAL;
+    if (c->mode == 1 && (!c->grad.g || (!c->grad.y) != (!c->grad.coef))) return MNAS_EINVAL;    // (y, coef) both or neither
     if (a.is_pw && (c->mode == 1 || !c->resid) && mnas_pws_parts(c->mode, a.M, c->Ci, c->Co) > 0) return mnas_pws_run(c, stream);
     if (c->mode == 0 && a.is_pw && !c->resid && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwf_forward(c, stream);
@@ -592,6 +614,9 @@ extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = nullptr; a.out = c->out; a.stats = c->stats;
     a.red_y = nullptr; a.red_bn = nullptr;
     a.nt = (mnas_nt_mask() & MNAS_NT_STEM) ? 1 : 0;
+    a.rcp_hw = (int64_t)a.M < (1 << 24) ? 1.0f / (float)(c->Ho * c->Wo) : 0.f;
+    a.rcp_wo = (int64_t)a.M < (1 << 24) ? 1.0f / (float)c->Wo : 0.f;
+    a.rcp_ci = 0.f;
     a.s2 = 0; a.Mc = 0; a.tpc = 0;
     const int tiles = (c->Co + 15) / 16;
     hipStream_t s = (hipStream_t)stream;

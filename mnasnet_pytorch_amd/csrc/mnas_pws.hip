@@ -273,7 +273,7 @@ static int pws_dispatch(const PwsArgs& a, const PwsPlan& p, int nparts, hipStrea
 int mnas_pws_run(const MnasConvGemm* c, void* stream) {
     const int M = c->N * c->Ho * c->Wo;
     PwsPlan p;
-    if (!pws_plan(c->mode, M, c->Ci, c->Co, &p)) return MNAS_EINVAL;
+    if (!pws_plan(c->mode, M, c->Ci, c->Co, &p) || (c->mode == 1 && !c->grad.coef)) return MNAS_EINVAL;
     PwsArgs a;
     a.M = M; a.K = c->Ci; a.N = c->Co;
     a.ksteps = (c->Ci + 31) / 32; a.Kpad = a.ksteps * 32;

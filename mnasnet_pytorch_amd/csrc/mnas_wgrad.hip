@@ -56,9 +56,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
     uint16_t* tile_a = tile_d + WG_BPIX * ldd;            // [128][lda]
     float* lds_out = (float*)tile_d;                      // reused at the end: [64][65]
 
+    const bool hasdy = a.dy.coef != nullptr;              // false: dy.g is a materialised dy
     for (int i = tid; i < 5 * 64; i += 256) {
         const int r = i >> 6, c = co0 + (i & 63);
-        lds_cd[i] = (c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
+        lds_cd[i] = (hasdy && c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
     }
     const bool hasx = !STEM && a.x.scale != nullptr;
     if (hasx)
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
                     okd[i] = true;
                     const size_t off = (size_t)m * a.Co + co0 + cd8[i] * 8;
                     vg[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
-                    vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
+                    if (hasdy) vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
                 }
             }
         }
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
         for (int i = 0; i < 4; ++i) {
             if (pd[i] < 0) continue;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (okd[i]) {
+            if (okd[i] && !hasdy) v = vg[i];           // materialised dy (mnas_dy_materialize): no transform
+            else if (okd[i]) {
                 float cf[5][8];
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {

@@ -372,6 +372,12 @@ class Program:
                     [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
             # the weight-gradient kernels only share READ-ONLY inputs (g, y, the dy coefficients just finalised, the
             # forward activations) with the input-gradient chain: they go to the side stream and run concurrently
+            gyd = gy
+            if ci.kind == "dense" and eng.materialize_dy:
+                # dense 3x3: every dy element is gathered 2.25-10 times by the input/weight-gradient kernels; form it once
+                dyb = new((N, Ho, Wo, Co))
+                ops.add(L.OP_DY_MAT, [Co], [float(M)], gy + [dyb.data_ptr()], 0)
+                gyd = [dyb.data_ptr(), None, None]
             WS = 1 if eng.use_side_stream else 0
             if WS:
                 ops.fork()
@@ -422,7 +428,7 @@ class Program:
                 slabs = _cdiv(Co, 64) * _cdiv(K, 64)
                 nsp = max(1, min(_cdiv(1024, slabs), _cdiv(M, 256)))
                 ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
-                        a_in.act_ptrs() + gy + [eng.scratch_wgrad.data_ptr()], WS)
+                        a_in.act_ptrs() + gyd + [eng.scratch_wgrad.data_ptr()], WS)
                 ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                 if need_gin:
                     gin = new((N, Hi, Wi, ci.cin))
@@ -435,7 +441,7 @@ class Program:
                         red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
                         ncols = nparts
                     ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
-                            [None, None, None] + gy + [ci.w_dgrad.data_ptr(), None,
+                            [None, None, None] + gyd + [ci.w_dgrad.data_ptr(), None,
                                                        resid.data_ptr() if resid is not None else None,
                                                        gin.data_ptr(), red[0], red[1], red[2]])
             if ci.kind == "dw" and resid is not None:
@@ -637,6 +643,7 @@ class Engine:
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        self.materialize_dy = True       # dense 3x3 convs: dy formed once (mnas_dy_materialize), gathered plain by dgrad / wgrad
         # MBConv_block: expand + depthwise forward in ONE kernel (statistics from the input's covariance, csrc/mnas_gram.hip).
         # Validated bit-identical to the unfused pair, but measured SLOWER at bs 256 (14.7 vs 13.05 ms/step): the depthwise
         # sweeps are latency/issue-bound, not HBM-bound, so removing the expanded tensor's read does not pay for the MFMA stage
