@@ -10,6 +10,12 @@ def key(name):
     m = re.match(r"void k_igemm<(\d)", name)
     if m:
         return {"0": "k_igemm<fwd>", "1": "k_igemm<dgrad>", "2": "k_igemm<stem>"}[m.group(1)]
+    m = re.match(r"void k_pws<(\d)", name)
+    if m:
+        return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"      # bench.py classes follow the C-ABI entry point
+    if name.startswith("void k_pwf"): return "k_igemm<fwd>"
+    if name.startswith("k_dy_mat"): return "k_dy_mat"
+    if name.startswith("k_pool"): return "k_pool"
     if name.startswith("void k_wgrad<true>"): return "k_wgrad<stem>"
     if name.startswith("void k_wgrad<false>"): return "k_wgrad"
     if name.startswith("void k_pw_bwd"): return "k_pw_bwd"
