@@ -312,7 +312,19 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
         load_a(blockIdx.x, 0);
         if (wloop) load_w(0);
     }
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // tile order of this workgroup.  Parity-class form: the four classes of the SAME pixel block back to back (class tile q of
+    // class c covers output rows 2*oh2+ph, columns 2*ow2+pw of one region), so the 32-byte pieces the classes interleave into
+    // each output line (and read from the fused-reduce target) meet in this CU's L2 within microseconds instead of being
+    // written by four workgroups on four XCDs at four different times.
+    auto tile_at = [&](int j) -> int {
+        if constexpr (par2) {
+            const int q = blockIdx.x + (j >> 2) * gridDim.x;
+            return q < a.tpc ? (j & 3) * a.tpc + q : ntiles;
+        } else {
+            return blockIdx.x + j * gridDim.x;
+        }
+    };
+    for (int jt = 0, t = tile_at(0); t < ntiles; t = tile_at(++jt)) {
         int tile0_ = t * BP, t_nkc_ = nkc, t_kpad_ = a.Kpad;
         if constexpr (par2) {
             const int cls = t / a.tpc;
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
             // next (tile, chunk) of this workgroup: its loads fly under the MFMAs (and the epilogue / next ypre fetch)
             if (PIPE) {
                 int nt_ = t, nk_ = kc + 1;
-                if (nk_ == t_nkc) { nk_ = 0; nt_ = t + gridDim.x; }
+                if (nk_ == t_nkc) { nk_ = 0; nt_ = tile_at(jt + 1); }
                 if (nt_ < ntiles) {
                     load_a(nt_, nk_ * kch);
                     if (wloop) load_w(nk_ * kch);
