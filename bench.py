@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--hw", type=str, default="", help="rectangular input HxW (BASELINE config 5 clusters: 384x512, 512x512, "
                                                        "512x384); overrides --size")
+    ap.add_argument("--k5", action="store_true", help="BASELINE config 4 (its 5x5 half): every MBConv stage with 5x5 depthwise convs "
+                                                     "(the SE block of that config has no counterpart in the reference: not built)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -206,11 +208,21 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         base = load_model("mnasnet")
+    if args.k5:
+        from mnasnet_pytorch_amd.mnasnet import ConvBlock, MBConv, SepConv, _Features
+        cfg = [(16, 24, 3, 3, True), (24, 40, 3, 3, True), (40, 80, 6, 3, True), (80, 96, 6, 2, False), (96, 192, 6, 4, True),
+               (192, 320, 6, 1, False)]
+        base.features = _Features(ConvBlock(3, 32, kernel_size=3, stride=2, padding=1), SepConv(32, 16, kernel_size=3),
+                                  *[MBConv(i, o, channel_factor=t, layers=n, kernel_size=5, reduce=r, cut_channels_first=False)
+                                    for i, o, t, n, r in cfg])
+        base.init_params()
     model = FineTuneModelPool(base, "mnasnet", 1000, "512").to(dev).train()
     trainer = Trainer(model, lr=1e-3, distributed=distributed)
     eng = trainer.engine
     if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
         eng.use_side_stream = False
+    if os.environ.get("MNAS_PWB_SMALL"):     # diagnosis only
+        eng.pw_bwd_parts_small = int(os.environ["MNAS_PWB_SMALL"])
     if os.environ.get("MNAS_NO_DYMAT"):      # diagnosis only: dense 3x3 backward forms dy on load (two reads + transform per gather)
         eng.materialize_dy = False
     if os.environ.get("MNAS_FUSE"):          # diagnosis only: fused expand + depthwise forward kernels (measured slower)
@@ -280,8 +292,8 @@ def main():
         "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes) fwd+bwd+Adam, "
-                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (B, Hh, Ww),
+        "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes%s) fwd+bwd+Adam, "
+                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (", all depthwise convs 5x5" if args.k5 else "", B, Hh, Ww),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss": round(lossv, 4)},
     }
     # ---- roofline of the dominant kernel class: events recorded inside the timed region (last timed step) -----------
