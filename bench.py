@@ -221,6 +221,8 @@ def main():
     eng = trainer.engine
     if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
         eng.use_side_stream = False
+    if os.environ.get("MNAS_NO_MERGE"):      # diagnosis only: separate finalize launches
+        eng.merge_post = False
     if os.environ.get("MNAS_PWB_SMALL"):     # diagnosis only
         eng.pw_bwd_parts_small = int(os.environ["MNAS_PWB_SMALL"])
     if os.environ.get("MNAS_NO_DYMAT"):      # diagnosis only: dense 3x3 backward forms dy on load (two reads + transform per gather)

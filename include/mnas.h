@@ -264,6 +264,27 @@ int mnas_dy_materialize(const MnasGradIn* d, int64_t rows, int C, void* out_bf16
 int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count,
                          float* bnbuf, float* dgamma, float* dbeta, int accumulate, void* stream);
 
+/* ---- one launch for the bookkeeping between two dependent backward kernels: mnas_bn_bwd_finalize (accumulate = 1) of the next
+ * layer + up to two weight-gradient reductions (mnas_wgrad_finalize / mnas_dw_wgrad_finalize semantics, accumulate = 1).
+ * level: 0 = none, 1 = whole reduction in one level (nsplit <= 256), 2 = first level of two (chunks of 128 rows folded into
+ * each chunk's first row, in place), 3 = second level of the same table (call it in a LATER launch than its level 2).
+ * bn_C == 0: no BatchNorm part. */
+typedef struct MnasPostWgrad {
+    float* partial;          /* float[nsplit][Co][taps*Ci]   (dw: float[nsplit][taps][Co]) */
+    float* grad;             /* reference layout, accumulated into */
+    int32_t nsplit, Co, Ci, taps, dw, level;
+} MnasPostWgrad;
+typedef struct MnasBwdPost {
+    const float* bn_partial; /* float[2][C][nparts] */
+    float* bnbuf;
+    float* dgamma;
+    float* dbeta;
+    double count;
+    int32_t bn_nparts, bn_C;
+    MnasPostWgrad w1, w2;
+} MnasBwdPost;
+int mnas_bwd_post(const MnasBwdPost* p, void* stream);
+
 /* ---- element-wise glue ------------------------------------------------------------------------------ */
 /* out = act(a) + act(b)   (b.data may be NULL -> out = act(a)); rows x C bf16.  The MBConv_block residual
  * (mnasnet.py:133).  If out_nchw_f32 != NULL the result is ALSO/INSTEAD written as fp32 NCHW (N,C,H,W)
@@ -323,6 +344,7 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_POOL_ACT 22
 #define MNAS_OP_POOL_BWD 23
 #define MNAS_OP_DY_MAT 24
+#define MNAS_OP_BWD_POST 25
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

@@ -61,6 +61,16 @@ class MnasPwBwd(C.Structure):
                 ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p)]
 
 
+class MnasPostWgrad(C.Structure):
+    _fields_ = [("partial", c_void_p), ("grad", c_void_p), ("nsplit", C.c_int32), ("Co", C.c_int32), ("Ci", C.c_int32),
+                ("taps", C.c_int32), ("dw", C.c_int32), ("level", C.c_int32)]
+
+
+class MnasBwdPost(C.Structure):
+    _fields_ = [("bn_partial", c_void_p), ("bnbuf", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("count", c_double),
+                ("bn_nparts", C.c_int32), ("bn_C", C.c_int32), ("w1", MnasPostWgrad), ("w2", MnasPostWgrad)]
+
+
 class MnasPackDesc(C.Structure):
     _fields_ = [("w", c_void_p), ("dst", c_void_p), ("kind", C.c_int32), ("Co", C.c_int32), ("Ci", C.c_int32),
                 ("taps", C.c_int32)]
@@ -85,6 +95,7 @@ OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRA
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
 OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
 OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
+OP_BWD_POST = 25
 PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
@@ -114,6 +125,7 @@ SYMBOLS = {
     "mnas_bn_fwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_float, c_float, c_int, c_void_p, c_void_p]),
     "mnas_bn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_bwd_post": (c_int, [C.POINTER(MnasBwdPost), c_void_p]),
     "mnas_dy_materialize": (c_int, [C.POINTER(MnasGradIn), c_int64, c_int, c_void_p, c_void_p]),
     "mnas_bn_bwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mnas_add_act": (c_int, [C.POINTER(MnasActIn), C.POINTER(MnasActIn), c_int64, c_int, c_void_p, c_void_p, c_int,

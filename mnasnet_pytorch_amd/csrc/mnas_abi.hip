@@ -68,6 +68,8 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  POOL_ACT         i: N,HW,C                                     p: a.data,a.scale,a.shift, out
 //  POOL_BWD         i: N,HW,C                                     p: gpool, g
 //  DY_MAT           i: C                  d: rows                 p: g,y,coef,out
+//  BWD_POST         i: bn_nparts,bn_C, w1{nsplit,Co,Ci,taps,dw,level}, w2{...}   d: count
+//                   p: bn_partial,bnbuf,dgamma,dbeta, w1.partial,w1.grad, w2.partial,w2.grad
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -170,6 +172,14 @@ static int run_one(const MnasOp& o, void* stream) {
         case MNAS_OP_POOL_ACT: {
             MnasActIn a = {p[0], (const float*)p[1], (const float*)p[2]};
             return mnas_pool_act(&a, i[0], i[1], i[2], (float*)p[3], stream);
+        }
+        case MNAS_OP_BWD_POST: {
+            MnasBwdPost a = {};
+            a.bn_partial = (const float*)p[0]; a.bnbuf = (float*)p[1]; a.dgamma = (float*)p[2]; a.dbeta = (float*)p[3];
+            a.count = o.d[0]; a.bn_nparts = i[0]; a.bn_C = i[1];
+            a.w1 = {(float*)p[4], (float*)p[5], i[2], i[3], i[4], i[5], i[6], i[7]};
+            a.w2 = {(float*)p[6], (float*)p[7], i[8], i[9], i[10], i[11], i[12], i[13]};
+            return mnas_bwd_post(&a, stream);
         }
         case MNAS_OP_DY_MAT: {
             MnasGradIn d = {p[0], p[1], (const float*)p[2]};

@@ -198,11 +198,10 @@ extern "C" int mnas_dy_materialize(const MnasGradIn* d, int64_t rows, int C, voi
 // dgamma, dbeta and the dy-on-load coefficients:
 //   dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) = c1*dz + c2*y + c3
 template <int TPC>
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nparts, int C,
-                                                         double count, float* bnbuf, float* dgamma, float* dbeta,
-                                                         int accumulate) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const float* __restrict__ partial, int nparts, int C, double count, float* bnbuf,
+                                                     float* dgamma, float* dbeta, int accumulate, int blk) {
     const int lane = threadIdx.x % TPC;
-    const int c = (TPC == 256) ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = (TPC == 256) ? blk : blk * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1, s2;
     bn_partial_sums<TPC>(partial, nparts, C, c, s1, s2);
@@ -215,6 +214,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
         if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
         if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
     }
+}
+template <int TPC>
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nparts, int C,
+                                                         double count, float* bnbuf, float* dgamma, float* dbeta,
+                                                         int accumulate) {
+    bn_bwd_finalize_body<TPC>(partial, nparts, C, count, bnbuf, dgamma, dbeta, accumulate, blockIdx.x);
 }
 
 extern "C" int mnas_bn_bwd_finalize(const float* partial, int nparts, int C, double count, float* bnbuf, float* dgamma,
@@ -488,14 +493,14 @@ extern "C" int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int k
 // (row stride FIN_SPLITS) and applies the relayout to the reference's weight layout.  No float atomics.
 #define FIN_SPLITS 128
 template <bool DW, bool FOLD>
-__global__ __launch_bounds__(256) void k_wgrad_finalize(float* __restrict__ partial, int nsplit, int pstride, int Co, int Ci,
-                                                         int taps, float* __restrict__ grad, int accumulate) {
+__device__ __forceinline__ void wgrad_finalize_body(float* __restrict__ partial, int nsplit, int pstride, int Co, int Ci, int taps,
+                                                    float* __restrict__ grad, int accumulate, int bx, int by) {
     __shared__ float red[8][33];
     const int K = taps * Ci;
     const int total = DW ? Co * taps : Co * K;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + tx;
-    const int p0 = FOLD ? blockIdx.y * FIN_SPLITS : 0, p1 = FOLD ? min(nsplit, p0 + FIN_SPLITS) : nsplit;
+    const int i = bx * 32 + tx;
+    const int p0 = FOLD ? by * FIN_SPLITS : 0, p1 = FOLD ? min(nsplit, p0 + FIN_SPLITS) : nsplit;
     float s = 0.f;
     if (i < total) {
         const float* src = partial + i;
@@ -529,6 +534,78 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(float* __restrict__ part
         *d = (accumulate ? *d : 0.f) + s;
     }
 }
+template <bool DW, bool FOLD>
+__global__ __launch_bounds__(256) void k_wgrad_finalize(float* __restrict__ partial, int nsplit, int pstride, int Co, int Ci,
+                                                         int taps, float* __restrict__ grad, int accumulate) {
+    wgrad_finalize_body<DW, FOLD>(partial, nsplit, pstride, Co, Ci, taps, grad, accumulate, blockIdx.x, blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch for everything that sits between two dependent backward kernels: the BatchNorm-backward finalize of the NEXT
+// layer and the weight-gradient reductions of the kernel that just ran (and the second level of the one before it).  As
+// separate launches these were 2-3 tiny dependent kernels (5-9 us each + launch boundaries) in every gap of the main stream.
+// Blocks [0, bn.nblk) run the BatchNorm part, the next w1.nx*w1.ny the first weight-gradient task, the rest the second.
+// ------------------------------------------------------------------------------------------------
+struct PostWg { float* partial; float* grad; int nsplit, Co, Ci, taps, dw, level, nx, ny; };
+struct PostArgs {
+    const float* bn_partial; float* bnbuf; float* dgamma; float* dbeta; double count;
+    int bn_nparts, bn_C, bn_nblk, bn_wide;
+    PostWg w1, w2;
+};
+__device__ __forceinline__ void post_wg(const PostWg& w, int b) {
+    const int bx = b % w.nx, by = b / w.nx;
+    // level 1: single-level finalize; 2: fold (first level of two); 3: second level over the folded rows (stride FIN_SPLITS)
+    if (w.level == 2) {
+        if (w.dw) wgrad_finalize_body<true, true>(w.partial, w.nsplit, 1, w.Co, w.Ci, w.taps, w.grad, 1, bx, by);
+        else wgrad_finalize_body<false, true>(w.partial, w.nsplit, 1, w.Co, w.Ci, w.taps, w.grad, 1, bx, by);
+    } else {
+        const int ns = w.level == 3 ? (w.nsplit + FIN_SPLITS - 1) / FIN_SPLITS : w.nsplit;
+        const int ps = w.level == 3 ? FIN_SPLITS : 1;
+        if (w.dw) wgrad_finalize_body<true, false>(w.partial, ns, ps, w.Co, w.Ci, w.taps, w.grad, 1, bx, by);
+        else wgrad_finalize_body<false, false>(w.partial, ns, ps, w.Co, w.Ci, w.taps, w.grad, 1, bx, by);
+    }
+}
+__global__ __launch_bounds__(256) void k_bwd_post(PostArgs a) {
+    int b = blockIdx.x;
+    if (b < a.bn_nblk) {
+        if (a.bn_wide) bn_bwd_finalize_body<256>(a.bn_partial, a.bn_nparts, a.bn_C, a.count, a.bnbuf, a.dgamma, a.dbeta, 1, b);
+        else bn_bwd_finalize_body<64>(a.bn_partial, a.bn_nparts, a.bn_C, a.count, a.bnbuf, a.dgamma, a.dbeta, 1, b);
+        return;
+    }
+    b -= a.bn_nblk;
+    const int n1 = a.w1.level ? a.w1.nx * a.w1.ny : 0;
+    if (b < n1) { post_wg(a.w1, b); return; }
+    post_wg(a.w2, b - n1);
+}
+static bool post_fill(PostWg* w, const MnasPostWgrad& t) {
+    w->level = t.level;
+    if (!t.level) { w->nx = w->ny = 0; return true; }
+    if (t.level < 1 || t.level > 3 || !t.partial || !t.grad || t.nsplit < 1 || t.Co < 1 || t.Ci < 1 || t.taps < 1) return false;
+    if (t.level == 1 && t.nsplit > 2 * FIN_SPLITS) return false;          // single level only for short split ranges
+    w->partial = t.partial; w->grad = t.grad; w->nsplit = t.nsplit; w->Co = t.Co; w->Ci = t.Ci; w->taps = t.taps; w->dw = t.dw;
+    const int total = t.dw ? t.Co * t.taps : t.Co * t.Ci * t.taps;
+    w->nx = (total + 31) / 32;
+    w->ny = t.level == 2 ? (t.nsplit + FIN_SPLITS - 1) / FIN_SPLITS : 1;
+    return true;
+}
+extern "C" int mnas_bwd_post(const MnasBwdPost* p, void* stream) {
+    if (!p) return MNAS_EINVAL;
+    PostArgs a = {};
+    if (p->bn_C > 0) {
+        if (!p->bn_partial || !p->bnbuf || p->bn_nparts < 1) return MNAS_EINVAL;
+        a.bn_partial = p->bn_partial; a.bnbuf = p->bnbuf; a.dgamma = p->dgamma; a.dbeta = p->dbeta; a.count = p->count;
+        a.bn_nparts = p->bn_nparts; a.bn_C = p->bn_C;
+        a.bn_wide = p->bn_nparts > 256 ? 1 : 0;
+        a.bn_nblk = a.bn_wide ? p->bn_C : (p->bn_C + 3) / 4;
+    }
+    if (!post_fill(&a.w1, p->w1) || !post_fill(&a.w2, p->w2)) return MNAS_EINVAL;
+    const int blocks = a.bn_nblk + a.w1.nx * a.w1.ny + a.w2.nx * a.w2.ny;
+    if (blocks < 1) return MNAS_OK;
+    hipLaunchKernelGGL(k_bwd_post, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 template <bool DW>
 static int launch_wgrad_finalize(float* partial, int nsplit, int Co, int Ci, int taps, float* grad, int accumulate,
                                  void* stream) {

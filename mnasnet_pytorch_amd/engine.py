@@ -350,6 +350,42 @@ class Program:
             j = seg(last_stage).add(L.OP_NCHW_TO_NHWC, [N, cur.C, cur.H * cur.W], [], [None, g_final.data_ptr()])
         self.patch_gout = (last_stage, j, 0)
 
+        # ---- merged bookkeeping launches (mnas_bwd_post): the weight-gradient reductions of the main-stream kernel that just
+        # ran ride in the SAME launch as the next layer's BatchNorm-backward finalize (and the second level of a two-level
+        # reduction in the one after that), instead of 2-3 tiny dependent launches in every gap of the main stream
+        merge = eng.merge_post
+        pend = {"w1": None, "w2": None, "ops": None}
+        rot = [0]
+        rot_bufs = [eng.scratch_wgrad2, eng.scratch_wgrad3, eng.scratch_wgrad4]
+
+        def next_scratch():
+            b = rot_bufs[rot[0] % 3]
+            rot[0] += 1
+            return b
+
+        def emit_post(ops: _OpList, bn=None):
+            w1, w2 = pend["w1"], pend["w2"]
+            pend["w1"] = pend["w2"] = None
+            if w1 is not None and w1[7] == 2:
+                pend["w2"] = w1[:7] + (3,)
+            if bn is None and w1 is None and w2 is None:
+                return
+            none = (None, None, 0, 0, 0, 0, 0, 0)
+            w1 = w1 or none
+            w2 = w2 or none
+            bn = bn or (None, None, None, None, 0, 0, 0.0)
+            ops.add(L.OP_BWD_POST, [bn[4], bn[5]] + list(w1[2:]) + list(w2[2:]), [bn[6]],
+                    list(bn[:4]) + [w1[0], w1[1], w2[0], w2[1]], 0)
+            pend["ops"] = ops
+
+        def flush_post():
+            while pend["w1"] is not None or pend["w2"] is not None:
+                emit_post(pend["ops"])
+
+        def queue_wgrad(ops, partial, nsplit, Co_, Ci_, taps, dw, grad_ptr):
+            pend["w1"] = (partial, grad_ptr, nsplit, Co_, Ci_, taps, 1 if dw else 0, 1 if nsplit <= 256 else 2)
+            pend["ops"] = ops
+
         def conv_bwd(ops: _OpList, rec, g, resid, need_gin, g_reduced=False, red_target=None):
             """Backward of one ConvBlock application.  g: bf16 grad wrt its activated output.
             g_reduced: the producer of g already wrote this layer's BN-backward partial sums into
@@ -368,8 +404,13 @@ class Program:
                 nred = max(1, min(1024, _cdiv(M * Co, 256 * 8 * 8)))
                 red_buf = eng.scratch_stats
                 ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), red_buf.data_ptr()])
-            ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
-                    [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
+            if merge:
+                if pend["ops"] is not None and pend["ops"] is not ops:
+                    flush_post()               # a stage's gradients are complete inside its own launch list
+                emit_post(ops, (red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3), nred, Co, float(M)))
+            else:
+                ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
+                        [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
             # the weight-gradient kernels only share READ-ONLY inputs (g, y, the dy coefficients just finalised, the
             # forward activations) with the input-gradient chain: they go to the side stream and run concurrently
             gyd = gy
@@ -395,7 +436,7 @@ class Program:
                 if rt is not None:
                     red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
                     ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 2)
-                wsc = eng.scratch_wgrad2 if ci.k in eng.dw_fused_k else eng.scratch_wgrad     # fused runs on the main stream
+                wsc = (next_scratch() if merge else eng.scratch_wgrad2) if ci.k in eng.dw_fused_k else eng.scratch_wgrad     # fused: main stream
                 dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), wsc.data_ptr()] + red
                 wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 3)
                 if wrows < 1 or (rt is not None and ncols < 1):
@@ -405,7 +446,10 @@ class Program:
                     if rt is not None:
                         ncols = wrows
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0], [], dwp, 0)
-                    ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
+                    if merge:
+                        queue_wgrad(ops, wsc.data_ptr(), wrows, Co, 1, ci.k * ci.k, True, eng.gptr(ci, 0))
+                    else:
+                        ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
                 else:
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
                     ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
@@ -419,10 +463,14 @@ class Program:
                 if rt is not None:
                     red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
                     ncols = nparts
+                wsc = next_scratch() if merge else eng.scratch_wgrad2
                 ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts], [],
                         a_in.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
-                                                gin.data_ptr(), eng.scratch_wgrad2.data_ptr()] + red, 0)
-                ops.add(L.OP_WGRAD_FINALIZE, [nparts, Co, ci.cin, 1, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
+                                                gin.data_ptr(), wsc.data_ptr()] + red, 0)
+                if merge:
+                    queue_wgrad(ops, wsc.data_ptr(), nparts, Co, ci.cin, 1, False, eng.gptr(ci, 0))
+                else:
+                    ops.add(L.OP_WGRAD_FINALIZE, [nparts, Co, ci.cin, 1, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
             else:
                 K = ci.k * ci.k * ci.cin
                 slabs = _cdiv(Co, 64) * _cdiv(K, 64)
@@ -497,6 +545,7 @@ class Program:
             j = seg(step_records[0][1]).add(L.OP_ADD_ACT, [Cin, H * W], [float(N * H * W)],
                                             [g.data_ptr(), None, None, None, None, None, None, None])
             self.patch_dx = (step_records[0][1], j, 7)
+        flush_post()
         built = {}
         for st in order:
             if eng.use_side_stream:
@@ -643,6 +692,7 @@ class Engine:
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        self.merge_post = True           # BatchNorm-backward finalize + weight-gradient reductions of the main stream in one launch
         self.materialize_dy = True       # dense 3x3 convs: dy formed once (mnas_dy_materialize), gathered plain by dgrad / wgrad
         # MBConv_block: expand + depthwise forward in ONE kernel (statistics from the input's covariance, csrc/mnas_gram.hip).
         # Validated bit-identical to the unfused pair, but measured SLOWER at bs 256 (14.7 vs 13.05 ms/step): the depthwise
@@ -704,6 +754,8 @@ class Engine:
         self.scratch_stats = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)
         self.scratch_wgrad = torch.empty(wmax, dtype=torch.float32, device=device)
         self.scratch_wgrad2 = torch.empty(wmax, dtype=torch.float32, device=device)
+        self.scratch_wgrad3 = torch.empty(wmax, dtype=torch.float32, device=device)      # main-stream producers rotate over 2..4:
+        self.scratch_wgrad4 = torch.empty(wmax, dtype=torch.float32, device=device)      # a table is reduced up to two launches later
         self.scratch_red = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)   # fused BN-bwd partials
         cmax = max(ci.cin for ci in self.convs)
         self.scratch_gram = torch.empty(512 * cmax * cmax, dtype=torch.float32, device=device)         # mnas_gram partials
