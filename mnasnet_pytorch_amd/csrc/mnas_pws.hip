@@ -227,19 +227,21 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
 struct PwsPlan { int nt, ksw, nw, nblocks; size_t lds; };
 static bool pws_plan(int mode, int M, int K, int N, PwsPlan* p) {
     if ((K & 7) || (N & 7) || K < 192 || N < 8 || M < 1) return false;       // long reductions only
-    // input-gradient mode: validated, but slower in the step than k_igemm (1.62 vs 1.15 ms over the 14 launches): the dy-on-load
-    // transform (two tensors, five coefficient rows) pushes the kernel to 256 VGPRs = one workgroup per CU.  MNAS_PWS=2 enables it.
-    if (mode == 1 && mnas_pws_enabled() < 2) return false;
+    // input-gradient mode: with 4 waves (KSW = 5) the dy-on-load transform (two tensors, five coefficient rows) pushed the kernel
+    // to 256 VGPRs = one 4-wave workgroup per CU and the step lost 0.47 ms against k_igemm; 8 waves per workgroup (below) fix that
+    if (mode == 1 && mnas_pws_enabled() < 2) return false;        // measured neutral in the step (dgrad class 1.05 -> 0.99 ms, step
+                                                                  // time unchanged): k_igemm stays the default, MNAS_PWS=2 enables it
     if (M > 250000) return false;                                            // the 112x112 / 56x56 layers stay on k_igemm / k_pw_bwd
     const int ksteps = (K + 31) / 32;
     const int tiles = (N + 15) / 16;
     int nt = tiles <= 3 ? 3 : 6;
     const int nblocks = (tiles + nt - 1) / nt;
     if (nblocks * nt - tiles > 3) return false;
-    const int nw = ksteps > 20 ? 8 : 4;
+    // input-gradient mode carries two tensors and five coefficient rows per fragment: 8 waves (KSW <= 3) keep it under 200 VGPRs
+    const int nw = (ksteps > 20 || (mode == 1 && ksteps >= 12)) ? 8 : 4;
     const int ksw_need = (ksteps + nw - 1) / nw;
-    if (ksw_need > 5) return false;
-    p->nt = nt; p->nw = nw; p->ksw = ksw_need <= 2 ? 2 : 5; p->nblocks = nblocks;
+    if (ksw_need > (mode == 1 ? 3 : 5)) return false;
+    p->nt = nt; p->nw = nw; p->ksw = ksw_need <= 2 ? 2 : (ksw_need == 3 ? 3 : 5); p->nblocks = nblocks;
     const int NB = nt * 16, Kpad = ksteps * 32, crows = mode == 1 ? 5 : 2;
     size_t part = (size_t)2 * nw * 16 * (NB + 4) * 4, fin = (size_t)16 * 2 * NB * 4;
     p->lds = (size_t)crows * Kpad * 4 + (part > fin ? part : fin) + (size_t)4 * NB * 4;
@@ -265,6 +267,7 @@ template <int MODE>
 static int pws_dispatch(const PwsArgs& a, const PwsPlan& p, int nparts, hipStream_t s) {
 #define MNAS_PWS(NT_, KSW_, NW_) if (p.nt == NT_ && p.ksw == KSW_ && p.nw == NW_) return pws_launch<MODE, NT_, KSW_, NW_>(a, p, nparts, s);
     MNAS_PWS(3, 2, 4) MNAS_PWS(3, 5, 4) MNAS_PWS(6, 2, 4) MNAS_PWS(6, 5, 4) MNAS_PWS(3, 5, 8) MNAS_PWS(6, 5, 8)
+    MNAS_PWS(3, 2, 8) MNAS_PWS(6, 2, 8) MNAS_PWS(3, 3, 8) MNAS_PWS(6, 3, 8) MNAS_PWS(3, 3, 4) MNAS_PWS(6, 3, 4)
 #undef MNAS_PWS
     return MNAS_EINVAL;
 }
