@@ -223,8 +223,8 @@ def main():
         eng.use_side_stream = False
     if os.environ.get("MNAS_NO_MERGE"):      # diagnosis only: separate finalize launches
         eng.merge_post = False
-    if os.environ.get("MNAS_PWB_SMALL"):     # diagnosis only
-        eng.pw_bwd_parts_small = int(os.environ["MNAS_PWB_SMALL"])
+    if os.environ.get("MNAS_PWB"):           # diagnosis only: large,mid,small persistent grids of the fused 1x1 backward
+        eng.pw_bwd_parts_large, eng.pw_bwd_parts_mid, eng.pw_bwd_parts_small = (int(v) for v in os.environ["MNAS_PWB"].split(","))
     if os.environ.get("MNAS_NO_DYMAT"):      # diagnosis only: dense 3x3 backward forms dy on load (two reads + transform per gather)
         eng.materialize_dy = False
     if os.environ.get("MNAS_FUSE"):          # diagnosis only: fused expand + depthwise forward kernels (measured slower)

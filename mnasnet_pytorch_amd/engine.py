@@ -458,7 +458,8 @@ class Program:
                 # large-pixel-count 1x1 conv: ONE sweep produces the input gradient, the weight-gradient partials and the
                 # fused reduce (both former kernels stream the same g, y; see csrc/mnas_pwbwd.hip).  Main stream.
                 gin = new((N, Hi, Wi, ci.cin))
-                nparts = max(1, min(1024 if M >= 800000 else (512 if M >= 100000 else eng.pw_bwd_parts_small), _cdiv(M, 128 if max(ci.cin, Co) <= 80 else 64)))
+                nparts = max(1, min(eng.pw_bwd_parts_large if M >= 800000 else (eng.pw_bwd_parts_mid if M >= 100000 else eng.pw_bwd_parts_small),
+                                    _cdiv(M, 128 if max(ci.cin, Co) <= 80 else 64)))
                 red = [None, None, None]
                 if rt is not None:
                     red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
@@ -707,6 +708,8 @@ class Engine:
         # per launch at bs 256 against the dgrad + wgrad pair: 201 vs 399 us (16->48 @112^2), 233 vs 331 (48->16), 119 vs 285
         # (32->16), 90 vs 199 (24->72 @56^2), 105 vs 195 (72->24), 81 vs 141 (40->240 @28^2), 111 vs 175 (240->40)
         self.pw_fused_min_pixels = 50000
+        self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
+        self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
         self.pw_bwd_parts_small = 64     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)
         self.side_stream = None
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
