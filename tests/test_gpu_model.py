@@ -483,3 +483,32 @@ def test_all_5x5_variant_stage_vs_mirror(name):
         if kk.endswith("conv.bias"):
             continue
         assert rl2(p.grad.cpu(), r["grads"][kk]) < (0.1 if kk.endswith("bn.weight") else 5e-2), kk
+
+
+@pytest.mark.parametrize("hw,n", [((70, 58), 3), ((33, 95), 2), ((224, 224), 1)])
+def test_net_odd_sizes_and_batch_one(hw, n):
+    """Shapes no tuned path was sized for: odd / non-multiple-of-32 inputs (every stride-2 conv sees odd extents, so the
+    parity-class input gradient falls back to the generic form, depthwise strips end in partial 4-column groups) and batch 1
+    (BatchNorm over a single image).  Output vs the bf16 mirror <= 3e-2, gradient cosine median > 0.9."""
+    from mnasnet_pytorch_amd import Mnasnet
+    H, W = hw
+    ccf, pg = False, 0.1
+    m = Mnasnet(cut_channels_first=ccf)
+    m.load_state_dict(O.init_state(ccf, C.STATE_SEED, proj_gamma=pg))
+    m = m.cuda().train()
+    x0 = C.det_input((n, 3, H, W))
+    y = m(x0.cuda())
+    cot = C.cotangent(tuple(y.shape))
+    (y * cot.cuda()).sum().backward()
+    prog, _ = O.build_program(ccf)
+    r = M.run(prog, O.init_state(ccf, C.STATE_SEED, proj_gamma=pg), x0, True, cot)
+    assert tuple(y.shape) == tuple(r["y"].shape)
+    assert rl2(y.detach().cpu(), r["y"]) < 3e-2
+    coss = []
+    for kk, p in m.named_parameters():
+        if kk.endswith("conv.bias"):
+            continue
+        a, b = p.grad.double().flatten().cpu(), r["grads"][kk].double().flatten()
+        coss.append(float((a @ b) / (a.norm() * b.norm() + 1e-30)))
+    print(hw, n, "grad cosine vs mirror: min %.4f median %.4f" % (min(coss), float(np.median(coss))))
+    assert np.median(coss) > 0.9
