@@ -221,6 +221,8 @@ def main():
     eng = trainer.engine
     if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
         eng.use_side_stream = False
+    if os.environ.get("MNAS_PW_FUSED_MIN"):  # diagnosis only: pixel count from which 1x1 convs use the fused backward
+        eng.pw_fused_min_pixels = int(os.environ["MNAS_PW_FUSED_MIN"])
     if os.environ.get("MNAS_NO_MERGE"):      # diagnosis only: separate finalize launches
         eng.merge_post = False
     if os.environ.get("MNAS_PWB"):           # diagnosis only: large,mid,small persistent grids of the fused 1x1 backward
