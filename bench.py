@@ -73,7 +73,8 @@ def class_key(opc, ints, L):
     names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_conv<fwd>", L.OP_DW_BWD: "k_dw_bwd",
              L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
              L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd", L.OP_GRAM: "k_gram", L.OP_DW_EXP_FWD: "k_dw_fwd_exp",
-             L.OP_POOL_ACT: "k_pool", L.OP_POOL_BWD: "k_pool", L.OP_DY_MAT: "k_dy_mat"}
+             L.OP_POOL_ACT: "k_pool", L.OP_POOL_BWD: "k_pool", L.OP_DY_MAT: "k_dy_mat",
+             L.OP_TCONV_DGRAD: "k_igemm<dgrad>"}
     if opc == L.OP_CONV_GEMM:
         return "k_igemm<dgrad>" if ints[0] == 1 else "k_igemm<fwd>"
     if opc == L.OP_DW_BWD:          # i: N,H,W,C,k,nparts,phase (1 = input gradient, 2 = weight gradient launch)
@@ -106,6 +107,10 @@ def launch_work(opc, ints, L):
             nbytes, flops = 2 * 4 * e, 4.0 * e * k_ * k_
         else:       # each backward launch reads (g, y) and one more tensor / writes gin: 3 tensors
             nbytes, flops = 2 * 3 * e, 2.0 * e * k_ * k_
+    elif opc == L.OP_TCONV_DGRAD:   # i: N,Ho,Wo,Co,Ci: stride-2 3x3 input gradient: reads g and y of the conv output, writes gin (2Ho x 2Wo)
+        N_, Ho, Wo, Co, Ci = ints[:5]
+        nbytes = 2 * (2 * N_ * Ho * Wo * Co + N_ * 4 * Ho * Wo * Ci)
+        flops = 2.0 * N_ * Ho * Wo * Co * Ci * 9
     elif opc == L.OP_DW_EXP_FWD:    # i: N,H,W,C,k,Cin: the expand ConvBlock (in + out once) AND the depthwise ConvBlock (in + out once)
         N_, H_, W_, C_, k_, Ci = ints[:6]
         px = N_ * H_ * W_
@@ -223,6 +228,8 @@ def main():
         eng.use_side_stream = False
     if os.environ.get("MNAS_PW_FUSED_MIN"):  # diagnosis only: pixel count from which 1x1 convs use the fused backward
         eng.pw_fused_min_pixels = int(os.environ["MNAS_PW_FUSED_MIN"])
+    if os.environ.get("MNAS_NO_TCONV"):      # diagnosis only: stride-2 3x3 input gradients through k_igemm's parity-class form
+        eng.use_tconv = False
     if os.environ.get("MNAS_NO_MERGE"):      # diagnosis only: separate finalize launches
         eng.merge_post = False
     if os.environ.get("MNAS_PWB"):           # diagnosis only: large,mid,small persistent grids of the fused 1x1 backward
@@ -235,7 +242,7 @@ def main():
         eng.dw_fused_k = (3,)
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
-               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT}
+               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD}
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size

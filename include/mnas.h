@@ -100,6 +100,24 @@ int mnas_conv_gemm_tile_pixels(int M, int Co, int K);
  * taps = kh*kw. */
 int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps);
 
+/* ---- input gradient of the stride-2 dense 3x3 convs as a transposed convolution (csrc/mnas_tconv.hip): one GEMM per 2x2
+ * output block over the four dy pixels it depends on; no per-element gather.  dy: bf16 (N,Ho,Wo,Co), MATERIALISED
+ * (mnas_dy_materialize); w: mnas_pack_weights(MNAS_PACK_TCONV, Co, Ci, 3, 3); out: bf16 (N,2Ho,2Wo,Ci); optional fused
+ * BatchNorm-backward reduce as in mnas_conv_gemm mode 1 (stats: float[2][Ci][nparts]).  Supported: the conv's input plane is
+ * exactly 2Ho x 2Wo, 4*Co <= 256, 4*Ci <= 96 (mnas_tconv_supported); otherwise use mnas_conv_gemm(mode 1). */
+typedef struct MnasTconvDgrad {
+    int32_t N, Ho, Wo, Co, Ci, nparts;
+    const void* dy;
+    const void* w;
+    void* out;
+    float* stats;
+    const void* red_y;
+    const float* red_bn;
+} MnasTconvDgrad;
+int mnas_tconv_dgrad(const MnasTconvDgrad* a, void* stream);
+int mnas_tconv_supported(int Ho, int Wo, int Co, int Ci);
+int mnas_tconv_parts(int N, int Ho, int Wo, int Co, int Ci);     /* preferred nparts (persistent workgroups) */
+
 /* ---- weight gradient of the same convs: dW[co][tap][ci] = sum_pix dy[pix][co] * act(x)[src(pix,tap)][ci]
  * Replaces ATen conv2d weight-gradient.  x = (N,Hi,Wi,Ci) forward input, dy = (N,Ho,Wo,Co).
  * partial: float[nsplit][Co][K] (K = kh*kw*Ci), one slab per pixel split, fully overwritten;
@@ -303,6 +321,8 @@ int mnas_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int HW
 #define MNAS_PACK_FWD   0   /* bf16 [Co_pad16][Kpad32], k = tap*Ci+ci            (mnas_conv_gemm mode 0) */
 #define MNAS_PACK_DGRAD 1   /* bf16 [Ci_pad16][Kpad32], k = tap*Co+co            (mnas_conv_gemm mode 1) */
 #define MNAS_PACK_DW    2   /* fp32 [k*k][C]                                      (mnas_dw_*)            */
+#define MNAS_PACK_TCONV 3   /* bf16 [round16(4*Ci)][round32(4*Co)]: block matrix of a 3x3 stride-2 conv's taps by output parity
+                               class (rows) and dy neighbour (columns)            (mnas_tconv_dgrad)     */
 int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int kh, int kw, void* dst, void* stream);
 /* The same for many tensors in one launch: `descs` is a DEVICE array of n descriptors (taps = kh*kw; for MNAS_PACK_DW
  * Ci is ignored).  Used once per forward for all layers of the network. */
@@ -345,6 +365,7 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_POOL_BWD 23
 #define MNAS_OP_DY_MAT 24
 #define MNAS_OP_BWD_POST 25
+#define MNAS_OP_TCONV_DGRAD 26
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

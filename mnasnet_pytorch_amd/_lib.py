@@ -71,6 +71,12 @@ class MnasBwdPost(C.Structure):
                 ("bn_nparts", C.c_int32), ("bn_C", C.c_int32), ("w1", MnasPostWgrad), ("w2", MnasPostWgrad)]
 
 
+class MnasTconvDgrad(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32), ("Ci", C.c_int32),
+                ("nparts", C.c_int32), ("dy", c_void_p), ("w", c_void_p), ("out", c_void_p), ("stats", c_void_p),
+                ("red_y", c_void_p), ("red_bn", c_void_p)]
+
+
 class MnasPackDesc(C.Structure):
     _fields_ = [("w", c_void_p), ("dst", c_void_p), ("kind", C.c_int32), ("Co", C.c_int32), ("Ci", C.c_int32),
                 ("taps", C.c_int32)]
@@ -95,8 +101,8 @@ OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRA
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
 OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
 OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
-OP_BWD_POST = 25
-PACK_FWD, PACK_DGRAD, PACK_DW = 0, 1, 2
+OP_BWD_POST, OP_TCONV_DGRAD = 25, 26
+PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
 SYMBOLS = {
@@ -125,6 +131,9 @@ SYMBOLS = {
     "mnas_bn_fwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_float, c_float, c_int, c_void_p, c_void_p]),
     "mnas_bn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_tconv_dgrad": (c_int, [C.POINTER(MnasTconvDgrad), c_void_p]),
+    "mnas_tconv_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "mnas_tconv_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mnas_bwd_post": (c_int, [C.POINTER(MnasBwdPost), c_void_p]),
     "mnas_dy_materialize": (c_int, [C.POINTER(MnasGradIn), c_int64, c_int, c_void_p, c_void_p]),
     "mnas_bn_bwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -70,6 +70,7 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  DY_MAT           i: C                  d: rows                 p: g,y,coef,out
 //  BWD_POST         i: bn_nparts,bn_C, w1{nsplit,Co,Ci,taps,dw,level}, w2{...}   d: count
 //                   p: bn_partial,bnbuf,dgamma,dbeta, w1.partial,w1.grad, w2.partial,w2.grad
+//  TCONV_DGRAD      i: N,Ho,Wo,Co,Ci,nparts                       p: dy,w,out,stats,red_y,red_bn
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -180,6 +181,12 @@ static int run_one(const MnasOp& o, void* stream) {
             a.w1 = {(float*)p[4], (float*)p[5], i[2], i[3], i[4], i[5], i[6], i[7]};
             a.w2 = {(float*)p[6], (float*)p[7], i[8], i[9], i[10], i[11], i[12], i[13]};
             return mnas_bwd_post(&a, stream);
+        }
+        case MNAS_OP_TCONV_DGRAD: {
+            MnasTconvDgrad a = {};
+            a.N = i[0]; a.Ho = i[1]; a.Wo = i[2]; a.Co = i[3]; a.Ci = i[4]; a.nparts = i[5];
+            a.dy = p[0]; a.w = p[1]; a.out = p[2]; a.stats = (float*)p[3]; a.red_y = p[4]; a.red_bn = (const float*)p[5];
+            return mnas_tconv_dgrad(&a, stream);
         }
         case MNAS_OP_DY_MAT: {
             MnasGradIn d = {p[0], p[1], (const float*)p[2]};

@@ -398,6 +398,7 @@ extern "C" int64_t mnas_packed_bytes(int kind, int Co, int Ci, int kh, int kw) {
     if (kind == MNAS_PACK_FWD) return (int64_t)round_up(Co, 16) * round_up(kh * kw * Ci, 32) * 2;
     if (kind == MNAS_PACK_DGRAD) return (int64_t)round_up(Ci, 16) * round_up(kh * kw * Co, 32) * 2;
     if (kind == MNAS_PACK_DW) return (int64_t)kh * kw * Co * 4;
+    if (kind == MNAS_PACK_TCONV) return (int64_t)round_up(4 * Ci, 16) * round_up(4 * Co, 32) * 2;
     return -1;
 }
 
@@ -426,6 +427,20 @@ __global__ void k_pack_dw(const float* __restrict__ w, int C, int taps, float* _
         dst[i] = w[(size_t)c * taps + tap];
     }
 }
+// MNAS_PACK_TCONV element (r, k) of the [round16(4Ci)][round32(4Co)] matrix: row = parity class (ph,pw) x ci, column = dy
+// neighbour (dh,dw) x co; class ph = 0 only sees kh = 1 from dh = 0; ph = 1 sees kh = 2 from dh = 0 and kh = 0 from dh = 1.
+__device__ __forceinline__ float tconv_elem(const float* __restrict__ w, int Co, int Ci, int r, int k) {
+    if (r >= 4 * Ci || k >= 4 * Co) return 0.f;
+    const int cls = r / Ci, ci = r - cls * Ci, nb = k / Co, co = k - nb * Co;
+    const int ph = cls >> 1, pw = cls & 1, dh = nb >> 1, dw = nb & 1;
+    const int kh = ph == 0 ? (dh == 0 ? 1 : -1) : (dh == 0 ? 2 : 0);
+    const int kw = pw == 0 ? (dw == 0 ? 1 : -1) : (dw == 0 ? 2 : 0);
+    return (kh >= 0 && kw >= 0) ? w[(((size_t)co * Ci + ci) * 3 + kh) * 3 + kw] : 0.f;
+}
+__global__ void k_pack_tconv(const float* __restrict__ w, int Co, int Ci, uint16_t* __restrict__ dst) {
+    const int rows = (4 * Ci + 15) / 16 * 16, kpad = (4 * Co + 31) / 32 * 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * kpad; i += gridDim.x * 256) dst[i] = f_to_bf(tconv_elem(w, Co, Ci, i / kpad, i % kpad));
+}
 // All layers of a network in ONE launch: blockIdx.y selects the descriptor (device array), blockIdx.x strides over its
 // elements.  A training step re-packs ~80 small tensors (the weights change with every optimizer step); as separate
 // launches they cost ~4 us each at the head of the forward.
@@ -439,6 +454,13 @@ __global__ __launch_bounds__(256) void k_pack_batch(const MnasPackDesc* __restri
             const int tap = i / d.Co, c = i % d.Co;
             dst[i] = d.w[(size_t)c * taps + tap];
         }
+        return;
+    }
+    if (d.kind == MNAS_PACK_TCONV) {
+        const int rows = (4 * d.Ci + 15) / 16 * 16, kpad = (4 * d.Co + 31) / 32 * 32;
+        uint16_t* dst = (uint16_t*)d.dst;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * kpad; i += gridDim.x * 256)
+            dst[i] = f_to_bf(tconv_elem(d.w, d.Co, d.Ci, i / kpad, i % kpad));
         return;
     }
     const int S = (d.kind == MNAS_PACK_FWD) ? d.Ci : d.Co;
@@ -474,6 +496,9 @@ extern "C" int mnas_pack_weights(const float* w, int kind, int Co, int Ci, int k
         if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(k_pack_gemm, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, kind, Co, Ci, taps,
                            (uint16_t*)dst, rows_pad, kpad);
+    } else if (kind == MNAS_PACK_TCONV) {
+        if (kh != 3 || kw != 3) return MNAS_EINVAL;
+        hipLaunchKernelGGL(k_pack_tconv, dim3(32), dim3(256), 0, (hipStream_t)stream, w, Co, Ci, (uint16_t*)dst);
     } else if (kind == MNAS_PACK_DW) {
         int blocks = (Co * taps + 255) / 256;
         hipLaunchKernelGGL(k_pack_dw, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Co, taps, (float*)dst);

@@ -187,6 +187,8 @@ class Program:
                 descs.append((w.data_ptr(), ci.w_fwd.data_ptr(), L.PACK_FWD, ci.cout, ci.cin, ci.k * ci.k))
                 if training:
                     descs.append((w.data_ptr(), ci.w_dgrad.data_ptr(), L.PACK_DGRAD, ci.cout, ci.cin, ci.k * ci.k))
+                    if ci.w_tconv is not None:
+                        descs.append((w.data_ptr(), ci.w_tconv.data_ptr(), L.PACK_TCONV, ci.cout, ci.cin, 9))
             elif ci.kind == "dw":
                 descs.append((w.data_ptr(), ci.w_fwd.data_ptr(), L.PACK_DW, ci.cout, 1, ci.k * ci.k))
             else:  # stem: [Co][27] viewed as a 1x1 conv over 27 "channels"
@@ -485,14 +487,23 @@ class Program:
                     nparts = lib.mnas_conv_gemm_parts(1, Min, Co, ci.cin, ci.k * ci.k)
                     if nparts < 1:
                         nparts = max(1, min(1024, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
+                    tconv = (eng.use_tconv and ci.kind == "dense" and getattr(ci, "w_tconv", None) is not None and gyd is not gy and resid is None
+                             and Hi == 2 * Ho and Wi == 2 * Wo and lib.mnas_tconv_supported(Ho, Wo, Co, ci.cin))
+                    if tconv:
+                        nparts = lib.mnas_tconv_parts(N, Ho, Wo, Co, ci.cin)
                     red = [None, None, None]
                     if rt is not None:
                         red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
                         ncols = nparts
-                    ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
-                            [None, None, None] + gyd + [ci.w_dgrad.data_ptr(), None,
-                                                       resid.data_ptr() if resid is not None else None,
-                                                       gin.data_ptr(), red[0], red[1], red[2]])
+                    if tconv:
+                        # stride-2 3x3: transposed convolution over the materialised dy (csrc/mnas_tconv.hip)
+                        ops.add(L.OP_TCONV_DGRAD, [N, Ho, Wo, Co, ci.cin, nparts], [],
+                                [gyd[0], ci.w_tconv.data_ptr(), gin.data_ptr(), red[0], red[1], red[2]])
+                    else:
+                        ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
+                                [None, None, None] + gyd + [ci.w_dgrad.data_ptr(), None,
+                                                           resid.data_ptr() if resid is not None else None,
+                                                           gin.data_ptr(), red[0], red[1], red[2]])
             if ci.kind == "dw" and resid is not None:
                 raise AssertionError("residual add into a depthwise dgrad does not occur")
             return gin, ncols
@@ -693,6 +704,7 @@ class Engine:
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        self.use_tconv = True            # stride-2 dense 3x3 input gradient as a transposed convolution (csrc/mnas_tconv.hip)
         self.merge_post = True           # BatchNorm-backward finalize + weight-gradient reductions of the main stream in one launch
         self.materialize_dy = True       # dense 3x3 convs: dy formed once (mnas_dy_materialize), gathered plain by dgrad / wgrad
         # MBConv_block: expand + depthwise forward in ONE kernel (statistics from the input's covariance, csrc/mnas_gram.hip).
@@ -742,6 +754,10 @@ class Engine:
             if ci.kind in ("pw", "dense"):
                 ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
                 ci.w_dgrad = torch.empty(nbytes(L.PACK_DGRAD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
+                ci.w_tconv = None
+                if ci.kind == "dense" and ci.stride == 2 and self.use_tconv and self.materialize_dy and \
+                        self.lib.mnas_tconv_supported(8, 8, ci.cout, ci.cin):
+                    ci.w_tconv = torch.empty(nbytes(L.PACK_TCONV, ci.cout, ci.cin, 3, 3), dtype=torch.uint8, device=device)
                 K = ci.k * ci.k * ci.cin
                 slabs = _cdiv(ci.cout, 64) * _cdiv(K, 64)
                 wmax = max(wmax, max(1, _cdiv(1024, slabs)) * ci.cout * K)

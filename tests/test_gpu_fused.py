@@ -122,3 +122,47 @@ def test_dw_exp_fwd(shape, virt, keep_y1):
     assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), \
         "depthwise output differs: max |d| = %g" % float((out.float() - out_ref.float()).abs().max())
     assert relerr(st.cpu().double().sum(-1), st_ref.cpu().double().sum(-1)) < 2e-3
+
+
+TCONV = [  # N,Ho,Wo,Co,Ci  (forward conv: Ci -> Co, 3x3 stride 2 pad 1, input plane 2Ho x 2Wo)
+    (2, 6, 6, 24, 16), (3, 5, 7, 32, 16), (2, 28, 28, 24, 16), (1, 56, 56, 24, 16), (5, 9, 4, 16, 8), (2, 7, 9, 24, 24),
+]
+
+
+@pytest.mark.parametrize("shape", TCONV)
+@pytest.mark.parametrize("red", [True, False])
+def test_tconv_dgrad(shape, red):
+    """mnas_tconv_dgrad (transposed convolution over a materialised dy) against torch's conv2d input gradient on the same
+    bf16-rounded operands (<= 6e-3 of max|ref|) and, for the fused BatchNorm-backward reduce, against fp64 sums (<= 2e-3)."""
+    lib = L.load()
+    N, Ho, Wo, Co, Ci = shape
+    Hi, Wi = 2 * Ho, 2 * Wo
+    dy = _x((N, Co, Ho, Wo), 1)
+    w = bf16r(O.det_param("t.conv.weight", (Co, Ci, 3, 3), 2))
+    ref = torch.nn.grad.conv2d_input((N, Ci, Hi, Wi), w, dy, stride=2, padding=1)
+    dyd = nhwc(dy)
+    wp = pack(w, L.PACK_TCONV)
+    nparts = lib.mnas_tconv_parts(N, Ho, Wo, Co, Ci)
+    assert nparts >= 1 and lib.mnas_tconv_supported(Ho, Wo, Co, Ci)
+    out = torch.full((N, Hi, Wi, Ci), float("nan"), dtype=torch.bfloat16, device="cuda")
+    a = L.MnasTconvDgrad()
+    a.N, a.Ho, a.Wo, a.Co, a.Ci, a.nparts = N, Ho, Wo, Co, Ci, nparts
+    a.dy, a.w, a.out = dyd.data_ptr(), wp.data_ptr(), out.data_ptr()
+    if red:
+        from gpu_util import rand_bn_coefs
+        y_t = _x((N, Ci, Hi, Wi), 5)
+        b = rand_bn_coefs(Ci, 9, O)
+        ytd, bd = nhwc(y_t), b.cuda()
+        st = torch.full((2, Ci, nparts), float("nan"), device="cuda")
+        a.stats, a.red_y, a.red_bn = st.data_ptr(), ytd.data_ptr(), bd.data_ptr()
+    L.check(lib.mnas_tconv_dgrad(C.byref(a), L.cur_stream()), "tconv_dgrad")
+    got = from_nhwc(out)
+    assert relerr(got, ref) < 6e-3
+    if red:
+        g = bf16r(got)                                   # the reduce uses the gradient as stored
+        s_, t_ = b[0].view(1, -1, 1, 1), b[1].view(1, -1, 1, 1)
+        dz = (g * ((s_ * y_t + t_) > 0)).double()
+        xhat = ((y_t - b[5].view(1, -1, 1, 1)) * b[6].view(1, -1, 1, 1)).double()
+        tot = st.cpu().double().sum(-1)
+        assert relerr(tot[0], dz.sum((0, 2, 3))) < 2e-3
+        assert relerr(tot[1], (dz * xhat).sum((0, 2, 3))) < 2e-3
