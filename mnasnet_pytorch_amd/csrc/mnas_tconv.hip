@@ -131,23 +131,39 @@ __global__ __launch_bounds__(256) void k_tconv(TconvArgs a) {
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    auto copy_out = [&](int obuf, int tile0) {
-        if (tid >= tcols) return;
+    // The output offsets of the rows this thread copies out, and the fused-reduce operand (raw output of the target layer at
+    // those offsets), are prepared ONE PHASE AHEAD: plan_out(t) runs in tile t's own phase (decode + 16-byte loads in flight
+    // under the MFMAs), copy_out consumes them in the next phase -- no load latency and no address decode on the copy-out path.
+    constexpr int MAXR = PT == 1 ? 4 : 7;                    // rows per thread: ceil(BP / (tcols / nch8)), nch8 <= 12
+    int ooff[MAXR];
+    uint4 yreg[MAXR];
+    auto plan_out = [&](int tile0) {
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            const int p = orow0 + k * orows, m = tile0 + p;
+            ooff[k] = -1;
+            yreg[k] = make_uint4(0, 0, 0, 0);
+            if (tid < tcols && p < BP && m < a.M2) {
+                const int hw = a.Ho * a.Wo;
+                const int n = tc_fdiv(m, hw, a.rcp_hw), rem = m - n * hw;
+                const int ii = tc_fdiv(rem, a.Wo, a.rcp_wo), jj = rem - ii * a.Wo;
+                ooff[k] = (((n * 2 * a.Ho + 2 * ii + (ocls >> 1)) * 2 * a.Wo + 2 * jj + (ocls & 1)) * a.Ci + occ * 8);
+                if (do_red) yreg[k] = *(const uint4*)((const uint16_t*)a.red_y + ooff[k]);
+            }
+        }
+    };
+    auto copy_out = [&](int obuf) {
         const uint4* o = lds_o + obuf * BP * OPITCH;
-        for (int p = orow0; p < BP; p += orows) {
-            const int m = tile0 + p;
-            if (m >= a.M2) break;
-            const int hw = a.Ho * a.Wo;
-            const int n = tc_fdiv(m, hw, a.rcp_hw), rem = m - n * hw;
-            const int ii = tc_fdiv(rem, a.Wo, a.rcp_wo), jj = rem - ii * a.Wo;
-            const size_t off = ((((size_t)n * 2 * a.Ho + 2 * ii + (ocls >> 1)) * 2 * a.Wo + 2 * jj + (ocls & 1)) * a.Ci + occ * 8);
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            if (ooff[k] < 0) continue;
+            const int p = orow0 + k * orows;
             const uint4 pk = o[p * OPITCH + oc8];
-            *(uint4*)((uint16_t*)a.out + off) = pk;
+            *(uint4*)((uint16_t*)a.out + ooff[k]) = pk;
             if (do_red) {
-                const uint4 yv = *(const uint4*)((const uint16_t*)a.red_y + off);
                 float gq[8], yq[8];
                 unpack8(pk, gq);
-                unpack8(yv, yq);
+                unpack8(yreg[k], yq);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = occ * 8 + j;
@@ -169,7 +185,8 @@ __global__ __launch_bounds__(256) void k_tconv(TconvArgs a) {
         clear_a(slot);
         __syncthreads();
         if (t + (int)gridDim.x < ntiles) dma_a(slot ^ 1, (t + gridDim.x) * BP);
-        if (prev_tile0 >= 0) { copy_out(obuf ^ 1, prev_tile0); prev_tile0 = -1; }
+        if (prev_tile0 >= 0) { copy_out(obuf ^ 1); prev_tile0 = -1; }
+        plan_out(tile0);
         f32x4_t acc[PT][NT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(256) void k_tconv(TconvArgs a) {
         obuf ^= 1;
     }
     __syncthreads();
-    if (prev_tile0 >= 0) copy_out(obuf ^ 1, prev_tile0);
+    if (prev_tile0 >= 0) copy_out(obuf ^ 1);
 
     if (do_red && a.stats) {
         // per-thread sums -> per-channel: the threads of one channel chunk (all classes, all row lanes) added in thread order
@@ -259,7 +276,7 @@ extern "C" int mnas_tconv_dgrad(const MnasTconvDgrad* c, void* stream) {
     if (c->red_y && (!c->red_bn || !c->stats)) return MNAS_EINVAL;
     int nt, pt; size_t lds;
     const long long M2 = (long long)c->N * c->Ho * c->Wo;
-    if (M2 > 0x7fffffff || !tconv_ok(c->Ho, c->Wo, c->Co, c->Ci, &nt, &pt, &lds, M2)) return MNAS_EINVAL;
+    if (M2 * 4 * c->Ci > 0x7fffffff || !tconv_ok(c->Ho, c->Wo, c->Co, c->Ci, &nt, &pt, &lds, M2)) return MNAS_EINVAL;
     TconvArgs a;
     a.M2 = (int)M2; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co; a.Ci = c->Ci;
     a.K = 4 * c->Co; a.Kpad = (a.K + 31) / 32 * 32; a.nch = a.Kpad / 8; a.N4 = 4 * c->Ci;
