@@ -226,6 +226,8 @@ def main():
     eng = trainer.engine
     if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
         eng.use_side_stream = False
+    if os.environ.get("MNAS_PW_SPLIT_MAX"):  # diagnosis only: pixel count below which project convs use dgrad + wgrad kernels
+        eng.pw_split_max_pixels = int(os.environ["MNAS_PW_SPLIT_MAX"])
     if os.environ.get("MNAS_PW_FUSED_MIN"):  # diagnosis only: pixel count from which 1x1 convs use the fused backward
         eng.pw_fused_min_pixels = int(os.environ["MNAS_PW_FUSED_MIN"])
     if os.environ.get("MNAS_NO_TCONV"):      # diagnosis only: stride-2 3x3 input gradients through k_igemm's parity-class form

@@ -21,6 +21,14 @@ int mnas_pwf_enabled() {
     }
     return on;
 }
+int mnas_pwd_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("MNAS_PWD");
+        on = (e ? atoi(e) : 1) && mnas_pwf_enabled();
+    }
+    return on;
+}
 
 int mnas_pws_enabled() {
     static int on = -1;

@@ -557,6 +557,7 @@ extern "C" int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps) {
         if (p > 0) return p;
     }
     if (mode == 0 && taps == 1 && mnas_pwf_enabled()) return mnas_pwf_parts(M, Ci, Co);
+    if (mode == 1 && taps == 1 && mnas_pwd_enabled()) return mnas_pwd_parts(M, Ci, Co);
     return -1;
 }
 
@@ -597,6 +598,8 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (a.is_pw && (c->mode == 1 || !c->resid) && mnas_pws_parts(c->mode, a.M, c->Ci, c->Co) > 0) return mnas_pws_run(c, stream);
     if (c->mode == 0 && a.is_pw && !c->resid && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwf_forward(c, stream);
+    if (c->mode == 1 && a.is_pw && !c->resid && !c->bias && mnas_pwd_enabled() && mnas_pwd_parts(a.M, c->Ci, c->Co) > 0)
+        return mnas_pwd_dgrad(c, stream);
 
     int best_nt, nblocks, pt;
     igemm_tiling(c->Co, a.Kpad, a.M, &best_nt, &nblocks, &pt);

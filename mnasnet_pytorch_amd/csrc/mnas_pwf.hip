@@ -40,9 +40,17 @@ struct PwfArgs {
     const float* bias;
     void* out;
     float* stats;            // [2][Co][gridDim.x] or NULL
+    // MODE 1 (input gradient of a WIDENING-in-backward 1x1 conv, i.e. the project conv: few dy channels, many outputs)
+    MnasGradIn grad;         // dy-on-load operand (M, Ci); coef == NULL: g is dy
+    const void* red_y;       // fused BatchNorm-backward reduce target (M, Co) or NULL
+    const float* red_bn;
 };
 
-template <int NT, int PT, bool WRES>
+// MODE 0: forward (see above).  MODE 1: out[M][Co] = dy[M][Ci] * Wd[Co][Ci]^T with dy = c1*(g*[s*y+t>0]) + c2*y + c3 formed
+// in place in LDS from the DMA'd raw (g, y) tiles, no bias / statistics of the output; instead the optional fused
+// BatchNorm-backward reduce of the layer the result is the gradient of (as k_igemm MODE 1), done on the copy-out path where a
+// thread owns one 16-byte channel column: the reduce operand red_y is loaded one phase ahead.
+template <int MODE, int NT, int PT, bool WRES>
 __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT, NB = NT * 16;
@@ -51,17 +59,21 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
     constexpr int MAXW = (NB * 17 + 255) / 256;              //                                  weight block
     constexpr int NO = (BP * (NB / 8) + 255) / 256;          // out-stage copy slots per thread
     const int pitch = a.nch + 1;
-    float* lds_coef = (float*)smem;                                      // [2][Kpad]
-    uint4* lds_a = (uint4*)(lds_coef + 2 * a.Kpad);                      // [2][BP * pitch]
-    uint4* lds_w = lds_a + 2 * BP * pitch;                               // [WRES ? nkc : 2][NB * pitch]
+    constexpr int CROWS = MODE == 1 ? 5 : 2;
+    constexpr int ASLOTS = MODE == 1 ? 3 : 2;                // MODE 1: slot 2 is the (single-buffered) raw-y tile
+    float* lds_coef = (float*)smem;                                      // [CROWS][Kpad]
+    float* lds_redc = lds_coef + CROWS * a.Kpad;                         // MODE 1: [4][NB] reduce coefficients
+    uint4* lds_a = (uint4*)(lds_redc + (MODE == 1 ? 4 * NB : 0));        // [ASLOTS][BP * pitch]
+    uint4* lds_w = lds_a + ASLOTS * BP * pitch;                          // [WRES ? nkc : 2][NB * pitch]
     uint4* lds_o = lds_w + (WRES ? a.nkc : 2) * NB * pitch;              // [2][BP * OPITCH]
-    float* lds_red = (float*)lds_o;                                      // reused at the very end: [4][2][NB]
+    float* lds_red = (float*)lds_o;                                      // reused at the very end: [4][2][NB] / MODE 1 [256][16]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const int n0 = blockIdx.y * NB;
-    const bool has_coef = a.act.scale != nullptr;
+    const bool has_coef = MODE == 1 ? a.grad.coef != nullptr : a.act.scale != nullptr;
+    const bool do_red = MODE == 1 && a.red_y != nullptr;
     const int na = (BP * pitch + 255) >> 8, nw = (NB * pitch + 255) >> 8;   // DMA rounds (uniform)
 
     // ---- slot plans (tile-invariant): slot q = 256*i + tid = row * pitch + j
@@ -80,26 +92,48 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
     }
     // ---- one-time setup: zero the tiles (K padding and never-written slots must read as 0), coefficient table
     {
-        const int nz = (2 * BP + (WRES ? a.nkc : 2) * NB) * pitch;
+        const int nz = (ASLOTS * BP + (WRES ? a.nkc : 2) * NB) * pitch;
         for (int i = tid; i < nz; i += 256) lds_a[i] = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < 2 * a.Kpad; i += 256) {
+        for (int i = tid; i < CROWS * a.Kpad; i += 256) {
             const int r = i / a.Kpad, c = i - r * a.Kpad;
-            lds_coef[i] = (has_coef && c < a.Ci) ? (r == 0 ? a.act.scale[c] : a.act.shift[c]) : 0.f;
+            float v = 0.f;
+            if (has_coef && c < a.Ci) {
+                if (MODE == 1) v = a.grad.coef[r * a.Ci + c];
+                else v = r == 0 ? a.act.scale[c] : a.act.shift[c];
+            }
+            lds_coef[i] = v;
         }
+        if (do_red)
+            for (int i = tid; i < 4 * NB; i += 256) {      // (s, t, invstd, -mean*invstd) of the reduce target, as k_igemm
+                const int r = i / NB, co = n0 + i % NB;
+                float v = 0.f;
+                if (co < a.Co) {
+                    if (r == 0) v = a.red_bn[0 * a.Co + co];
+                    else if (r == 1) v = a.red_bn[1 * a.Co + co];
+                    else if (r == 2) v = a.red_bn[6 * a.Co + co];
+                    else v = -a.red_bn[5 * a.Co + co] * a.red_bn[6 * a.Co + co];
+                }
+                lds_redc[i] = v;
+            }
     }
     __syncthreads();
 
     auto dma_a = [&](int slot, int tile0, int k0) {
         uint4* dst = lds_a + slot * BP * pitch;
-        const uint16_t* src = (const uint16_t*)a.act.data;
+        uint4* dsty = lds_a + 2 * BP * pitch;
+        const uint16_t* src = (const uint16_t*)(MODE == 1 ? a.grad.g : a.act.data);
+        const uint16_t* srcy = (const uint16_t*)a.grad.y;
         if (a.abl & 8) return;
 #pragma unroll
         for (int i = 0; i < MAXA; ++i) {
             if (i >= na) break;
             const int k = k0 + ja[i] * 8;
-            if (ja[i] >= 0 && k < a.Ci && tile0 + pa[i] < a.M)
-                __builtin_amdgcn_global_load_lds((pwf_gbl_ptr)(src + (size_t)(tile0 + pa[i]) * a.Ci + k),
-                                                 (pwf_lds_ptr)(dst + 256 * i + wave * 64), 16, 0, 0);
+            if (ja[i] >= 0 && k < a.Ci && tile0 + pa[i] < a.M) {
+                const size_t off = (size_t)(tile0 + pa[i]) * a.Ci + k;
+                __builtin_amdgcn_global_load_lds((pwf_gbl_ptr)(src + off), (pwf_lds_ptr)(dst + 256 * i + wave * 64), 16, 0, 0);
+                if (MODE == 1 && has_coef)
+                    __builtin_amdgcn_global_load_lds((pwf_gbl_ptr)(srcy + off), (pwf_lds_ptr)(dsty + 256 * i + wave * 64), 16, 0, 0);
+            }
         }
     };
     auto dma_w = [&](int slot, int k0) {
@@ -127,7 +161,19 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
                 *(float4*)&s[4] = *(const float4*)(lds_coef + k + 4);
                 *(float4*)&sh[0] = *(const float4*)(lds_coef + a.Kpad + k);
                 *(float4*)&sh[4] = *(const float4*)(lds_coef + a.Kpad + k + 4);
-                t[256 * i + tid] = act8(t[256 * i + tid], s, sh);
+                if constexpr (MODE == 1) {
+                    float c1[8], c2[8], c3[8], d[8];
+                    *(float4*)&c1[0] = *(const float4*)(lds_coef + 2 * a.Kpad + k);
+                    *(float4*)&c1[4] = *(const float4*)(lds_coef + 2 * a.Kpad + k + 4);
+                    *(float4*)&c2[0] = *(const float4*)(lds_coef + 3 * a.Kpad + k);
+                    *(float4*)&c2[4] = *(const float4*)(lds_coef + 3 * a.Kpad + k + 4);
+                    *(float4*)&c3[0] = *(const float4*)(lds_coef + 4 * a.Kpad + k);
+                    *(float4*)&c3[4] = *(const float4*)(lds_coef + 4 * a.Kpad + k + 4);
+                    dy8(t[256 * i + tid], lds_a[2 * BP * pitch + 256 * i + tid], s, sh, c1, c2, c3, d);
+                    t[256 * i + tid] = pack8(d);
+                } else {
+                    t[256 * i + tid] = act8(t[256 * i + tid], s, sh);
+                }
             }
         }
     };
@@ -140,6 +186,51 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
             const int m = tile0 + p, co = n0 + c8 * 8;
             if (p < BP && m < a.M && co < a.Co && !(a.abl & 1))
                 st_u4((uint16_t*)a.out + (size_t)m * a.Co + co, o[p * OPITCH + c8], a.nt_store);
+        }
+    };
+
+    // MODE 1 copy-out role: thread -> fixed 16-byte channel column of the out-stage rows orow0, orow0 + orows, ...
+    constexpr int NCH8 = NB / 8;
+    constexpr int TCOLS = (256 / NCH8) * NCH8, OROWS = TCOLS / NCH8;
+    constexpr int MAXR = MODE == 1 ? (BP + OROWS - 1) / OROWS : 1;
+    const int oc8 = tid % NCH8, orow0 = tid / NCH8;
+    float r1[8], r2[8];
+    int ooff[MAXR];
+    uint4 yreg[MAXR];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; }
+    auto plan_out = [&](int tile0) {          // runs in tile t's own phase; copy_out1 consumes it one phase later
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            const int p = orow0 + k * OROWS, m = tile0 + p, co = n0 + oc8 * 8;
+            ooff[k] = -1;
+            yreg[k] = make_uint4(0, 0, 0, 0);
+            if (tid < TCOLS && p < BP && m < a.M && co < a.Co) {
+                ooff[k] = m * a.Co + co;
+                if (do_red) yreg[k] = *(const uint4*)((const uint16_t*)a.red_y + ooff[k]);
+            }
+        }
+    };
+    auto copy_out1 = [&](int obuf) {
+        const uint4* o = lds_o + obuf * BP * OPITCH;
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            if (ooff[k] < 0) continue;
+            const int p = orow0 + k * OROWS;
+            const uint4 pk = o[p * OPITCH + oc8];
+            if (!(a.abl & 1)) st_u4((uint16_t*)a.out + ooff[k], pk, a.nt_store);
+            if (do_red) {
+                float gq[8], yq[8];
+                unpack8(pk, gq);
+                unpack8(yreg[k], yq);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = oc8 * 8 + j;
+                    const float dz = (fmaf(yq[j], lds_redc[c], lds_redc[NB + c]) > 0.f) ? gq[j] : 0.f;
+                    r1[j] += dz;
+                    r2[j] = fmaf(dz, fmaf(yq[j], lds_redc[2 * NB + c], lds_redc[3 * NB + c]), r2[j]);
+                }
+            }
         }
     };
 
@@ -186,7 +277,11 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
                     if (!WRES) dma_w(slot ^ 1, nk * a.kc);
                 }
             }
-            if (prev_tile0 >= 0) { copy_out(obuf ^ 1, prev_tile0); prev_tile0 = -1; }
+            if (prev_tile0 >= 0) {
+                if constexpr (MODE == 1) copy_out1(obuf ^ 1); else copy_out(obuf ^ 1, prev_tile0);
+                prev_tile0 = -1;
+            }
+            if (MODE == 1 && kc == 0) plan_out(tile0);
             const uint4* ta = lds_a + slot * BP * pitch;
             const uint4* tw = lds_w + (WRES ? kc : slot) * NB * pitch;
             const int ksteps = (a.abl & 4) ? 0 : (min(a.kc, a.Kpad - k0) >> 5);
@@ -214,8 +309,8 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
             for (int nt = 0; nt < NT; ++nt) {
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[pt][nt][r] + bias_r[nt][r];
-                if (mok) {
+                for (int r = 0; r < 4; ++r) v[r] = MODE == 1 ? acc[pt][nt][r] : acc[pt][nt][r] + bias_r[nt][r];
+                if (MODE == 0 && mok) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { s1[nt][r] += v[r]; s2[nt][r] = fmaf(v[r], v[r], s2[nt][r]); }
                 }
@@ -229,8 +324,26 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
         obuf ^= 1;
     }
     __syncthreads();
-    if (prev_tile0 >= 0) copy_out(obuf ^ 1, prev_tile0);
+    if (prev_tile0 >= 0) {
+        if constexpr (MODE == 1) copy_out1(obuf ^ 1); else copy_out(obuf ^ 1, prev_tile0);
+    }
 
+    if constexpr (MODE == 1) {
+        if (do_red && a.stats) {
+            // per-thread sums -> per-channel: the threads of one channel column added in thread order (deterministic)
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lds_red[tid * 16 + j] = r1[j]; lds_red[tid * 16 + 8 + j] = r2[j]; }
+            __syncthreads();
+            for (int i = tid; i < 2 * NB; i += 256) {
+                const int r = i / NB, cl = i % NB, c = n0 + cl;
+                float v = 0.f;
+                for (int th = cl >> 3; th < TCOLS; th += NCH8) v += lds_red[th * 16 + r * 8 + (cl & 7)];
+                if (c < a.Co) a.stats[((size_t)r * a.Co + c) * gridDim.x + blockIdx.x] = v;
+            }
+        }
+        return;
+    }
     if (a.stats) {
         // deterministic workgroup reduction (as k_igemm): 16-lane shuffle tree, one LDS slot per (wave, channel), waves in order
         __syncthreads();
@@ -259,12 +372,13 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct PwfPlan { int nt, nblocks, pt, kc, nkc, wres; size_t lds; };
 
-static size_t pwf_lds_bytes(int nt, int pt, int Kpad, int kc, int nkc, int wres) {
+static size_t pwf_lds_bytes(int mode, int nt, int pt, int Kpad, int kc, int nkc, int wres) {
     const int BP = 64 * pt, NB = nt * 16, pitch = kc / 8 + 1;
-    size_t b = (size_t)2 * Kpad * 4;
-    b += (size_t)2 * BP * pitch * 16;
+    size_t b = (size_t)(mode == 1 ? 5 : 2) * Kpad * 4;
+    if (mode == 1) b += (size_t)4 * NB * 4;
+    b += (size_t)(mode == 1 ? 3 : 2) * BP * pitch * 16;
     b += (size_t)(wres ? nkc : 2) * NB * pitch * 16;
-    size_t o = (size_t)2 * BP * (NB / 8 + 1) * 16, red = (size_t)8 * NB * 4;
+    size_t o = (size_t)2 * BP * (NB / 8 + 1) * 16, red = mode == 1 ? (size_t)256 * 16 * 4 : (size_t)8 * NB * 4;
     b += o > red ? o : red;
     return b;
 }
@@ -293,16 +407,35 @@ static bool pwf_plan(int M, int Ci, int Co, PwfPlan* p) {
     // whole weight block resident when it is small (single-chunk layers, and multi-chunk ones up to 48 KB)
     const size_t wbytes = (size_t)p->nkc * nt * 16 * (p->kc / 8 + 1) * 16;
     p->wres = wbytes <= 48 * 1024 ? 1 : 0;
-    p->lds = pwf_lds_bytes(nt, p->pt, Kpad, p->kc, p->nkc, p->wres);
-    if (p->lds > 96 * 1024 && p->wres) { p->wres = 0; p->lds = pwf_lds_bytes(nt, p->pt, Kpad, p->kc, p->nkc, 0); }
-    if (p->lds > 96 * 1024 && p->pt == 2) { p->pt = 1; p->lds = pwf_lds_bytes(nt, 1, Kpad, p->kc, p->nkc, p->wres); }
+    p->lds = pwf_lds_bytes(0, nt, p->pt, Kpad, p->kc, p->nkc, p->wres);
+    if (p->lds > 96 * 1024 && p->wres) { p->wres = 0; p->lds = pwf_lds_bytes(0, nt, p->pt, Kpad, p->kc, p->nkc, 0); }
+    if (p->lds > 96 * 1024 && p->pt == 2) { p->pt = 1; p->lds = pwf_lds_bytes(0, nt, 1, Kpad, p->kc, p->nkc, p->wres); }
     return p->lds <= 160 * 1024;
 }
 
-// persistent workgroups along the pixel dimension for a 1x1 forward with M pixels (host-side, no launch)
-int mnas_pwf_parts(int M, int Ci, int Co) {
-    PwfPlan p;
-    if (!pwf_plan(M, Ci, Co, &p)) return -1;
+// MODE 1: K = dy channels (<= 128, one chunk, weights resident), Co = conv input channels > K.  Channel block = the tile
+// count (<= 6) with the least padding among those that leave room for two workgroups per CU (80 KB each).
+static bool pwd_plan(int M, int Ci, int Co, PwfPlan* p) {
+    if ((Ci & 7) || (Co & 7) || Ci < 8 || Co < 8 || M < 1 || !mnas_pwf_enabled()) return false;
+    if (!(Co > Ci && Ci <= 128) || (int64_t)M * Co >= (1ll << 31)) return false;
+    const int tiles = (Co + 15) / 16, Kpad = (Ci + 31) / 32 * 32;
+    p->kc = Kpad; p->nkc = 1; p->wres = 1;
+    p->pt = ((int64_t)M >= 400000) ? 2 : 1;
+    for (; p->pt >= 1; --p->pt) {
+        int best = 1 << 30;
+        p->nt = 0;
+        for (int c = tiles < 6 ? tiles : 6; c >= 1; --c) {
+            const size_t lds = pwf_lds_bytes(1, c, p->pt, Kpad, Kpad, 1, 1);
+            if (lds > 80 * 1024) continue;
+            const int b = (tiles + c - 1) / c, waste = b * c - tiles;
+            if (waste < best) { best = waste; p->nt = c; p->nblocks = b; p->lds = lds; }
+        }
+        if (p->nt) return true;
+    }
+    return false;
+}
+
+static int pwf_grid(const PwfPlan& p, int M) {
     const int ntiles = (M + 64 * p.pt - 1) / (64 * p.pt);
     const int per_cu = (int)(160 * 1024 / p.lds) < 1 ? 1 : (int)(160 * 1024 / p.lds);
     int want = 256 * (per_cu > 3 ? 3 : per_cu) / p.nblocks;      // fill the chip once with resident workgroups
@@ -311,10 +444,30 @@ int mnas_pwf_parts(int M, int Ci, int Co) {
     return ntiles < want ? ntiles : want;
 }
 
-template <int NT, int PT>
+// persistent workgroups along the pixel dimension for a 1x1 forward with M pixels (host-side, no launch)
+int mnas_pwf_parts(int M, int Ci, int Co) {
+    PwfPlan p;
+    if (!pwf_plan(M, Ci, Co, &p)) return -1;
+    return pwf_grid(p, M);
+}
+// same for the input gradient (Ci = dy channels, Co = channels of the result)
+int mnas_pwd_parts(int M, int Ci, int Co) {
+    PwfPlan p;
+    if (!pwd_plan(M, Ci, Co, &p)) return -1;
+    // exactly the resident capacity (two workgroups per CU), never a second partial round of workgroups; a multiple of 8:
+    // the channel blocks of one pixel tile then land on the same XCD (shared L2)
+    const int ntiles = (M + 64 * p.pt - 1) / (64 * p.pt);
+    int g = 256 * (int)(160 * 1024 / p.lds) / p.nblocks;
+    if (const char* e = getenv("MNAS_PWD_GRID")) g = atoi(e);
+    if (g > ntiles) g = ntiles;
+    if (g > 8) g &= ~7;
+    return g < 1 ? 1 : g;
+}
+
+template <int MODE, int NT, int PT>
 static int pwf_launch2(const PwfArgs& a, const PwfPlan& p, int nparts, hipStream_t s) {
-    if (p.wres) hipLaunchKernelGGL((k_pwf<NT, PT, true>), dim3(nparts, p.nblocks), dim3(256), p.lds, s, a);
-    else hipLaunchKernelGGL((k_pwf<NT, PT, false>), dim3(nparts, p.nblocks), dim3(256), p.lds, s, a);
+    if (p.wres) hipLaunchKernelGGL((k_pwf<MODE, NT, PT, true>), dim3(nparts, p.nblocks), dim3(256), p.lds, s, a);
+    else if (MODE == 0) hipLaunchKernelGGL((k_pwf<0, NT, PT, false>), dim3(nparts, p.nblocks), dim3(256), p.lds, s, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -332,9 +485,34 @@ int mnas_pwf_forward(const MnasConvGemm* c, void* stream) {
     a.nt_store = (mnas_nt_mask() & MNAS_NT_PWF) ? 1 : 0;
     { const char* e = getenv("MNAS_PWF_ABL"); a.abl = e ? atoi(e) : 0; }
     a.act = c->act; a.w = (const uint16_t*)c->w; a.bias = c->bias; a.out = c->out; a.stats = c->stats;
+    a.grad.g = nullptr; a.grad.y = nullptr; a.grad.coef = nullptr; a.red_y = nullptr; a.red_bn = nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define MNAS_PWF(NT_) if (p.nt == NT_) return p.pt == 2 ? pwf_launch2<NT_, 2>(a, p, c->nparts, s) : pwf_launch2<NT_, 1>(a, p, c->nparts, s);
+#define MNAS_PWF(NT_) if (p.nt == NT_) return p.pt == 2 ? pwf_launch2<0, NT_, 2>(a, p, c->nparts, s) : pwf_launch2<0, NT_, 1>(a, p, c->nparts, s);
     MNAS_PWF(1) MNAS_PWF(2) MNAS_PWF(3) MNAS_PWF(4) MNAS_PWF(5) MNAS_PWF(6)
 #undef MNAS_PWF
+    return MNAS_EINVAL;
+}
+
+// called by mnas_conv_gemm for mode 1, 1x1, stride 1, no residual (MNAS_EINVAL: not this kernel's shape, caller falls back)
+int mnas_pwd_dgrad(const MnasConvGemm* c, void* stream) {
+    PwfPlan p;
+    const int M = c->N * c->Ho * c->Wo;
+    if (c->resid || c->bias || !pwd_plan(M, c->Ci, c->Co, &p)) return MNAS_EINVAL;
+    if ((c->grad.coef == nullptr) != (c->grad.y == nullptr)) return MNAS_EINVAL;
+    PwfArgs a;
+    a.M = M; a.Ci = c->Ci; a.Co = c->Co;
+    a.Kpad = (c->Ci + 31) / 32 * 32;
+    a.kc = p.kc; a.nkc = 1; a.nch = p.kc / 8;
+    a.co_pad16 = (c->Co + 15) / 16 * 16;
+    a.nt_store = (mnas_nt_mask() & MNAS_NT_PWF) ? 1 : 0;
+    { const char* e = getenv("MNAS_PWF_ABL"); a.abl = e ? atoi(e) : 0; }
+    a.act.data = nullptr; a.act.scale = nullptr; a.act.shift = nullptr;
+    a.w = (const uint16_t*)c->w; a.bias = nullptr; a.out = c->out;
+    a.grad = c->grad; a.red_y = c->red_y; a.red_bn = c->red_bn;
+    a.stats = c->red_y ? c->stats : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+#define MNAS_PWD(NT_) if (p.nt == NT_) return p.pt == 2 ? pwf_launch2<1, NT_, 2>(a, p, c->nparts, s) : pwf_launch2<1, NT_, 1>(a, p, c->nparts, s);
+    MNAS_PWD(1) MNAS_PWD(2) MNAS_PWD(3) MNAS_PWD(4) MNAS_PWD(5) MNAS_PWD(6)
+#undef MNAS_PWD
     return MNAS_EINVAL;
 }

@@ -456,7 +456,9 @@ class Program:
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
                     ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                     ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
-            elif ci.kind == "pw" and need_gin and M >= eng.pw_fused_min_pixels and lib.mnas_pw_bwd_supported(ci.cin, Co):
+            elif (ci.kind == "pw" and need_gin and M >= eng.pw_fused_min_pixels and lib.mnas_pw_bwd_supported(ci.cin, Co)
+                  and not (M < eng.pw_split_max_pixels and resid is None and Co < ci.cin and Co <= 128
+                           and lib.mnas_conv_gemm_parts(1, M, Co, ci.cin, 1) > 0)):
                 # large-pixel-count 1x1 conv: ONE sweep produces the input gradient, the weight-gradient partials and the
                 # fused reduce (both former kernels stream the same g, y; see csrc/mnas_pwbwd.hip).  Main stream.
                 gin = new((N, Hi, Wi, ci.cin))
@@ -720,6 +722,11 @@ class Engine:
         # per launch at bs 256 against the dgrad + wgrad pair: 201 vs 399 us (16->48 @112^2), 233 vs 331 (48->16), 119 vs 285
         # (32->16), 90 vs 199 (24->72 @56^2), 105 vs 195 (72->24), 81 vs 141 (40->240 @28^2), 111 vs 175 (240->40)
         self.pw_fused_min_pixels = 50000
+        # narrowing (project) 1x1 convs below this pixel count: DMA-pipelined input gradient on the main stream
+        # (csrc/mnas_pwf.hip MODE 1) + weight gradient on the side stream, instead of the fused sweep.  Off: alone the input
+        # gradient takes 68 us against the fused kernel's 116 (576->96 at 14x14, bs 256), but next to the side stream's
+        # k_wgrad it takes 130 us and the step is 0.1 ms slower (12.56 vs 12.44 ms)
+        self.pw_split_max_pixels = 0
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
         self.pw_bwd_parts_small = 64     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)

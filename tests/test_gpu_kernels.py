@@ -62,7 +62,7 @@ def test_bn_fwd_finalize(C_, nparts, count):
 # ---------------------------------------------------------------------------------------------------
 PW = [  # N,H,W,Ci,Co
     (2, 12, 12, 16, 48), (2, 12, 12, 48, 16), (3, 9, 7, 72, 24), (2, 6, 7, 96, 576), (2, 5, 5, 1152, 192),
-    (5, 16, 16, 32, 16), (2, 7, 7, 240, 40), (1, 28, 28, 40, 240),
+    (5, 16, 16, 32, 16), (2, 7, 7, 240, 40), (1, 28, 28, 40, 240), (2, 14, 14, 576, 96), (1, 9, 9, 480, 80), (3, 5, 5, 120, 40),
 ]
 
 
@@ -138,6 +138,21 @@ def test_pw_dgrad(shape, with_resid):
     st = st.cpu().double().sum(-1)
     assert relerr(st[0], dz.sum((0, 2, 3))) < 1e-3
     assert relerr(st[1], (dz * xhat).sum((0, 2, 3))) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 14, 14, 576, 96), (1, 20, 20, 72, 24), (4, 28, 28, 240, 40)])
+@pytest.mark.parametrize("nparts", [1, 8, 40])
+def test_pw_dgrad_plain_dy(shape, nparts):
+    """materialised dy (no dy-on-load operand) through the DMA-pipelined 1x1 input gradient, several grid sizes"""
+    N, H, W, Ci, Co = shape
+    dy = _x((N, Co, H, W), 3)
+    w = bf16r(O.det_param("t.conv.weight", (Co, Ci, 1, 1), 2))
+    ref = F.conv_transpose2d(dy, w)
+    g = L.MnasGradIn()
+    dyd = nhwc(dy)
+    g.g = dyd.data_ptr()
+    out, _ = conv_gemm(1, N, H, W, Co, H, W, Ci, 1, 1, 0, pack(w, L.PACK_DGRAD), None, grad=g, nparts=nparts)
+    assert relerr(from_nhwc(out), ref) < TOL_BF16
 
 
 @pytest.mark.parametrize("shape", DENSE)
