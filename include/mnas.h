@@ -317,6 +317,44 @@ int mnas_pool_bwd(const float* gpool, int N, int HW, int C, void* g_bf16, void* 
 /* bf16 NHWC <- fp32 NCHW  (incoming gradient of the features output) */
 int mnas_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int HW, void* stream);
 
+/* ---- classifier head + loss (csrc/mnas_head.hip) -------------------------------------------------------
+ * Replaces, for FineTuneModelPool.classifier (classifiers.py:56-89: nn.Sequential of Dropout / Linear / ReLU) and
+ * nn.CrossEntropyLoss (train.py:277), ATen's dropout / addmm / relu / log_softmax / nll_loss forward and backward.
+ * One MnasHeadLinear = the Dropout in front of a Linear + the Linear + the optional ReLU behind it, all fp32:
+ *   fwd    y[N][O]  = act( (x * keep/(1-p)) W^T + b )                 act = relu if `relu`
+ *   bwd_w  dw[O][I] (+)= dz^T (x * keep/(1-p)),  db[O] (+)= sum_n dz   (+= if `accumulate`)
+ *   bwd_x  dx[N][I] = (dz W) * keep/(1-p) * [relu_mask > 0]            relu_mask = x when the layer in FRONT ends in a
+ *                                                                      ReLU (then dx is that layer's dz), else NULL
+ * keep(seed, n*I+i) is a counter-based hash (splitmix64), never stored: the three calls of one layer and step take the same
+ * (drop_p, seed); drop_p == 0 (or eval mode) -> no dropout.  mnas_head_dropout_mask writes the keep bytes of a layer
+ * (tests).  Unused pointers may be NULL. */
+typedef struct MnasHeadLinear {
+    int32_t N, I, O;
+    int32_t relu;            /* fwd: ReLU after the Linear */
+    int32_t accumulate;      /* bwd_w */
+    float   drop_p;          /* dropout probability on the layer's input, 0 <= p < 1 */
+    uint64_t seed;
+    const void* x;           /* [N][I] layer input (before dropout) */
+    const void* w;           /* [O][I] */
+    const void* b;           /* [O] or NULL */
+    void*       y;           /* [N][O] */
+    const void* dz;          /* [N][O] gradient of the Linear's output (after the ReLU mask) */
+    void*       dw;          /* [O][I] */
+    void*       db;          /* [O] or NULL */
+    void*       dx;          /* [N][I] */
+    const void* relu_mask;   /* [N][I] or NULL */
+} MnasHeadLinear;
+int mnas_head_linear_fwd(const MnasHeadLinear* a, void* stream);
+int mnas_head_linear_bwd_w(const MnasHeadLinear* a, void* stream);
+int mnas_head_linear_bwd_x(const MnasHeadLinear* a, void* stream);
+int mnas_head_dropout_mask(void* out_u8, int64_t n, float p, uint64_t seed, void* stream);
+/* nn.CrossEntropyLoss(reduction='mean', ignore_index): logits fp32 [N][C], target int64 [N].
+ * loss_rows[N] (scratch), *loss = mean over the non-ignored rows, dlogits[N][C] = dloss/dlogits (NULL: forward only).
+ * A target outside [0, C) that is not ignore_index sets *bad_flag (int32, device) and poisons the loss with NaN (ATen
+ * asserts on the device). */
+int mnas_head_cross_entropy(const void* logits, const void* target, int N, int C, int64_t ignore_index,
+                            void* loss_rows, void* loss, void* dlogits, void* bad_flag, void* stream);
+
 /* ---- weight packing (fp32 reference layout [Co][Ci/g][kh][kw] -> kernel layouts) -------------------- */
 #define MNAS_PACK_FWD   0   /* bf16 [Co_pad16][Kpad32], k = tap*Ci+ci            (mnas_conv_gemm mode 0) */
 #define MNAS_PACK_DGRAD 1   /* bf16 [Ci_pad16][Kpad32], k = tap*Co+co            (mnas_conv_gemm mode 1) */

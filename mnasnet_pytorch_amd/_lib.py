@@ -105,7 +105,20 @@ OP_BWD_POST, OP_TCONV_DGRAD = 25, 26
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 
 # every symbol include/mnas.h declares: (name, restype, argtypes)
+class MnasHeadLinear(C.Structure):
+    _fields_ = [("N", C.c_int32), ("I", C.c_int32), ("O", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32),
+                ("drop_p", c_float), ("seed", C.c_uint64), ("x", c_void_p), ("w", c_void_p), ("b", c_void_p),
+                ("y", c_void_p), ("dz", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("dx", c_void_p),
+                ("relu_mask", c_void_p)]
+
+
 SYMBOLS = {
+    "mnas_head_linear_fwd": (c_int, [C.POINTER(MnasHeadLinear), c_void_p]),
+    "mnas_head_linear_bwd_w": (c_int, [C.POINTER(MnasHeadLinear), c_void_p]),
+    "mnas_head_linear_bwd_x": (c_int, [C.POINTER(MnasHeadLinear), c_void_p]),
+    "mnas_head_dropout_mask": (c_int, [c_void_p, c_int64, c_float, C.c_uint64, c_void_p]),
+    "mnas_head_cross_entropy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),
     "mnas_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),

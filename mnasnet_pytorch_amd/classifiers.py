@@ -2,11 +2,14 @@
 ``load_model`` (classifiers.py:7-17) and ``FineTuneModelPool`` (classifiers.py:19-111).
 
 The feature extractor is the HIP engine (``Mnasnet(cut_channels_first=False).features``, exactly what
-train.py:194-207 builds); pooling + the small MLP head stay PyTorch modules (0.3-0.7 M
-parameters, negligible time; 8(f) rank 2 is the "next" row that fuses them).  The resnet branches of the
-reference need torchvision and are outside the hot path: they raise."""
+train.py:194-207 builds); the global average pool is fused into the engine's last kernel and the MLP head runs on
+the HIP library too (head.py / csrc/mnas_head.hip).  ``pooling`` and ``classifier`` stay ordinary
+``nn.Module`` attributes (state_dict keys, ``.parameters()``, replacing them all work); a head that is not a
+Dropout/Linear/ReLU chain simply runs as the PyTorch module it is.  The resnet branches of the reference need
+torchvision and are outside the hot path: they raise."""
 import torch.nn as nn
 
+from .head import NativeHead
 from .mnasnet import Mnasnet
 
 
@@ -43,6 +46,9 @@ class FineTuneModelPool(nn.Module):
         else:
             raise ValueError("Finetuning not supported on this architecture yet")
         self.fuse_pool = True        # see forward()
+        self.native_head = True      # classifier on csrc/mnas_head.hip when it is a Dropout/Linear/ReLU chain
+        self._head = None
+        self._head_key = None
         self.mean = (0.485, 0.456, 0.406)
         self.std = (0.229, 0.224, 0.225)
 
@@ -69,4 +75,17 @@ class FineTuneModelPool(nn.Module):
             f = self.features._engine().forward(x, pooled=True)
         else:
             f = self.pooling(self.features(x))
-        return self.classifier(f.view(f.size(0), -1))
+        f = f.view(f.size(0), -1)
+        head = self._native_head() if (self.native_head and f.is_cuda) else None
+        if head is not None:
+            return head.apply(f)
+        return self.classifier(f)
+
+    def _native_head(self):
+        """NativeHead over the CURRENT classifier modules (rebuilt if the Sequential or one of its children was replaced);
+        None if the classifier is not a Dropout/Linear/ReLU chain."""
+        c = self.classifier
+        key = (id(c),) + tuple(id(m) for m in c.children()) + tuple((m.p if isinstance(m, nn.Dropout) else None) for m in c.children())
+        if key != self._head_key:
+            self._head, self._head_key = NativeHead.build(c), key
+        return self._head

@@ -145,6 +145,8 @@ class Trainer:
                  criterion: Optional[nn.Module] = None, distributed: bool = False, process_group=None,
                  early_bucket_stage: int = 5):
         self.model = model
+        self.native_step = True          # see _native_head()
+        self.last_logits = None
         self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss()   # train.py:277
         self.lib = L.load()
         dev = next(model.parameters()).device
@@ -228,6 +230,22 @@ class Trainer:
     def load_state_dict(self, sd):
         self.optimizer.load_state_dict(sd["optimizer"])
 
+    def _native_head(self):
+        """The model's NativeHead when the whole step can bypass autograd: FineTuneModelPool-like model in training mode
+        (fused pool, Dropout/Linear/ReLU classifier) and a plain mean-reduced nn.CrossEntropyLoss (train.py:277)."""
+        m, c = self.model, self.criterion
+        if not self.native_step or type(c) is not nn.CrossEntropyLoss:
+            return None
+        if c.weight is not None or c.reduction != "mean" or getattr(c, "label_smoothing", 0.0) != 0.0:
+            return None
+        if not (hasattr(m, "_native_head") and getattr(m, "native_head", False) and getattr(m, "fuse_pool", False)):
+            return None
+        if not (m.training and self.engine.root.training and m._pool_is_global_average()):
+            return None
+        if self.engine.root is not m.features or any(not p.requires_grad for p in self.head_params):
+            return None
+        return m._native_head()
+
     # engine callback: backward of features.<stage> has been enqueued
     def _on_stage_done(self, stage: int):
         if self.buckets is not None and not self._launched0 and self._early_stage is not None and stage <= self._early_stage:
@@ -247,9 +265,23 @@ class Trainer:
         """One iteration of train.py:427-440.  Returns the loss tensor (no host sync)."""
         self.optimizer.zero_grad()                           # train.py:438
         self._launched0 = False
-        out = self.model(x.float())
-        loss = self.criterion(out, target)
-        loss.backward()
+        head = self._native_head()
+        if head is not None:
+            # features -> pool -> head -> cross-entropy -> head backward -> features backward as plain launch lists: no
+            # autograd graph, no ATen kernels (csrc/mnas_head.hip); same arithmetic as the module path below
+            eng = self.engine
+            x = x.float().contiguous()
+            eng._check_modes()
+            prog = eng.program(x.shape[0], x.shape[2], x.shape[3], True, False, True)
+            f = prog.run_forward(x)
+            self.last_logits, loss, df = head.loss_and_grad(f.view(f.size(0), -1), target, self.criterion.ignore_index)
+            accumulate = eng.prepare_grads()
+            prog.run_backward(df, eng.on_stage_done)
+            eng.finish_grads(accumulate)
+        else:
+            out = self.model(x.float())
+            loss = self.criterion(out, target)
+            loss.backward()
         if self.buckets is not None:
             if not self._launched0:
                 self.buckets.launch(0)

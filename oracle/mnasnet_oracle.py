@@ -298,6 +298,37 @@ def head_forward(f, hst, config: str, train: bool, dropout: bool = True):
     return h
 
 
+def head_dropout_keep(seed: int, n: int, p: float) -> np.ndarray:
+    """keep mask (bool[n]) of an nn.Dropout(p) over n elements as the HIP head draws it (csrc/mnas_head.hip head_keep):
+    element i is kept iff the high 32 bits of splitmix64(seed + golden*(i+1)) are >= p*2^32, so P(keep) = 1-p exactly as
+    F.dropout's Bernoulli(1-p) (classifiers.py:57-88); kept elements are scaled by 1/(1-p)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    t = min(int(float(np.float32(p)) * 4294967296.0), 4294967295)
+    return (z >> np.uint64(32)) >= np.uint64(t)
+
+
+def head_forward_masked(h, hst, config: str, keeps: Optional[list]):
+    """head_forward on already pooled features h (N, 320) with EXPLICIT dropout keep masks: keeps[j] (bool tensor shaped
+    like the j-th Dropout's input, or None = no dropout) -- F.dropout semantics x * keep / (1-p)."""
+    j = 0
+    for i, layer in enumerate(HEAD_CONFIGS[config]):
+        if layer[0] == "drop":
+            k = keeps[j] if keeps is not None else None
+            j += 1
+            if k is not None:
+                h = h * k.to(h.dtype) * (1.0 / (1.0 - layer[1]))
+        elif layer[0] == "relu":
+            h = F.relu(h)
+        else:
+            h = F.linear(h, hst["classifier.%d.weight" % i], hst["classifier.%d.bias" % i])
+    return h
+
+
 class OracleNet(torch.nn.Module):
     """nn.Module wrapper so torch.optim can drive the functional oracle (FineTuneModelPool over
     Mnasnet(ccf) -- what train.py:194-207 builds)."""
