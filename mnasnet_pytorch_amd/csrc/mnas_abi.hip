@@ -101,6 +101,11 @@ static int run_one(const MnasOp& o, void* stream) {
             a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.partial = (float*)p[6];
+            {   // diagnosis only (MNAS_ABL_NOWGRAD=1): skip the launch -- upper bound of what the side stream costs the main one
+                static int skip = -1;
+                if (skip < 0) { const char* e = getenv("MNAS_ABL_NOWGRAD"); skip = e ? atoi(e) : 0; }
+                if (skip && a.kh == 1) return MNAS_OK;
+            }
             return mnas_conv_wgrad(&a, stream);
         }
         case MNAS_OP_PACK_BATCH:

@@ -562,8 +562,15 @@ class Program:
         flush_post()
         built = {}
         for st in order:
-            if eng.use_side_stream:
-                seg_ops[st].join()          # a stage's gradients are complete when its launch list returns (DDP buckets)
+            # the main stream waits for the side stream's weight gradients at the end of backward, and at the end of the
+            # stages somebody consumes right away (Trainer: the stage that completes gradient bucket 0); joining after every
+            # stage cost 0.1 ms/step of main-stream waits with nobody looking at the gradients
+            if eng.join_stages is None:
+                need = st == order[-1] or eng.on_stage_done is not None
+            else:
+                need = st == order[-1] or st in eng.join_stages
+            if eng.use_side_stream and need:
+                seg_ops[st].join()
             built[st] = seg_ops[st].build()
         self.bwd_segments = [(st,) + built[st] for st in order]
         self._seg_index = {st: n for n, st in enumerate(order)}
@@ -706,6 +713,7 @@ class Engine:
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
         self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        self.join_stages = None          # stages after which the main stream joins the side stream (None: see Program)
         self.use_tconv = True            # stride-2 dense 3x3 input gradient as a transposed convolution (csrc/mnas_tconv.hip)
         self.merge_post = True           # BatchNorm-backward finalize + weight-gradient reductions of the main stream in one launch
         self.materialize_dy = True       # dense 3x3 convs: dy formed once (mnas_dy_materialize), gathered plain by dgrad / wgrad

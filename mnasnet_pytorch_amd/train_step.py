@@ -198,6 +198,9 @@ class Trainer:
             self.buckets = FlatBuckets(self.flat_g, [0, split, n], process_group)
             self._early_stage = min(stages_early) if stages_early else None
             self.engine.on_stage_done = self._on_stage_done
+            # bucket 0 is all-reduced as soon as stage `_early_stage` is done: its side-stream weight gradients must be in
+            self.engine.join_stages = {self._early_stage} if self._early_stage is not None else set()
+            self.engine.reset_programs()
         self._launched0 = False
         self.optimizer = FlatAdam(head + eng_params, self.flat_p, self.flat_g, lr=lr, betas=betas, eps=eps,
                                   weight_decay=weight_decay, grad_scale=1.0 / self.world)
