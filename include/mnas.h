@@ -260,6 +260,10 @@ typedef struct MnasStemWgrad {
     float* partial;          /* float[nparts][Co][27], fully overwritten */
 } MnasStemWgrad;
 int mnas_stem_wgrad(const MnasStemWgrad* a, void* stream);
+/* Preferred nparts (persistent workgroups) for the stem launches: which = 0 forward, 1 weight gradient; -1 = caller's choice
+ * (host-side, no launch).  Co == 32, W % 4 == 0 (and Wo % 8 == 0 for the weight gradient) run as band kernels
+ * (csrc/mnas_stem.hip: input rows staged once per band in LDS); other shapes use the im2col staging of the GEMM kernels. */
+int mnas_stem_parts(int which, int N, int H, int W, int Co);
 
 /* ---- BatchNorm2d bookkeeping (replaces ATen native_batch_norm / native_batch_norm_backward) ---------- */
 /* partial: float[2][C][nparts] (sum, sumsq over `count` elements per channel).

@@ -92,6 +92,8 @@ int mnas_nt_mask();
 int mnas_pwf_enabled();
 int mnas_pwf_parts(int M, int Ci, int Co);
 int mnas_pwf_forward(const MnasConvGemm* c, void* stream);
+int mnas_stem_fwd_band(const MnasStemFwd* c, void* stream);      // csrc/mnas_stem.hip; MNAS_EINVAL = not a band shape
+int mnas_stem_wgrad_band(const MnasStemWgrad* c, void* stream);
 int mnas_pwd_enabled();      // MNAS_PWD (default 1): DMA-pipelined 1x1 input gradient for the few-dy-channel convs
 int mnas_pwd_parts(int M, int Ci, int Co);
 int mnas_pwd_dgrad(const MnasConvGemm* c, void* stream);

@@ -618,6 +618,10 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
 // staging mode (K = 27 padded to 32, image values rounded to bf16 like every other activation).
 extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     if (!c || (c->Co & 7) || c->Co > 128 || c->nparts < 1) return MNAS_EINVAL;
+    {   // 32 couts, W % 4 == 0: band kernel (csrc/mnas_stem.hip); anything else: im2col staging below
+        const int rc = mnas_stem_fwd_band(c, stream);
+        if (rc != MNAS_EINVAL) return rc;
+    }
     IgemmArgs a;
     a.M = c->N * c->Ho * c->Wo;
     a.Hi = c->H; a.Wi = c->W; a.Ci = 27; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co;

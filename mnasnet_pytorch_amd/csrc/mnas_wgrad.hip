@@ -266,6 +266,10 @@ extern "C" int mnas_conv_wgrad(const MnasConvWgrad* c, void* stream) {
 // (finalize with mnas_wgrad_finalize(partial, nsplit, Co, 27, 1, grad, ...)).
 extern "C" int mnas_stem_wgrad(const MnasStemWgrad* c, void* stream) {
     if (!c || (c->Co & 7) || c->nparts < 1) return MNAS_EINVAL;
+    {   // 32 couts, W % 4 == 0, Wo % 8 == 0: band kernel (csrc/mnas_stem.hip)
+        const int rc = mnas_stem_wgrad_band(c, stream);
+        if (rc != MNAS_EINVAL) return rc;
+    }
     WgradArgs a;
     a.M = c->N * c->Ho * c->Wo;
     a.Hi = c->H; a.Wi = c->W; a.Ci = 27; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co;

@@ -228,6 +228,8 @@ class Program:
                 nparts = max(1, min(1024, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
             stats = eng.scratch_stats.data_ptr() if training else None
             if ci.kind == "stem":
+                sp = lib.mnas_stem_parts(0, N, Hi, Wi, ci.cout)
+                nparts = sp if sp > 0 else nparts
                 j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts], [],
                             [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
                 self.patch_x.append((j, 0))
@@ -428,6 +430,8 @@ class Program:
             rt = red_target if (red_target is not None and need_gin) else None
             if ci.kind == "stem":
                 nsp = max(1, min(512, _cdiv(M, 1024)))
+                sp = lib.mnas_stem_parts(1, N, Hi, Wi, Co)
+                nsp = sp if sp > 0 else nsp
                 jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()], WS)
                 self.patch_x_bwd = (ops, jx, 0)
                 ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)

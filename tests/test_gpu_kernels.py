@@ -306,11 +306,14 @@ def test_dw_bwd(shape, phase):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(2, 12, 12), (3, 33, 21), (1, 64, 64)])
+# (N, H, W[, Co]): W % 4 == 0 with 32 couts runs the band kernels (csrc/mnas_stem.hip; weight gradient also needs Wo % 8 == 0),
+# everything else the im2col staging of k_igemm / k_wgrad; partial last bands, odd heights, more bands than workgroups
+@pytest.mark.parametrize("shape", [(2, 12, 12), (3, 33, 21), (1, 64, 64), (3, 40, 48), (2, 37, 32), (11, 18, 16), (2, 224, 224),
+                                   (2, 24, 24, 16), (1, 34, 80)])
 def test_stem(shape):
     lib = L.load()
-    N, H, W = shape
-    Co = 32
+    N, H, W = shape[:3]
+    Co = shape[3] if len(shape) > 3 else 32
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     x = O.det_uniform((N, 3, H, W), 1)
     w = bf16r(O.det_param("t.conv.weight", (Co, 3, 3, 3), 2))
