@@ -4,7 +4,7 @@ import ctypes as C, sys, os, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from mnasnet_pytorch_amd import _lib as L
 lib = L.load()
-SHAPES = [(112, 48, 16), (56, 72, 24), (28, 240, 40), (28, 120, 40), (14, 480, 80), (14, 480, 96), (14, 576, 96)]   # H, conv Ci, conv Co
+SHAPES = [(7, 1152, 192), (112, 48, 16), (56, 72, 24), (28, 240, 40), (28, 120, 40), (14, 480, 80), (14, 480, 96), (14, 576, 96)]   # H, conv Ci, conv Co
 N = int(os.environ.get("KB_N", "256"))
 def run(H, Ci, Co):
     M = N * H * H
