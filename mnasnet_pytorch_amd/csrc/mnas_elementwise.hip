@@ -22,13 +22,18 @@ __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ partia
     const float* p1 = partial + (size_t)c * nparts;
     const float* p2 = partial + ((size_t)C + c) * nparts;
     float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-    int p = t;
-    for (; p + 3 * TPC < nparts; p += 4 * TPC) {
+    // every pass issues its 8 loads together (predicated, no dependent tail loop: these launches are a chain of
+    // memory round trips and little else)
+    for (int p = t; p < nparts; p += 4 * TPC) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a1[j] += p1[p + j * TPC]; a2[j] += p2[p + j * TPC]; }
+        for (int j = 0; j < 4; ++j) {
+            const int pj = p + j * TPC;
+            const bool ok = pj < nparts;
+            a1[j] += ok ? p1[pj] : 0.f;
+            a2[j] += ok ? p2[pj] : 0.f;
+        }
     }
     s1 = 0.0; s2 = 0.0;
-    for (; p < nparts; p += TPC) { s1 += (double)p1[p]; s2 += (double)p2[p]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s1 += (double)a1[j]; s2 += (double)a2[j]; }
     s1 = wave_sum_d(s1);
@@ -536,12 +541,17 @@ __device__ __forceinline__ void wgrad_finalize_body(float* __restrict__ partial,
     if (i < total) {
         const float* src = partial + i;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        int p = p0 + ty;
-        for (; p + 24 < p1; p += 32) {
+        // 16 rows per lane and pass, all loads of a pass in flight together (predicated: no dependent tail loop)
+        for (int p = p0 + ty; p < p1; p += 128) {
+            float v[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] += src[(size_t)(p + 8 * j) * pstride * total];
+            for (int j = 0; j < 16; ++j) {
+                const int pj = p + 8 * j;
+                v[j] = pj < p1 ? src[(size_t)pj * pstride * total] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += (v[j] + v[j + 4]) + (v[j + 8] + v[j + 12]);
         }
-        for (; p < p1; p += 8) s += src[(size_t)p * pstride * total];
         s += (a[0] + a[1]) + (a[2] + a[3]);
     }
     red[ty][tx] = s;

@@ -107,6 +107,33 @@ def timeline_main(path, nlast):
         print("%9.1f  %s  ->  %s" % (g / 1e3, (a or "")[:60], (b or "")[:60]))
 
 
+def seq_main(path):
+    """One full step, dispatch by dispatch: rocpd_stats.py --seq results.db  (k_adam to the next k_adam, the last complete one)"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    cols = [r[1] for r in cur.execute("pragma table_info(`%s`)" % kd)]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    q = "select d.start, d.end, s.display_name, %s from `%s` d join `%s` s on d.kernel_id=s.id order by d.start" % (
+        ("d." + qcol) if qcol else "0", kd, ks)
+    rows = cur.execute(q).fetchall()
+    idx = [i for i, r in enumerate(rows) if r[2].startswith("k_adam")]
+    if len(idx) < 3:
+        print("# fewer than 3 steps in the trace")
+        return
+    i0, i1 = idx[-3], idx[-2]
+    base = rows[i0][0]
+    for st, en, name, qq in rows[i0:i1 + 1]:
+        print("q%s %9.1f %8.1f  %s" % (qq, (st - base) / 1e3, (en - st) / 1e3, name[:90]))
+
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--seq":
+    seq_main(sys.argv[2])
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--timeline":
     timeline_main(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 2000)
     sys.exit(0)
