@@ -45,7 +45,12 @@ __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int NTO, int NTI, int PT>
+// OS (out-stage; the narrowing convs, where gin is the WIDE tensor): the input-gradient tile goes through LDS (the act(x) tile
+// is dead after the weight-gradient MFMAs) and leaves as 16-byte nontemporal stores of whole row segments -- the tile's
+// pixels are contiguous in memory, so these are full-line writes -- with the fused reduce done on that copy-out path (its
+// operand red_y loaded as 16-byte chunks before the MFMA phases).  The 8-byte-per-lane stores of the MFMA epilogue
+// (partial lines) sustained 2-2.4 TB/s of writes; the same change took the widening forward convs from 2.4 to 4.7 TB/s.
+template <int NTO, int NTI, int PT, bool OS>
 __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
@@ -129,6 +134,13 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 
     // BatchNorm-backward partial sums: per lane in registers across all tiles when there are few cin tiles (one shuffle tree
     // at the very end), per tile through LDS otherwise (15 cin tiles would need 120 registers)
+    // OS copy-out role: thread -> fixed 16-byte channel column c8 of the out-stage rows orow0 + k*OROWS
+    constexpr int NCH8 = CIP / 8, TCOLS = (256 / NCH8) * NCH8, OROWS = TCOLS / NCH8, MAXR = OS ? (BP + OROWS - 1) / OROWS : 1;
+    const int oc8 = tid % NCH8, orow0 = tid / NCH8;
+    const bool ocol_ok = tid < TCOLS && oc8 * 8 < cis;
+    float r1[8], r2[8], rcs[8], rct[8], rci[8], rcm[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; rcs[j] = 0.f; rct[j] = 0.f; rci[j] = 0.f; rcm[j] = 0.f; }
     constexpr bool REGSTAT = NTI <= 6;
     float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
 #pragma unroll
@@ -136,6 +148,16 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { rs1[i][r] = 0.f; rs2[i][r] = 0.f; }
 
+    if (OS && do_red) {
+        __syncthreads();                                     // lds_rc written above
+        if (ocol_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rcs[j] = lds_rc[oc8 * 8 + j]; rct[j] = lds_rc[CIP + oc8 * 8 + j];
+                rci[j] = lds_rc[2 * CIP + oc8 * 8 + j]; rcm[j] = lds_rc[3 * CIP + oc8 * 8 + j];
+            }
+        }
+    }
     const int ntiles = (a.M + BP - 1) / BP;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tile0 = t * BP;
@@ -194,6 +216,20 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         // the epilogue's global operands (raw output of the reduce target, residual gradient) for this lane's fragments:
         // issued now, they land under the MFMA phases
         uint2 ypre[PT][NTI], rpre[PT][NTI];
+        uint4 yreg[MAXR];
+        long long ooff[MAXR];
+        if constexpr (OS) {
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k) {
+                const int p = orow0 + k * OROWS, m = tile0 + p;
+                ooff[k] = -1;
+                yreg[k] = make_uint4(0, 0, 0, 0);
+                if (ocol_ok && p < BP && m < a.M) {
+                    ooff[k] = (long long)m * a.Ci + ci0 + oc8 * 8;
+                    if (do_red) yreg[k] = *(const uint4*)((const uint16_t*)a.red_y + ooff[k]);
+                }
+            }
+        }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int m = tile0 + (wave * PT + pt) * 16 + l15;
@@ -203,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 ypre[pt][nt] = make_uint2(0, 0); rpre[pt][nt] = make_uint2(0, 0);
                 if (m < a.M && ci < cis) {
                     const size_t o = (size_t)m * a.Ci + ci0 + ci;
-                    if (do_red) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + o);
+                    if (!OS && do_red) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + o);
                     if (a.resid) rpre[pt][nt] = *(const uint2*)((const uint16_t*)a.resid + o);
                 }
             }
@@ -246,6 +282,46 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                     acc_w[i][j] = OWN_O ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine, oth[j], acc_w[i][j], 0, 0, 0)
                                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(oth[j], mine, acc_w[i][j], 0, 0, 0);
             }
+        }
+        if constexpr (OS) {
+            // ---- out-stage: bf16 tile [pixel][ci] over the dead act(x) tile, then whole row segments leave as 16-byte stores
+            __syncthreads();                                 // every wave is done reading tile_a / tile_d fragments
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int p = (wave * PT + pt) * 16 + l15;
+#pragma unroll
+                for (int nt = 0; nt < NTI; ++nt) {
+                    float v[4] = {acc_g[pt][nt][0], acc_g[pt][nt][1], acc_g[pt][nt][2], acc_g[pt][nt][3]};
+                    if (a.resid) {
+                        const uint2 rv = rpre[pt][nt];
+                        v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16(v[0], v[1]);
+                    pk.y = pack_bf16(v[2], v[3]);
+                    *(uint2*)(tile_a + p * lda + nt * 16 + lg * 4) = pk;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k) {
+                if (ooff[k] < 0) continue;
+                const int p = orow0 + k * OROWS;
+                const uint4 pk = *(const uint4*)(tile_a + p * lda + oc8 * 8);
+                st_u4((uint16_t*)a.gin + ooff[k], pk, true);
+                if (do_red) {
+                    float gq[8], yq[8];
+                    unpack8(pk, gq);
+                    unpack8(yreg[k], yq);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float dz = (fmaf(yq[j], rcs[j], rct[j]) > 0.f) ? gq[j] : 0.f;
+                        r1[j] += dz;
+                        r2[j] = fmaf(dz, fmaf(yq[j], rci[j], rcm[j]), r2[j]);
+                    }
+                }
+            }
+            continue;
         }
         // ---- input-gradient epilogue: lane holds ci = nt*16 + lg*4 + {0..3} of pixel tile0 + (wave*PT+pt)*16 + l15
 #pragma unroll
@@ -322,7 +398,20 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             }
         }
     }
-    if (do_red) {
+    if (OS && do_red) {
+        // per-thread sums -> per-channel: the threads of one channel column added in thread order (deterministic)
+        float* fin = (float*)tile_d;                         // [256][16] (tile_d + tile_a hold >= 16 KB)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fin[tid * 16 + j] = r1[j]; fin[tid * 16 + 8 + j] = r2[j]; }
+        __syncthreads();
+        for (int i = tid; i < 2 * CIP; i += 256) {
+            const int r = i / CIP, c = i % CIP;
+            float v = 0.f;
+            for (int th = c >> 3; th < TCOLS; th += NCH8) v += fin[th * 16 + r * 8 + (c & 7)];
+            if (c < cis) a.red_partial[((size_t)r * a.Ci + ci0 + c) * gridDim.x + blockIdx.x] = v;   // [2][Ci][P]
+        }
+    } else if (do_red) {
         if (REGSTAT) {
 #pragma unroll
             for (int nt = 0; nt < (REGSTAT ? NTI : 1); ++nt)
@@ -347,13 +436,27 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     }
 }
 
+static int pw_bwd_outstage() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MNAS_PWB_OS"); on = e ? atoi(e) : 1; }
+    return on;
+}
 template <int NTO, int NTI, int PT>
 static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int nslices = 1) {
     constexpr int BP = 64 * PT, COP = NTO * 16, CIP = NTI * 16;
     const size_t lds = (size_t)(5 * COP + 14 * CIP) * sizeof(float) +
                        ((size_t)CIP * (a.Kd + 8) + (size_t)BP * (a.Kd + 8) + (size_t)BP * (CIP + 8)) * 2;
     if (lds > 160 * 1024) return MNAS_EINVAL;
-    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+    // narrowing conv with >= 48 result channels: gin is the wide tensor (32 -> 16 at 112x112 is 124 us without and 184 us with
+    // the out-stage: two more barriers per tile and nothing to win on 64-byte rows)
+    if constexpr (NTI > NTO && NTI >= 3) {
+        if (pw_bwd_outstage() && !a.resid) {
+            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+            MNAS_CHECK_LAUNCH();
+            return MNAS_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false>), dim3(nparts, nslices), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
