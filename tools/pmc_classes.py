@@ -13,7 +13,11 @@ def key(name):
     m = re.match(r"void k_pws<(\d)", name)
     if m:
         return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"      # bench.py classes follow the C-ABI entry point
-    if name.startswith("void k_pwf"): return "k_igemm<fwd>"
+    m = re.match(r"void k_pwf<(\d)", name)
+    if m:
+        return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"
+    if name.startswith("k_stem_fwd"): return "k_igemm<stem>"
+    if name.startswith("k_stem_wgrad"): return "k_wgrad<stem>"
     if name.startswith("k_dy_mat"): return "k_dy_mat"
     if name.startswith("k_pool"): return "k_pool"
     if name.startswith("void k_wgrad<true>"): return "k_wgrad<stem>"
