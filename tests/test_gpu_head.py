@@ -153,17 +153,6 @@ def test_head_module_matches_oracle(cfg, train):
     seq.zero_grad()
 
 
-def test_unsupported_heads_stay_pytorch():
-    import torch.nn as nn
-    assert parse_sequential(nn.Sequential(nn.Linear(4, 4), nn.BatchNorm1d(4))) is None
-    assert parse_sequential(nn.Sequential(nn.Linear(4, 4), nn.Dropout())) is None
-    assert parse_sequential(nn.Sequential(nn.ReLU(), nn.Linear(4, 4))) is None
-    assert parse_sequential(nn.Sequential(nn.Linear(4, 5), nn.ReLU(), nn.Linear(4, 3))) is None
-    assert parse_sequential(nn.Linear(4, 4)) is None
-    ok = parse_sequential(nn.Sequential(nn.Dropout(0.3), nn.Linear(4, 5), nn.ReLU(), nn.Linear(5, 3)))
-    assert [(l.p, l.relu) for l in ok] == [(0.3, True), (0.0, False)]
-
-
 def test_native_step_matches_module_path():
     """Trainer.step without autograd (pool -> head -> cross-entropy -> backward as launch lists) against the same model
     stepped through model(x) / criterion / loss.backward(): identical kernels for the features, so loss, logits and every
