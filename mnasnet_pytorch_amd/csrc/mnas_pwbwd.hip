@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 
 static int pw_bwd_outstage() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("MNAS_PWB_OS"); on = e ? atoi(e) : 1; }
+    if (on < 0) { const char* e = getenv("MNAS_PWB_OS"); on = e ? atoi(e) : 2; }      // 0 off, 1 narrowing convs, 2 + the 14x14 channel slices
     return on;
 }
 template <int NTO, int NTI, int PT>
@@ -449,8 +449,8 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
     if (lds > 160 * 1024) return MNAS_EINVAL;
     // narrowing conv with >= 48 result channels: gin is the wide tensor (32 -> 16 at 112x112 is 124 us without and 184 us with
     // the out-stage: two more barriers per tile and nothing to win on 64-byte rows)
-    if constexpr (NTI > NTO && NTI >= 3) {
-        if (pw_bwd_outstage() && !a.resid) {
+    if constexpr ((NTI > NTO && NTI >= 3) || (NTI == NTO && NTI >= 5)) {       // (the 14x14 channel slices: 5/5, 6/6)
+        if (pw_bwd_outstage() >= (NTI == NTO ? 2 : 1) && !a.resid) {
             hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true>), dim3(nparts, nslices), dim3(256), lds, stream, a);
             MNAS_CHECK_LAUNCH();
             return MNAS_OK;
