@@ -8,7 +8,7 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmnas_hip.so")
+LIB_PATH = os.environ.get("MNAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmnas_hip.so")      # override: A/B builds (tools/)
 
 c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 

@@ -26,6 +26,9 @@
 //     on another stream) once 2-row DMA groups give it full-width strips: 155 vs 118 + 92 us at 56x56x72, bs 256.
 // Roofline: HBM (AI 4.5 flop/B for 3x3, 12.5 for 5x5 forward; backward moves 4 tensors for 2x the FMAs).
 #include "mnas_common.h"
+#ifndef MNAS_DW_XFILL
+#define MNAS_DW_XFILL 1      // backward: out-of-image ring columns of x pre-filled, window read without per-column selects (as the forward)
+#endif
 
 #define DW_G 4          // rows per sweep step (default; the 5x5 weight-gradient sweep uses 2, see mnas_dw_bwd)
 #define DW_BW 4         // output columns per thread
@@ -684,6 +687,9 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             }
         };
         __syncthreads();                             // previous item's last group consumed
+#if MNAS_DW_XFILL
+        if (NEEDX) dw_fill_edges<2 * G>(a, plan, ring_x, wave, nwaves, lane, has_coef);   // out-of-image columns of x act to 0
+#endif
         dma_group(-PAD);
         load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
@@ -742,7 +748,11 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 f2 xa[WIN_W];
                 if (NEEDX && orow_in) {
                     const uint32_t* rowp = ring_x + (size_t)dw_slot<2 * G>(oy) * a.rc * 4 + coloff;
+#if MNAS_DW_XFILL
+                    if (WG) dw_read_act_nm<WIN_W>(rowp, ps, has_coef, cs, ct, xa);
+#else
                     if (WG) dw_read_act<WIN_W>(rowp, ps, has_coef, cs, ct, colmask, xa);
+#endif
                     if (RED && !REDG) {
 #pragma unroll
                         for (int ox = 0; ox < DW_BW; ++ox) xraw[ox] = rowp[(ox + PAD) * ps];
