@@ -741,7 +741,7 @@ class Engine:
         self.pw_split_max_pixels = 0
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
-        self.pw_bwd_parts_small = 64     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)
+        self.pw_bwd_parts_small = 85     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)
         self.side_stream = None
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_filter = None       # optional predicate (opcode, ints) -> bool narrowing the bracketed launches
