@@ -247,6 +247,8 @@ class Trainer:
             return None
         if self.engine.root is not m.features or any(not p.requires_grad for p in self.head_params):
             return None
+        if any(not p.requires_grad for p in self.engine.params):
+            return None            # frozen features (FineTuneModelPool.freeze()): the module path skips their backward
         return m._native_head()
 
     # engine callback: backward of features.<stage> has been enqueued
