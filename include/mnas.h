@@ -99,6 +99,10 @@ int mnas_conv_gemm_tile_pixels(int M, int Co, int K);
  * forward: DMA-pipelined kernel, csrc/mnas_pwf.hip), -1 = caller's choice in whole tiles (mnas_conv_gemm_tile_pixels).
  * taps = kh*kw. */
 int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps);
+/* Same question for the dense k x k convs, which depend on the image geometry: > 0 (= N) where mnas_conv_gemm runs the
+ * whole-image kernel (csrc/mnas_dimg.hip: 3x3, pad 1, output plane <= 256 pixels, N >= 32; mode 1: stride 1 and a
+ * materialised dy), -1 otherwise.  mode 1 arguments as in MnasConvGemm (Hi,Wi,Ci = dy dims, Ho,Wo,Co = result dims). */
+int mnas_conv_img_parts(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int k, int stride, int pad);
 
 /* ---- input gradient of the stride-2 dense 3x3 convs as a transposed convolution (csrc/mnas_tconv.hip): one GEMM per 2x2
  * output block over the four dy pixels it depends on; no per-element gather.  dy: bf16 (N,Ho,Wo,Co), MATERIALISED

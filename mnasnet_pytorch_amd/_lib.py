@@ -113,6 +113,7 @@ class MnasHeadLinear(C.Structure):
 
 
 SYMBOLS = {
+    "mnas_conv_img_parts": (c_int, [c_int] * 11),
     "mnas_stem_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mnas_head_linear_fwd": (c_int, [C.POINTER(MnasHeadLinear), c_void_p]),
     "mnas_head_linear_bwd_w": (c_int, [C.POINTER(MnasHeadLinear), c_void_p]),

@@ -601,6 +601,11 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (c->mode == 1 && a.is_pw && !c->resid && !c->bias && mnas_pwd_enabled() && mnas_pwd_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwd_dgrad(c, stream);
 
+    // dense 3x3 on the 14x14 / 7x7 maps: whole image per workgroup (csrc/mnas_dimg.hip); MODE 1 there takes a materialised dy
+    if (a.taps == 9 && !(c->mode == 0 && c->resid) && !(c->mode == 1 && (c->grad.y || c->resid)) &&
+        mnas_dimg_parts(c->mode, c->N, c->Hi, c->Wi, c->Ci, c->Ho, c->Wo, c->Co, c->kh, c->kw, c->stride, c->pad) > 0)
+        return mnas_dimg_run(c, stream);
+
     int best_nt, nblocks, pt;
     igemm_tiling(c->Co, a.Kpad, a.M, &best_nt, &nblocks, &pt);
     if (pt == 1 && a.Kpad >= 256 && (best_nt == 2 || best_nt == 3 || best_nt == 6)) a.kch = 128;

@@ -226,6 +226,9 @@ class Program:
             nparts = lib.mnas_conv_gemm_parts(0, M, ci.cin, ci.cout, ci.k * ci.k) if ci.kind in ("pw", "dense") else -1
             if nparts < 1:
                 nparts = max(1, min(1024, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
+            if ci.kind == "dense":       # small maps: one image per workgroup (csrc/mnas_dimg.hip)
+                ip = lib.mnas_conv_img_parts(0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.stride, ci.pad)
+                nparts = ip if ip > 0 else nparts
             stats = eng.scratch_stats.data_ptr() if training else None
             if ci.kind == "stem":
                 sp = lib.mnas_stem_parts(0, N, Hi, Wi, ci.cout)
@@ -497,6 +500,9 @@ class Program:
                              and Hi == 2 * Ho and Wi == 2 * Wo and lib.mnas_tconv_supported(Ho, Wo, Co, ci.cin))
                     if tconv:
                         nparts = lib.mnas_tconv_parts(N, Ho, Wo, Co, ci.cin)
+                    elif ci.kind == "dense" and gyd is not gy and resid is None:
+                        ip = lib.mnas_conv_img_parts(1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.stride, ci.pad)
+                        nparts = ip if ip > 0 else nparts
                     red = [None, None, None]
                     if rt is not None:
                         red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]

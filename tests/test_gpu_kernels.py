@@ -88,6 +88,9 @@ def test_pw_fwd(shape, virt):
 
 DENSE = [  # N,H,W,Ci,Co,stride
     (2, 12, 12, 16, 24, 2), (2, 7, 9, 80, 96, 1), (2, 9, 9, 24, 40, 2), (1, 7, 7, 192, 320, 1), (2, 14, 10, 96, 192, 2),
+    # N >= 32 with an output plane of <= 256 pixels: the whole-image kernel (csrc/mnas_dimg.hip); ragged planes, cout groups
+    (32, 14, 14, 80, 96, 1), (33, 14, 14, 96, 192, 2), (32, 7, 7, 192, 320, 1), (40, 9, 11, 24, 40, 2), (32, 16, 16, 16, 24, 1),
+    (35, 13, 15, 40, 80, 2),
 ]
 
 
@@ -167,6 +170,33 @@ def test_dense_dgrad(shape):
     gd, yd, bd = nhwc(g), nhwc(y), b.cuda()
     out, _ = conv_gemm(1, N, Ho, Wo, Co, H, W, Ci, 3, s, 1, pack(w, L.PACK_DGRAD), None, grad=grad_in(gd, yd, bd), nparts=7)
     assert relerr(from_nhwc(out), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("shape", [(32, 14, 14, 80, 96), (32, 7, 7, 192, 320), (36, 9, 11, 24, 40), (32, 16, 16, 16, 24), (2, 14, 14, 80, 96)])
+@pytest.mark.parametrize("nparts", [5, 32])
+def test_dense_dgrad_plain_dy_with_reduce(shape, nparts):
+    """stride-1 3x3 input gradient over a MATERIALISED dy (what the engine hands the dense convs), fused BatchNorm-backward
+    reduce: whole-image kernel for N >= 32, k_igemm otherwise -- same contract"""
+    N, H, W, Ci, Co = shape
+    dy = _x((N, Co, H, W), 3)
+    w = bf16r(O.det_param("t.conv.weight", (Co, Ci, 3, 3), 2))
+    ref = torch.nn.grad.conv2d_input((N, Ci, H, W), w, dy, stride=1, padding=1)
+    g = L.MnasGradIn()
+    dyd = nhwc(dy)
+    g.g = dyd.data_ptr()
+    y_in = _x((N, Ci, H, W), 21)
+    b_in = rand_bn_coefs(Ci, 22, O)
+    yid, bid = nhwc(y_in), b_in.cuda()
+    out, st = conv_gemm(1, N, H, W, Co, H, W, Ci, 3, 1, 1, pack(w, L.PACK_DGRAD), None, grad=g, nparts=nparts, stats=True,
+                        red_y=yid, red_bn=bid)
+    assert relerr(from_nhwc(out), ref) < TOL_BF16
+    gq = from_nhwc(out)
+    s_, t_, mu_, is_ = (b_in[i].view(1, -1, 1, 1) for i in (0, 1, 5, 6))
+    dz = (gq * ((s_ * y_in + t_) > 0)).double()
+    xhat = (y_in * is_ - mu_ * is_).double()
+    st = st.cpu().double().sum(-1)
+    assert relerr(st[0], dz.sum((0, 2, 3))) < 1e-3
+    assert relerr(st[1], (dz * xhat).sum((0, 2, 3))) < 1e-3
 
 
 def _wgrad(N, H, W, Ci, Ho, Wo, Co, k, s, pad, xact, dy, nsplit, accumulate=False, init=None):
