@@ -16,6 +16,9 @@ def key(name):
     m = re.match(r"void k_pwf<(\d)", name)
     if m:
         return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"
+    m = re.match(r"void k_dimg<(\d)", name)
+    if m:
+        return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"
     if name.startswith("k_stem_fwd"): return "k_igemm<stem>"
     if name.startswith("k_stem_wgrad"): return "k_wgrad<stem>"
     if name.startswith("k_dy_mat"): return "k_dy_mat"
