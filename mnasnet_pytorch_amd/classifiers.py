@@ -52,6 +52,13 @@ class FineTuneModelPool(nn.Module):
         self.mean = (0.485, 0.456, 0.406)
         self.std = (0.229, 0.224, 0.225)
 
+    # The NativeHead cache holds the ctypes library handle: it is process-local state, not model state.  Keep it out of
+    # pickles / deep copies (torch.save(model), copy.deepcopy(model) for EMA or best-model copies); it is rebuilt lazily.
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_head"], st["_head_key"] = None, None
+        return st
+
     def freeze(self):
         print("Features frozen")
         for p in self.features.parameters():
@@ -71,7 +78,9 @@ class FineTuneModelPool(nn.Module):
         # classifiers.py:107-111.  features -> AdaptiveAvgPool2d(1) -> flatten is ONE engine call: the pool is fused with the
         # last BatchNorm+ReLU (mnas_pool_act) and the N x 320 x H/32 x W/32 fp32 feature map is never materialised; backward
         # starts from the pooled gradient (mnas_pool_bwd).  Any other pooling module takes the two-step path.
-        if self.fuse_pool and hasattr(self.features, "_engine") and self._pool_is_global_average():
+        hooked = bool(self.features._forward_hooks or self.features._forward_pre_hooks or self.pooling._forward_hooks
+                      or self.pooling._forward_pre_hooks)       # hooks on features / pooling must fire: take the module path
+        if self.fuse_pool and not hooked and hasattr(self.features, "_engine") and self._pool_is_global_average():
             f = self.features._engine().forward(x, pooled=True)
         else:
             f = self.pooling(self.features(x))

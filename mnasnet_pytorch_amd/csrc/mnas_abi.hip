@@ -2,13 +2,11 @@
 // segment instead of ~450 ctypes calls per training step).
 #include "mnas_common.h"
 
-#include <cstdlib>
 #define MNAS_NT_DEFAULT MNAS_NT_PWF
 int mnas_nt_mask() {
     static int mask = -1;
     if (mask < 0) {
-        const char* e = getenv("MNAS_NT");
-        mask = e ? atoi(e) : MNAS_NT_DEFAULT;
+        mask = mnas_diag_env("MNAS_NT", MNAS_NT_DEFAULT);
     }
     return mask;
 }
@@ -16,16 +14,14 @@ int mnas_nt_mask() {
 int mnas_pwf_enabled() {
     static int on = -1;
     if (on < 0) {
-        const char* e = getenv("MNAS_PWF");
-        on = e ? atoi(e) : 1;
+        on = mnas_diag_env("MNAS_PWF", 1);
     }
     return on;
 }
 int mnas_pwd_enabled() {
     static int on = -1;
     if (on < 0) {
-        const char* e = getenv("MNAS_PWD");
-        on = (e ? atoi(e) : 1) && mnas_pwf_enabled();
+        on = mnas_diag_env("MNAS_PWD", 1) && mnas_pwf_enabled();
     }
     return on;
 }
@@ -33,8 +29,7 @@ int mnas_pwd_enabled() {
 int mnas_pws_enabled() {
     static int on = -1;
     if (on < 0) {
-        const char* e = getenv("MNAS_PWS");
-        on = e ? atoi(e) : 1;
+        on = mnas_diag_env("MNAS_PWS", 1);
     }
     return on;
 }
@@ -101,11 +96,13 @@ static int run_one(const MnasOp& o, void* stream) {
             a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.partial = (float*)p[6];
-            {   // diagnosis only (MNAS_ABL_NOWGRAD=1): skip the launch -- upper bound of what the side stream costs the main one
+#ifdef MNAS_DIAG
+            {   // diagnosis build only (MNAS_ABL_NOWGRAD=1|2|3): skip the launch -- upper bound of what the side stream costs the main one
                 static int skip = -1;
-                if (skip < 0) { const char* e = getenv("MNAS_ABL_NOWGRAD"); skip = e ? atoi(e) : 0; }
+                if (skip < 0) skip = mnas_diag_env("MNAS_ABL_NOWGRAD", 0);
                 if ((skip == 1 && a.kh == 1) || (skip == 2 && a.kh == 3) || skip == 3) return MNAS_OK;      // 1: 1x1, 2: 3x3, 3: all
             }
+#endif
             return mnas_conv_wgrad(&a, stream);
         }
         case MNAS_OP_PACK_BATCH:

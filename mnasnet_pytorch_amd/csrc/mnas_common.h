@@ -8,6 +8,16 @@
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16 = 4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 C/D fragment
 
+// Diagnosis switches (A/B runs of kernel variants, ablations that skip work) exist only in a -DMNAS_DIAG build
+// (tools/build_alt.sh -> libmnas_hip_alt.so).  The shipped library reads NO environment variable and has no mutable
+// global state beyond these compile-time constants (include/mnas.h contract).
+#ifdef MNAS_DIAG
+#include <cstdlib>
+static inline int mnas_diag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+#define mnas_diag_env(name, dflt) (dflt)
+#endif
+
 #define MNAS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }

@@ -284,7 +284,7 @@ int mnas_dimg_parts(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int
 
 int mnas_dimg_enabled() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("MNAS_DIMG"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = mnas_diag_env("MNAS_DIMG", 1);
     return on;
 }
 static bool dimg_plan(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad,
@@ -300,7 +300,7 @@ static bool dimg_plan(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, i
     // 7x7 planes: two images per pass (98 pixels, 2 tiles per wave): every weight chunk is used twice -- the weights are
     // re-read per pass from L2, 283 MB per launch for 192->320 with one image, which is what bounded it
     static int wgs = -1, nimax = -1;
-    if (wgs < 0) { const char* e = getenv("MNAS_DIMG_WGS"); wgs = e ? atoi(e) : 256; const char* f = getenv("MNAS_DIMG_NI"); nimax = f ? atoi(f) : 2; }
+    if (wgs < 0) { wgs = mnas_diag_env("MNAS_DIMG_WGS", 256); nimax = mnas_diag_env("MNAS_DIMG_NI", 2); }
     const int Kpad = (9 * Ci + 31) / 32 * 32;
     for (p->ni = (npix <= 64 ? nimax : 1); p->ni >= 1; --p->ni) {
         p->pxw = p->ni * npix > 128 ? 4 : (p->ni * npix > 64 ? 2 : 1);

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 
 static int pw_bwd_outstage() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("MNAS_PWB_OS"); on = e ? atoi(e) : 2; }      // 0 off, 1 narrowing convs, 2 + the 14x14 channel slices
+    if (on < 0) on = mnas_diag_env("MNAS_PWB_OS", 2);      // 0 off, 1 narrowing convs, 2 + the 14x14 channel slices
     return on;
 }
 template <int NTO, int NTI, int PT>

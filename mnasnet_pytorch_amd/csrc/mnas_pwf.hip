@@ -22,6 +22,11 @@
 // (the activation tile of an expand conv is re-read per block -- from L2 / the Infinity Cache: it is the small tensor).
 // Roofline: HBM (AI 11-165 flop/B, left of the 312 flop/B bf16 ridge).
 #include "mnas_common.h"
+#ifdef MNAS_DIAG
+#define PWF_ABL(a_, bit_) ((a_).abl & (bit_))
+#else
+#define PWF_ABL(a_, bit_) false
+#endif
 #include <cstdlib>
 
 typedef __attribute__((address_space(3))) void* pwf_lds_ptr;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
         uint4* dsty = lds_a + 2 * BP * pitch;
         const uint16_t* src = (const uint16_t*)(MODE == 1 ? a.grad.g : a.act.data);
         const uint16_t* srcy = (const uint16_t*)a.grad.y;
-        if (a.abl & 8) return;
+        if (PWF_ABL(a, 8)) return;
 #pragma unroll
         for (int i = 0; i < MAXA; ++i) {
             if (i >= na) break;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
     };
     // relu(scale*x+shift) in place on the slots THIS thread's DMA wrote (after its own vmcnt wait)
     auto transform_a = [&](int slot, int tile0, int k0) {
-        if (!has_coef || (a.abl & 2)) return;
+        if (!has_coef || PWF_ABL(a, 2)) return;
         uint4* t = lds_a + slot * BP * pitch;
 #pragma unroll
         for (int i = 0; i < MAXA; ++i) {
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
             const int q = 256 * i + tid;
             const int p = q / (NB / 8), c8 = q - p * (NB / 8);
             const int m = tile0 + p, co = n0 + c8 * 8;
-            if (p < BP && m < a.M && co < a.Co && !(a.abl & 1))
+            if (p < BP && m < a.M && co < a.Co && !PWF_ABL(a, 1))
                 st_u4((uint16_t*)a.out + (size_t)m * a.Co + co, o[p * OPITCH + c8], a.nt_store);
         }
     };
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
             if (ooff[k] < 0) continue;
             const int p = orow0 + k * OROWS;
             const uint4 pk = o[p * OPITCH + oc8];
-            if (!(a.abl & 1)) st_u4((uint16_t*)a.out + ooff[k], pk, a.nt_store);
+            if (!PWF_ABL(a, 1)) st_u4((uint16_t*)a.out + ooff[k], pk, a.nt_store);
             if (do_red) {
                 float gq[8], yq[8];
                 unpack8(pk, gq);
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
             if (MODE == 1 && kc == 0) plan_out(tile0);
             const uint4* ta = lds_a + slot * BP * pitch;
             const uint4* tw = lds_w + (WRES ? kc : slot) * NB * pitch;
-            const int ksteps = (a.abl & 4) ? 0 : (min(a.kc, a.Kpad - k0) >> 5);
+            const int ksteps = PWF_ABL(a, 4) ? 0 : (min(a.kc, a.Kpad - k0) >> 5);
             for (int ks = 0; ks < ksteps; ++ks) {
                 bf16x8_t bfrag[PT];
 #pragma unroll
@@ -458,7 +463,7 @@ int mnas_pwd_parts(int M, int Ci, int Co) {
     // the channel blocks of one pixel tile then land on the same XCD (shared L2)
     const int ntiles = (M + 64 * p.pt - 1) / (64 * p.pt);
     int g = 256 * (int)(160 * 1024 / p.lds) / p.nblocks;
-    if (const char* e = getenv("MNAS_PWD_GRID")) g = atoi(e);
+    g = mnas_diag_env("MNAS_PWD_GRID", g);
     if (g > ntiles) g = ntiles;
     if (g > 8) g &= ~7;
     return g < 1 ? 1 : g;
@@ -483,7 +488,7 @@ int mnas_pwf_forward(const MnasConvGemm* c, void* stream) {
     a.kc = p.kc; a.nkc = p.nkc; a.nch = p.kc / 8;
     a.co_pad16 = (c->Co + 15) / 16 * 16;
     a.nt_store = (mnas_nt_mask() & MNAS_NT_PWF) ? 1 : 0;
-    { const char* e = getenv("MNAS_PWF_ABL"); a.abl = e ? atoi(e) : 0; }
+    a.abl = mnas_diag_env("MNAS_PWF_ABL", 0);
     a.act = c->act; a.w = (const uint16_t*)c->w; a.bias = c->bias; a.out = c->out; a.stats = c->stats;
     a.grad.g = nullptr; a.grad.y = nullptr; a.grad.coef = nullptr; a.red_y = nullptr; a.red_bn = nullptr;
     hipStream_t s = (hipStream_t)stream;
@@ -505,7 +510,7 @@ int mnas_pwd_dgrad(const MnasConvGemm* c, void* stream) {
     a.kc = p.kc; a.nkc = 1; a.nch = p.kc / 8;
     a.co_pad16 = (c->Co + 15) / 16 * 16;
     a.nt_store = (mnas_nt_mask() & MNAS_NT_PWF) ? 1 : 0;
-    { const char* e = getenv("MNAS_PWF_ABL"); a.abl = e ? atoi(e) : 0; }
+    a.abl = mnas_diag_env("MNAS_PWF_ABL", 0);
     a.act.data = nullptr; a.act.scale = nullptr; a.act.shift = nullptr;
     a.w = (const uint16_t*)c->w; a.bias = nullptr; a.out = c->out;
     a.grad = c->grad; a.red_y = c->red_y; a.red_bn = c->red_bn;

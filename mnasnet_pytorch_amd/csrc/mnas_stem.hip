@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(StemArgs a) {
 extern "C" int mnas_stem_parts(int which, int N, int H, int W, int Co);
 int mnas_stem_band_enabled() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("MNAS_STEM_BAND"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = mnas_diag_env("MNAS_STEM_BAND", 1);
     return on;
 }
 static bool stem_band_ok(int N, int H, int W, int Ho, int Wo, int Co, bool wgrad) {

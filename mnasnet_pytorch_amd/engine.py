@@ -31,6 +31,7 @@ from . import _lib as L
 # two tiles leave most of the 256 CUs idle; measured -23..-35 % per launch there, +17..+37 % on the 14x14 stage)
 _SMALL_M = 20000
 _STATS_PARTS = 2048          # persistent pixel-workgroups for conv kernels / rows of the stats scratch
+_STEM_WGRAD_PARTS_MAX = 768  # upper bound of mnas_stem_parts(1, ...) (csrc/mnas_stem.hip): sizes the partial-slab scratch
 
 
 def _cdiv(a, b):
@@ -268,12 +269,15 @@ class Program:
             bn_e, bn_d = bnbuf(C_), bnbuf(C_)
             if training:
                 nsplit = max(1, min(512, _cdiv(M, 2048)))
-                fwd.add(L.OP_GRAM, [e_ci.cin, nsplit], [float(M)], a_in.act_ptrs() + [eng.scratch_gram.data_ptr(), eng.scratch_gram_s.data_ptr()])
+                gsc = eng.gram_scratch(e_ci.cin, nsplit)
+                gd = torch.empty(e_ci.cin * e_ci.cin + e_ci.cin, dtype=torch.float64, device=dev)
+                self.keep.append(gd)
+                fwd.add(L.OP_GRAM, [e_ci.cin, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
                 fwd.add(L.OP_GRAM_BN, [nsplit, e_ci.cin, C_], [float(M), ebn.momentum, ebn.eps],
-                        [eng.scratch_gram.data_ptr(), eng.scratch_gram_s.data_ptr(), econv.weight.data_ptr(),
+                        [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
                          econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
                          ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
-                         eng.scratch_gram_d.data_ptr(), bn_e.data_ptr()])
+                         gd.data_ptr(), bn_e.data_ptr()])
             else:
                 fwd.add(L.OP_BN_FWD_FINALIZE, [1, C_, 0], [float(M), ebn.momentum, ebn.eps],
                         [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
@@ -434,7 +438,9 @@ class Program:
             if ci.kind == "stem":
                 nsp = max(1, min(512, _cdiv(M, 1024)))
                 sp = lib.mnas_stem_parts(1, N, Hi, Wi, Co)
-                nsp = sp if sp > 0 else nsp
+                nsp = min(sp if sp > 0 else nsp, _STEM_WGRAD_PARTS_MAX)
+                if nsp * Co * 27 > eng.scratch_wgrad.numel():
+                    raise RuntimeError("stem weight-gradient scratch too small (%d splits)" % nsp)
                 jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()], WS)
                 self.patch_x_bwd = (ops, jx, 0)
                 ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
@@ -793,7 +799,7 @@ class Engine:
                 wmax = max(wmax, 1024 * ci.k * ci.k * ci.cout)
             else:
                 ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, 27, 1, 1), dtype=torch.uint8, device=device)
-                wmax = max(wmax, 512 * ci.cout * 27)
+                wmax = max(wmax, _STEM_WGRAD_PARTS_MAX * ci.cout * 27)   # k_stem_wgrad writes partial[nparts][Co][27]
             smax = max(smax, ci.cout)
         self.scratch_stats = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)
         self.scratch_wgrad = torch.empty(wmax, dtype=torch.float32, device=device)
@@ -801,10 +807,7 @@ class Engine:
         self.scratch_wgrad3 = torch.empty(wmax, dtype=torch.float32, device=device)      # main-stream producers rotate over 2..4:
         self.scratch_wgrad4 = torch.empty(wmax, dtype=torch.float32, device=device)      # a table is reduced up to two launches later
         self.scratch_red = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)   # fused BN-bwd partials
-        cmax = max(ci.cin for ci in self.convs)
-        self.scratch_gram = torch.empty(512 * cmax * cmax, dtype=torch.float32, device=device)         # mnas_gram partials
-        self.scratch_gram_s = torch.empty(512 * cmax, dtype=torch.float32, device=device)
-        self.scratch_gram_d = torch.empty(cmax * cmax + cmax, dtype=torch.float64, device=device)
+        self._gram_scratch = None        # allocated on first use (fused expand paths only): see gram_scratch()
         if self._ext_grad is not None:
             self.flat_grad = self._ext_grad
         else:
@@ -893,6 +896,20 @@ class Engine:
                 out.append((tag, ms.value))
         return out
 
+    def gram_scratch(self, cin, nsplit):
+        """(partials float[nsplit][cin][cin], sums float[nsplit][cin]) for mnas_gram: allocated lazily, grown on demand, shared by
+        all blocks (a block's Gram is reduced by the finalize launch right behind it on the same stream)."""
+        need = (nsplit * cin * cin, nsplit * cin)
+        cur = self._gram_scratch
+        if cur is None or cur[0].numel() < need[0] or cur[1].numel() < need[1]:
+            if cur is not None and any(p.busy for lst in self.programs.values() for p in lst):
+                raise RuntimeError("gram scratch would be re-allocated while a program is in flight")
+            n0 = max(need[0], cur[0].numel() if cur else 0)
+            n1 = max(need[1], cur[1].numel() if cur else 0)
+            self._gram_scratch = (torch.empty(n0, dtype=torch.float32, device=self.device),
+                                  torch.empty(n1, dtype=torch.float32, device=self.device))
+        return self._gram_scratch
+
     def gptr(self, ci: _ConvInfo, j: int):
         return self.flat_grad.data_ptr() + 4 * ci.gslice[j][0]
 
@@ -942,15 +959,24 @@ class Engine:
                 p.grad.add_(v)          # a foreign .grad tensor: add into it, like AccumulateGrad
 
     # ---- entry point ------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, pooled: bool = False) -> torch.Tensor:
-        """pooled=True returns the global average of the features, [N, C] fp32 (AdaptiveAvgPool2d(1) + flatten fused in)."""
-        if not x.is_cuda:
+    def check_input(self, x: torch.Tensor):
+        """Everything a launch list assumes about its input pointer; shared by forward() and Trainer.step's autograd-free path
+        (a host or wrong-device pointer handed to the kernels is a GPU memory fault, not an exception)."""
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise RuntimeError("mnasnet_pytorch_amd runs on MI355X only: got a %s tensor; there is no CPU/eager "
-                               "fallback (use oracle/ in tests for a CPU reference)" % x.device)
+                               "fallback (use oracle/ in tests for a CPU reference)" % (x.device if isinstance(x, torch.Tensor) else type(x)))
         if x.dim() != 4:
             raise ValueError("expected NCHW input")
+        if x.shape[1] != (3 if self.starts_with_stem else self.in_channels_hint):
+            raise ValueError("expected %d input channels, got %d" % (3 if self.starts_with_stem else self.in_channels_hint, x.shape[1]))
+        if x.shape[0] < 1 or x.shape[2] < 1 or x.shape[3] < 1:
+            raise ValueError("empty input %s" % (tuple(x.shape),))
         if any(p.device != x.device for p in self.params):
             raise RuntimeError("module parameters and input are on different devices")
+
+    def forward(self, x: torch.Tensor, pooled: bool = False) -> torch.Tensor:
+        """pooled=True returns the global average of the features, [N, C] fp32 (AdaptiveAvgPool2d(1) + flatten fused in)."""
+        self.check_input(x)
         track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params))
         if track and x.requires_grad and self.starts_with_stem and self.root.training:
             # the stem's input gradient (fp32 NCHW image gradient) is not part of the training path (train.py:427:

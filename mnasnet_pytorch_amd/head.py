@@ -179,6 +179,8 @@ class NativeHead:
         N, Cn = logits.shape
         if target.dtype != torch.int64 or target.shape != (N,):
             raise ValueError("target must be int64 of shape (N,)")
+        if target.device != logits.device:
+            raise RuntimeError("target is on %s, logits on %s (the kernel takes raw device pointers)" % (target.device, logits.device))
         dev = logits.device
         key = (N, dev)
         if key not in self._scratch:
@@ -190,6 +192,15 @@ class NativeHead:
                                                  rows.data_ptr(), loss.data_ptr(), L.ptr(dl), bad.data_ptr(), L.cur_stream()),
                 "head_cross_entropy")
         return loss, dl
+
+    def check_targets(self):
+        """Host check of the device-side "target out of range" flag that mnas_head_cross_entropy raises (the loss is NaN from
+        that step on; ATen asserts on the device instead).  Synchronises: call it next to a ``loss.item()``, not per step.
+        Resets the flag."""
+        for (N, dev), (_, bad) in self._scratch.items():
+            if int(bad.item()) != 0:
+                bad.zero_()
+                raise ValueError("cross_entropy: a target index was outside [0, num_classes) and not ignore_index")
 
     # ---- entry points -----------------------------------------------------------------------------------------------
     def apply(self, x):

@@ -49,6 +49,50 @@ class FlatBuckets:
         self.handles = []
 
 
+class BucketSchedule:
+    """WHEN the two gradient buckets are all-reduced during backward (pure host logic; tests/test_ddp_gloo.py drives it
+    with a stub engine on CPU/gloo).
+
+    The flat gradient buffer is ``[head | engine stages, later stages first]``.  Bucket 0 = head + every stage >=
+    ``early_bucket_stage`` (>80 % of the bytes: the late stages hold the wide weights) and is complete as soon as the backward
+    of stage ``early_stage`` (= the smallest such stage present) has been enqueued -- the engine's stage-done callback fires
+    right there, so the all-reduce runs under the backward of the early, activation-heavy stages.  Bucket 1 = the rest, launched
+    at the end of backward.  ``join_stages`` = the stages after which the engine must join its weight-gradient side stream
+    (bucket 0's gradients have to be complete on the stream the collective is ordered after)."""
+
+    def __init__(self, flat_g: torch.Tensor, n_head: int, stage_ranges, early_bucket_stage: int, group=None):
+        n = flat_g.numel()
+        early = [s for s in stage_ranges if s >= early_bucket_stage]
+        split = n_head + (max(stage_ranges[s][1] for s in early) if early else 0)
+        self.buckets = FlatBuckets(flat_g, [0, split, n], group)
+        self.early_stage = min(early) if early else None
+        self.join_stages = {self.early_stage} if self.early_stage is not None else set()
+        self.launched0 = False
+        self.log = []                     # ("stage", s) / ("launch", bucket): the order things happened in (tests)
+
+    def begin_step(self):
+        self.launched0 = False
+        self.log = []
+
+    def on_stage_done(self, stage: int):
+        """engine callback: the backward of features.<stage> (and everything after it) has been enqueued"""
+        self.log.append(("stage", stage))
+        if not self.launched0 and self.early_stage is not None and stage <= self.early_stage:
+            self.buckets.launch(0)
+            self.launched0 = True
+            self.log.append(("launch", 0))
+
+    def finish(self):
+        """end of backward: whatever has not been launched yet, then wait for both"""
+        if not self.launched0:
+            self.buckets.launch(0)
+            self.launched0 = True
+            self.log.append(("launch", 0))
+        self.buckets.launch(1)
+        self.log.append(("launch", 1))
+        self.buckets.wait()
+
+
 class FlatAdam(torch.optim.Optimizer):
     """``torch.optim.Adam`` (train.py:219-221) over ONE flat fp32 buffer: a single fused launch (``mnas_adam_step``) instead
     of ~110 per-tensor updates.  It is a real ``torch.optim.Optimizer``:
@@ -186,22 +230,16 @@ class Trainer:
         # ---- data parallel
         self.distributed = distributed
         self.world = 1
-        self.buckets = None
+        self.schedule: Optional[BucketSchedule] = None
         if distributed:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
             dist.broadcast(self.flat_p, src=0, group=process_group)     # identical replicas (DP semantics)
-            # bucket 0 ends where stage `early_bucket_stage`'s gradients end
-            rng = self.engine.stage_ranges
-            stages_early = [s for s in rng if s >= early_bucket_stage]
-            split = n_head + (max(rng[s][1] for s in stages_early) if stages_early else 0)
-            self.buckets = FlatBuckets(self.flat_g, [0, split, n], process_group)
-            self._early_stage = min(stages_early) if stages_early else None
-            self.engine.on_stage_done = self._on_stage_done
-            # bucket 0 is all-reduced as soon as stage `_early_stage` is done: its side-stream weight gradients must be in
-            self.engine.join_stages = {self._early_stage} if self._early_stage is not None else set()
+            self.schedule = BucketSchedule(self.flat_g, n_head, self.engine.stage_ranges, early_bucket_stage, process_group)
+            self.engine.on_stage_done = self.schedule.on_stage_done
+            # bucket 0 is all-reduced as soon as its last stage is done: its side-stream weight gradients must be in
+            self.engine.join_stages = self.schedule.join_stages
             self.engine.reset_programs()
-        self._launched0 = False
         self.optimizer = FlatAdam(head + eng_params, self.flat_p, self.flat_g, lr=lr, betas=betas, eps=eps,
                                   weight_decay=weight_decay, grad_scale=1.0 / self.world)
 
@@ -251,11 +289,9 @@ class Trainer:
             return None            # frozen features (FineTuneModelPool.freeze()): the module path skips their backward
         return m._native_head()
 
-    # engine callback: backward of features.<stage> has been enqueued
-    def _on_stage_done(self, stage: int):
-        if self.buckets is not None and not self._launched0 and self._early_stage is not None and stage <= self._early_stage:
-            self.buckets.launch(0)
-            self._launched0 = True
+    @property
+    def buckets(self):
+        return self.schedule.buckets if self.schedule is not None else None
 
     def sync_buffers(self):
         """Rank-0 BatchNorm running statistics win (DataParallel semantics, train.py:202) -- call before
@@ -269,16 +305,23 @@ class Trainer:
     def step(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """One iteration of train.py:427-440.  Returns the loss tensor (no host sync)."""
         self.optimizer.zero_grad()                           # train.py:438
-        self._launched0 = False
+        if self.schedule is not None:
+            self.schedule.begin_step()
         head = self._native_head()
         if head is not None:
             # features -> pool -> head -> cross-entropy -> head backward -> features backward as plain launch lists: no
             # autograd graph, no ATen kernels (csrc/mnas_head.hip); same arithmetic as the module path below
             eng = self.engine
+            eng.check_input(x)                               # same checks as Engine.forward: the launch lists take raw pointers
+            if not isinstance(target, torch.Tensor) or target.device != x.device:
+                raise RuntimeError("target must be a tensor on the input's device (%s)" % (x.device,))
             x = x.float().contiguous()
+            eng.ensure_setup(x.device)
             eng._check_modes()
             prog = eng.program(x.shape[0], x.shape[2], x.shape[3], True, False, True)
             f = prog.run_forward(x)
+            head.calls = self.optimizer.step_count           # dropout masks follow the CHECKPOINTED step count: a resumed run does
+                                                             # not replay the masks of the first steps
             self.last_logits, loss, df = head.loss_and_grad(f.view(f.size(0), -1), target, self.criterion.ignore_index)
             accumulate = eng.prepare_grads()
             prog.run_backward(df, eng.on_stage_done)
@@ -287,10 +330,7 @@ class Trainer:
             out = self.model(x.float())
             loss = self.criterion(out, target)
             loss.backward()
-        if self.buckets is not None:
-            if not self._launched0:
-                self.buckets.launch(0)
-            self.buckets.launch(1)
-            self.buckets.wait()
+        if self.schedule is not None:
+            self.schedule.finish()
         self.optimizer.step()                                # train.py:440
         return loss.detach()

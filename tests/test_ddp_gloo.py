@@ -96,3 +96,96 @@ def test_bucket_bounds_validation():
         FlatBuckets(torch.zeros(10), [0, 11, 10])
     with pytest.raises(AssertionError):
         FlatBuckets(torch.zeros(10), [1, 5, 10])
+
+
+# ---- the ORDER in which Trainer launches its buckets, with a stub engine (no GPU): train_step.BucketSchedule -----------------
+def _stub_layout():
+    """flat gradient layout of a head (50 elements) + 8 engine stages, later stages first, as engine.stage_ranges gives it"""
+    sizes = {7: 400, 6: 300, 5: 120, 4: 60, 3: 30, 2: 20, 1: 10, 0: 10}
+    ranges, off = {}, 0
+    for st in sorted(sizes, reverse=True):
+        ranges[st] = [off, off + sizes[st]]
+        off += sizes[st]
+    return 50, ranges, off
+
+
+def _sched_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from mnasnet_pytorch_amd.train_step import BucketSchedule
+        n_head, ranges, n_eng = _stub_layout()
+        n = n_head + n_eng
+        flat = torch.zeros(n)
+        sched = BucketSchedule(flat, n_head, ranges, early_bucket_stage=5)
+        oks = []
+        for step in range(2):                   # two steps: begin_step() must re-arm the early launch
+            flat.zero_()
+            sched.begin_step()
+            launch_seen_at = {}
+            orig = sched.buckets.launch
+
+            def launch(i, _orig=orig):
+                # what the flat buffer looked like when bucket i was handed to the collective: stages written so far
+                launch_seen_at[i] = [st for st in ranges if float(flat[n_head + ranges[st][0]]) != 0.0]
+                _orig(i)
+            sched.buckets.launch = launch
+            # stub engine: the head's gradients exist before the features backward; then stages 7..0 in backward order, each
+            # writing ITS slice of the flat buffer right before its stage-done callback (as Program.run_backward does)
+            flat[:n_head] = 1.0 + rank
+            for st in sorted(ranges, reverse=True):
+                a, b = ranges[st]
+                flat[n_head + a:n_head + b] = (st + 1) * (1.0 + rank) + step
+                sched.on_stage_done(st)
+            sched.finish()
+            sched.buckets.launch = orig
+            # ordering: bucket 0 right after stage 5's callback, before stage 4 wrote anything; bucket 1 at the end
+            want_log = [("stage", 7), ("stage", 6), ("stage", 5), ("launch", 0)] + [("stage", s) for s in (4, 3, 2, 1, 0)] + [("launch", 1)]
+            oks.append(sched.log == want_log)
+            oks.append(sorted(launch_seen_at[0]) == [5, 6, 7] and sorted(launch_seen_at[1]) == list(range(8)))
+            # result: every element is the sum over ranks of what the ranks wrote
+            tot = sum(1.0 + r for r in range(world))
+            exp = torch.empty(n)
+            exp[:n_head] = tot
+            for st in ranges:
+                a, b = ranges[st]
+                exp[n_head + a:n_head + b] = (st + 1) * tot + step * world
+            oks.append(bool(torch.allclose(flat, exp)))
+        oks.append(sched.join_stages == {5} and sched.buckets.bounds == [0, n_head + ranges[5][1], n])
+        # a model without late stages (engine rooted at an early stage): everything goes at the end, nothing deadlocks
+        s2 = BucketSchedule(torch.ones(40), 0, {1: [0, 30], 0: [30, 40]}, early_bucket_stage=5)
+        s2.begin_step(); s2.on_stage_done(1); s2.on_stage_done(0); s2.finish()
+        oks.append(s2.log == [("stage", 1), ("stage", 0), ("launch", 0), ("launch", 1)] and s2.early_stage is None)
+        oks.append(bool(torch.allclose(s2.buckets.flat, torch.full((40,), float(world)))))
+        q.put((rank, oks))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_schedule_order_world2_gloo():
+    """Trainer's overlap logic without a GPU: bucket 0 (head + features.5..7) is all-reduced from the stage-done callback of
+    stage 5 -- after its gradients exist, before stage 4's backward is enqueued -- bucket 1 at the end; begin_step() re-arms."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sched_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, oks in res:
+        assert all(oks), (rank, oks)
+
+
+def test_bench_multi_gpu_spawn_is_a_child_process():
+    """bench.py --gpus N (plain python) must start torch.distributed.run as a CHILD before anything touches the GPU and never
+    exec: checked on the source (the GPU box refuses an exec from a process that initialised HIP)."""
+    src = open(os.path.join(os.path.dirname(__file__), "..", "bench.py")).read()
+    head = src[src.index("def main():"):src.index("torch.cuda.set_device")]
+    assert "subprocess.run(cmd)" in head and "torch.distributed.run" in head
+    assert "os.exec" not in src and "execv" not in src

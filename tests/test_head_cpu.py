@@ -62,3 +62,23 @@ def test_masked_head_equals_plain_head_without_dropout():
         # all-ones masks = F.dropout in training mode with nothing dropped, scaled by 1/(1-p)
         out = O.head_forward_masked(h, hst, cfg, ones)
         assert out.shape == ref.shape and torch.isfinite(out).all()
+
+
+def test_model_with_cached_native_head_pickles_and_deepcopies():
+    """FineTuneModelPool caches a NativeHead (which holds the ctypes library handle) after the first forward: the cache must
+    stay out of pickles and deep copies (torch.save(model), EMA / best-model copies)."""
+    import contextlib, copy, io, pickle
+    from mnasnet_pytorch_amd import FineTuneModelPool, load_model
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = FineTuneModelPool(load_model("mnasnet"), "mnasnet", 10, "512")
+    head = m._native_head()                 # loads libmnas_hip.so (no GPU call)
+    assert head is not None and m._head is head
+    m2 = copy.deepcopy(m)
+    assert m2._head is None and m2._head_key is None
+    assert m2.classifier[1].weight.data_ptr() != m.classifier[1].weight.data_ptr()
+    m3 = pickle.loads(pickle.dumps(m))
+    assert m3._head is None and list(m3.state_dict().keys()) == list(m.state_dict().keys())
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    assert m._head is head                  # the live model keeps its cache
+    assert m2._native_head() is not None    # and a copy rebuilds its own lazily

@@ -1,10 +1,23 @@
 #!/bin/bash
-# Build a second library with extra compiler defines for an in-one-call A/B:  bash tools/build_alt.sh mnas_dw.hip -DMNAS_DW_XFILL=0
+# Build the DIAGNOSIS library: every source with -DMNAS_DIAG (the MNAS_* environment switches documented in DESIGN.md exist only
+# in this build; the shipped libmnas_hip.so reads no environment), optionally one source with extra defines for an in-one-call A/B:
+#     bash tools/build_alt.sh                       # plain diagnosis build
+#     bash tools/build_alt.sh mnas_dw.hip -DMNAS_DW_XFILL=0
 # -> mnasnet_pytorch_amd/csrc/libmnas_hip_alt.so (git-ignored); run with MNAS_LIB_PATH=$PWD/mnasnet_pytorch_amd/csrc/libmnas_hip_alt.so
 set -e
 cd "$(dirname "$0")/../mnasnet_pytorch_amd/csrc"
-SRC=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -fno-slp-vectorize "$@" -c $SRC -o /tmp/alt_${SRC%.hip}.o
-OBJS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/alt_${SRC%.hip}.o -o libmnas_hip_alt.so
+OBJ=/tmp/mnas_diag_obj
+mkdir -p $OBJ
+SRC=${1:-}; [ $# -gt 0 ] && shift
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -fno-slp-vectorize -DMNAS_DIAG"
+for f in *.hip; do
+    o=$OBJ/${f%.hip}.o
+    if [ "$f" = "$SRC" ]; then
+        /opt/rocm/bin/hipcc $FLAGS "$@" -c $f -o $o &
+    elif [ ! -f $o ] || [ $f -nt $o ] || [ mnas_common.h -nt $o ]; then
+        /opt/rocm/bin/hipcc $FLAGS -c $f -o $o &
+    fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/*.o -o libmnas_hip_alt.so
 echo built libmnas_hip_alt.so
