@@ -211,6 +211,30 @@ typedef struct MnasDwExpFwd {
 int mnas_dw_exp_fwd(const MnasDwExpFwd* a, void* stream);
 int mnas_dw_exp_rows(int N, int H, int W, int C, int k, int Cin, int nparts);
 
+/* ---- fused inverted-residual block on the small feature maps (csrc/mnas_irb.hip, mnas_irb_bwd.hip): MBConv_block
+ * (mnasnet.py:105-137) of the 14x14 / 7x7 stages with the t-times EXPANDED tensor kept off HBM.  Supported shapes
+ * (mnas_irb_supported): W in {14, 7}, H <= W, C <= 192, C % 8 == 0, E % 32 == 0, k in {3, 5}; otherwise MNAS_EINVAL
+ * (use the per-layer entry points).
+ * Forward: y1 = W1 act(x) + b1 (matrix cores, never stored unless y1 != NULL) -> a1 = relu(bn1(y1)) -> y2 = depthwise(a1) +
+ * bias (raw, stored) + BatchNorm partial statistics of y2 (float[2][E][nparts]).  bn1 = bnbuf of the expand conv with rows 0,1
+ * (scale, shift) valid BEFORE the launch: mnas_gram + mnas_gram_bn_finalize.  nparts must be mnas_irb_fwd_parts(..., want). */
+typedef struct MnasIrbFwd {
+    int32_t N, H, W, C, E, k;
+    int32_t nparts, reserved;
+    MnasActIn x;             /* block input (N,H,W,C), act-on-load */
+    const void*  w1;         /* expand weights, MNAS_PACK_FWD [E_pad16][C_pad32] */
+    const float* b1;         /* expand bias [E] or NULL */
+    const float* bn1;        /* bnbuf float[8][E] of the expand conv */
+    const float* wdw;        /* depthwise weights fp32 [k*k][E] (MNAS_PACK_DW) */
+    const float* bdw;        /* depthwise bias [E] or NULL */
+    void*  y1;               /* bf16 (N,H,W,E) or NULL */
+    void*  y2;               /* bf16 (N,H,W,E) raw depthwise output */
+    float* stats;            /* float[2][E][nparts] or NULL */
+} MnasIrbFwd;
+int mnas_irb_fwd(const MnasIrbFwd* a, void* stream);
+int mnas_irb_supported(int N, int H, int W, int C, int E, int k);
+int mnas_irb_fwd_parts(int N, int H, int W, int C, int E, int k, int want);
+
 /* ---- BatchNorm statistics of a 1x1 conv from the second moments of its INPUT (csrc/mnas_gram.hip) ----
  * mnas_gram: gpart[s][C][C] = sum over the pixels of split s of a a^T, spart[s][C] = sum a, a = act(x) (M pixels, C channels).
  * mnas_gram_bn_finalize: for y = W a + b (W: fp32 [Co][C], used bf16-rounded like the conv kernels do): batch mean / variance
@@ -412,6 +436,7 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_DY_MAT 24
 #define MNAS_OP_BWD_POST 25
 #define MNAS_OP_TCONV_DGRAD 26
+#define MNAS_OP_IRB_FWD 27
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

@@ -74,6 +74,7 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  BWD_POST         i: bn_nparts,bn_C, w1{nsplit,Co,Ci,taps,dw,level}, w2{...}   d: count
 //                   p: bn_partial,bnbuf,dgamma,dbeta, w1.partial,w1.grad, w2.partial,w2.grad
 //  TCONV_DGRAD      i: N,Ho,Wo,Co,Ci,nparts                       p: dy,w,out,stats,red_y,red_bn
+//  IRB_FWD          i: N,H,W,C,E,k,nparts          p: x.data,x.scale,x.shift, w1,b1,bn1,wdw,bdw,y1,y2,stats
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -197,6 +198,14 @@ static int run_one(const MnasOp& o, void* stream) {
             a.N = i[0]; a.Ho = i[1]; a.Wo = i[2]; a.Co = i[3]; a.Ci = i[4]; a.nparts = i[5];
             a.dy = p[0]; a.w = p[1]; a.out = p[2]; a.stats = (float*)p[3]; a.red_y = p[4]; a.red_bn = (const float*)p[5];
             return mnas_tconv_dgrad(&a, stream);
+        }
+        case MNAS_OP_IRB_FWD: {
+            MnasIrbFwd a = {};
+            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.E = i[4]; a.k = i[5]; a.nparts = i[6];
+            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
+            a.w1 = p[3]; a.b1 = (const float*)p[4]; a.bn1 = (const float*)p[5]; a.wdw = (const float*)p[6];
+            a.bdw = (const float*)p[7]; a.y1 = p[8]; a.y2 = p[9]; a.stats = (float*)p[10];
+            return mnas_irb_fwd(&a, stream);
         }
         case MNAS_OP_DY_MAT: {
             MnasGradIn d = {p[0], p[1], (const float*)p[2]};
