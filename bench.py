@@ -76,7 +76,9 @@ def class_key(opc, ints, L):
              L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
              L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd", L.OP_GRAM: "k_gram", L.OP_DW_EXP_FWD: "k_dw_fwd_exp",
              L.OP_POOL_ACT: "k_pool", L.OP_POOL_BWD: "k_pool", L.OP_DY_MAT: "k_dy_mat",
-             L.OP_TCONV_DGRAD: "k_igemm<dgrad>"}
+             L.OP_TCONV_DGRAD: "k_igemm<dgrad>", L.OP_IRB_FWD: "k_irb_fwd"}
+    if opc == L.OP_IRB_BWD:         # i: N,H,W,C,E,k,nparts,which
+        return ("k_irb_bwd_proj", "k_irb_bwd_dw", "k_irb_bwd_exp")[ints[7]]
     if opc == L.OP_CONV_GEMM:
         return "k_igemm<dgrad>" if ints[0] == 1 else "k_igemm<fwd>"
     if opc == L.OP_DW_BWD:          # i: N,H,W,C,k,nparts,phase (1 = input gradient, 2 = weight gradient launch)
@@ -118,6 +120,20 @@ def launch_work(opc, ints, L):
         px = N_ * H_ * W_
         nbytes = 2 * (px * Ci + px * C_) + 2 * 2 * px * C_
         flops = 2.0 * px * C_ * Ci + 2.0 * px * C_ * k_ * k_
+    elif opc == L.OP_IRB_FWD:       # fused expand + depthwise forward of a block: both ConvBlocks' tensors once (SURVEY 8(d) accounting)
+        N_, H_, W_, C_, E_, k_ = ints[:6]
+        px = N_ * H_ * W_
+        nbytes = 2 * (px * C_ + px * E_) + 2 * 2 * px * E_
+        flops = 2.0 * px * E_ * C_ + 2.0 * px * E_ * k_ * k_
+    elif opc == L.OP_IRB_BWD:       # the three backward launches of a fused block: the unfused accounting of what each replaces
+        N_, H_, W_, C_, E_, k_ = ints[:6]
+        px = N_ * H_ * W_
+        if ints[7] == 0:            # project conv backward (k_pw_bwd accounting: g, y of C; x and gin of E), dgrad + wgrad flops
+            nbytes, flops = 2 * px * (2 * C_ + 2 * E_), 2 * 2.0 * px * C_ * E_
+        elif ints[7] == 1:          # depthwise backward (fused accounting: 4 tensors of E) + the recomputed 1x1 GEMMs (y1, da2, P)
+            nbytes, flops = 2 * 4 * px * E_, 4.0 * px * E_ * k_ * k_ + 3 * 2.0 * px * C_ * E_
+        else:                       # expand conv input gradient (reads g, y of E; writes C) -- y1 recomputed: 2 GEMMs
+            nbytes, flops = 2 * (2 * px * E_ + px * C_), 2 * 2.0 * px * C_ * E_
     elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT, L.OP_GRAM, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT):
         nbytes, flops = 0, 0.0      # pure overhead in SURVEY 8(d)'s accounting
     else:                           # stem fwd / wgrad: fp32 image + bf16 output
@@ -253,13 +269,18 @@ def main():
         eng.pw_bwd_parts_large, eng.pw_bwd_parts_mid, eng.pw_bwd_parts_small = (int(v) for v in os.environ["MNAS_PWB"].split(","))
     if os.environ.get("MNAS_NO_DYMAT"):      # diagnosis only: dense 3x3 backward forms dy on load (two reads + transform per gather)
         eng.materialize_dy = False
+    if os.environ.get("MNAS_IRB"):           # diagnosis only: fused-block mode on the 14x14 / 7x7 stages: full | fwd | off
+        eng.fuse_irb = {"full": "full", "fwd": "fwd", "off": False}[os.environ["MNAS_IRB"]]
+    if os.environ.get("MNAS_IRB_WGS"):       # diagnosis only: workgroups per fused-block launch
+        eng.irb_workgroups = int(os.environ["MNAS_IRB_WGS"])
     if os.environ.get("MNAS_FUSE"):          # diagnosis only: fused expand + depthwise forward kernels (measured slower)
         eng.fuse_expand = True
     if os.environ.get("MNAS_DW5_SPLIT"):     # diagnosis only: two-launch backward for the 5x5 depthwise layers
         eng.dw_fused_k = (3,)
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
-               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD}
+               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD,
+               L.OP_IRB_FWD, L.OP_IRB_BWD}
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size

@@ -235,6 +235,45 @@ int mnas_irb_fwd(const MnasIrbFwd* a, void* stream);
 int mnas_irb_supported(int N, int H, int W, int C, int E, int k);
 int mnas_irb_fwd_parts(int N, int H, int W, int C, int E, int k, int want);
 
+/* Backward of the same block (csrc/mnas_irb_bwd.hip), three launches separated by the BatchNorm-backward finalizes
+ * (mnas_bwd_post / mnas_bn_bwd_finalize) whose coefficients the next launch needs; all take the same descriptor and read the
+ * fields listed (unused ones may be NULL).  nparts = the forward's mnas_irb_fwd_parts value (image groups).
+ *   mnas_irb_bwd_proj : gout = (G, y3, bnbuf3 rows 0..4), y2, bn2 (rows 0,1,5,6), w3t -> dy3 (bf16 (N,H,W,C), the project conv's
+ *                       dy, materialised), w3partial float[nparts][C][E] (-> mnas_wgrad_finalize(.., nparts, C, E, 1, ..)),
+ *                       red2 float[2][E][nparts] (BatchNorm2-backward sums of the never-written g2 = dy3 . W3).
+ *   mnas_irb_bwd_dw   : x, dy3, y2, w1, w3t, b1, bn1 (rows 0,1,5,6), bn2 (rows 0..4, finalized), wdw -> g1 (bf16 (N,H,W,E): the
+ *                       MASKED gradient dz1 of the expand conv's activated output), dwpartial float[nparts][k*k][E]
+ *                       (-> mnas_dw_wgrad_finalize), ppartial float[nparts][E][C] (P = dz1^T act(x)), red1 float[2][E][nparts].
+ *   mnas_irb_bwd_exp  : x, g1, w1, b1, bn1 (rows 2..4, finalized), gout.g (the skip gradient G, or NULL) -> dx (bf16 (N,H,W,C)).
+ *   mnas_irb_w1_finalize: the expand conv's weight gradient from P, the forward's Gram sums (double[C*C + C]: G, Sx -- the
+ *                       scratch of mnas_gram_bn_finalize) and bn1 rows 2..4; w1 = fp32 reference-layout weights [E][C]. */
+typedef struct MnasIrbBwd {
+    int32_t N, H, W, C, E, k;
+    int32_t nparts, reserved;
+    MnasActIn  x;            /* block input */
+    MnasGradIn gout;         /* G, y3, bnbuf of the project conv */
+    const void*  y2;
+    const void*  w1;         /* MNAS_PACK_FWD  of the expand conv  [E_pad16][C_pad32] */
+    const void*  w3t;        /* MNAS_PACK_DGRAD of the project conv [E_pad16][C_pad32] */
+    const float* b1;
+    const float* bn1;
+    const float* bn2;
+    const float* wdw;
+    void*  dy3;
+    void*  g1;
+    void*  dx;
+    float* w3partial;
+    float* red2;
+    float* dwpartial;
+    float* ppartial;
+    float* red1;
+} MnasIrbBwd;
+int mnas_irb_bwd_proj(const MnasIrbBwd* a, void* stream);
+int mnas_irb_bwd_dw(const MnasIrbBwd* a, void* stream);
+int mnas_irb_bwd_exp(const MnasIrbBwd* a, void* stream);
+int mnas_irb_w1_finalize(const float* ppartial, int nparts, int E, int C, const double* gsum, const float* w1,
+                         const float* b1, const float* bn1, float* grad, int accumulate, void* stream);
+
 /* ---- BatchNorm statistics of a 1x1 conv from the second moments of its INPUT (csrc/mnas_gram.hip) ----
  * mnas_gram: gpart[s][C][C] = sum over the pixels of split s of a a^T, spart[s][C] = sum a, a = act(x) (M pixels, C channels).
  * mnas_gram_bn_finalize: for y = W a + b (W: fp32 [Co][C], used bf16-rounded like the conv kernels do): batch mean / variance
@@ -437,6 +476,8 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_BWD_POST 25
 #define MNAS_OP_TCONV_DGRAD 26
 #define MNAS_OP_IRB_FWD 27
+#define MNAS_OP_IRB_BWD 28     /* i[7] selects the launch: 0 proj, 1 dw, 2 exp */
+#define MNAS_OP_IRB_W1_FIN 29
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

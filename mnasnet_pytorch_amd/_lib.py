@@ -100,6 +100,14 @@ class MnasIrbFwd(C.Structure):
                 ("stats", c_void_p)]
 
 
+class MnasIrbBwd(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("E", C.c_int32), ("k", C.c_int32),
+                ("nparts", C.c_int32), ("reserved", C.c_int32), ("x", MnasActIn), ("gout", MnasGradIn), ("y2", c_void_p),
+                ("w1", c_void_p), ("w3t", c_void_p), ("b1", c_void_p), ("bn1", c_void_p), ("bn2", c_void_p), ("wdw", c_void_p),
+                ("dy3", c_void_p), ("g1", c_void_p), ("dx", c_void_p), ("w3partial", c_void_p), ("red2", c_void_p),
+                ("dwpartial", c_void_p), ("ppartial", c_void_p), ("red1", c_void_p)]
+
+
 class MnasOp(C.Structure):
     _fields_ = [("opcode", C.c_int32), ("i", C.c_int32 * 15), ("d", C.c_double * 4), ("p", c_void_p * 16)]
 
@@ -108,7 +116,7 @@ OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRA
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
 OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
 OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
-OP_BWD_POST, OP_TCONV_DGRAD, OP_IRB_FWD = 25, 26, 27
+OP_BWD_POST, OP_TCONV_DGRAD, OP_IRB_FWD, OP_IRB_BWD, OP_IRB_W1_FIN = 25, 26, 27, 28, 29
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 EINVAL = 10001      # MNAS_EINVAL
 
@@ -131,6 +139,10 @@ SYMBOLS = {
                                         c_void_p]),
     "mnas_irb_fwd": (c_int, [C.POINTER(MnasIrbFwd), c_void_p]),
     "mnas_irb_supported": (c_int, [c_int] * 6),
+    "mnas_irb_bwd_proj": (c_int, [C.POINTER(MnasIrbBwd), c_void_p]),
+    "mnas_irb_bwd_dw": (c_int, [C.POINTER(MnasIrbBwd), c_void_p]),
+    "mnas_irb_bwd_exp": (c_int, [C.POINTER(MnasIrbBwd), c_void_p]),
+    "mnas_irb_w1_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mnas_irb_fwd_parts": (c_int, [c_int] * 7),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),

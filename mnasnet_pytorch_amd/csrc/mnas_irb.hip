@@ -43,7 +43,7 @@ struct IrbFwdArgs {
 // LDS image: [NI][(H + 2p)][RW][32] bf16 with RW = W + 2p rounded up to an ODD number of pixels: a pixel is 16 dwords, so two
 // rows of a 32-lane read group fall into different bank halves (conflict-free ds_read_b32).
 template <int KS, int WW, int KST>
-__global__ __launch_bounds__(256) void k_irb_fwd(IrbFwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_irb_fwd(IrbFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = KS / 2;
     constexpr int RW = (WW + 2 * P) | 1;
@@ -115,23 +115,27 @@ __global__ __launch_bounds__(256) void k_irb_fwd(IrbFwdArgs a) {
         const int n0 = pass * a.NI;
         const int nimg = min(a.NI, a.N - n0);
         const uint16_t* xb = (const uint16_t*)a.x.data + (size_t)n0 * a.HW * a.C;
-        // ---- expand: D[e][pix] = W1[e][:] . act(x)[pix][:]
+        // ---- expand: D[e][pix] = W1[e][:] . act(x)[pix][:]  (all activation fragments of the pass are loaded up front)
+        uint4 xv[NPTW][KST];
+#pragma unroll
+        for (int i = 0; i < NPTW; ++i) {
+            const bool live = ppix[i] >= 0 && ppix[i] < nimg * a.HW;
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                xv[i][ks] = make_uint4(0, 0, 0, 0);
+                const int c = ks * 32 + lg * 8;
+                if (ks < ksteps && live && c < a.C) xv[i][ks] = *(const uint4*)(xb + (size_t)ppix[i] * a.C + c);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NPTW; ++i) {
             if (wave + 4 * i >= a.npt) break;                       // uniform
             const bool live = ppix[i] >= 0 && ppix[i] < nimg * a.HW;
             f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-            uint4 xv[KST];
-#pragma unroll
-            for (int ks = 0; ks < KST; ++ks) {
-                xv[ks] = make_uint4(0, 0, 0, 0);
-                const int c = ks * 32 + lg * 8;
-                if (ks < ksteps && live && c < a.C) xv[ks] = *(const uint4*)(xb + (size_t)ppix[i] * a.C + c);
-            }
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 if (ks >= ksteps) break;
-                uint4 u = xv[ks];
+                uint4 u = xv[i][ks];
                 if (hasx) {
                     const int c = ks * 32 + lg * 8;
                     float s[8], t[8];

@@ -59,7 +59,7 @@ struct IrbProjArgs {
 
 // workgroup = 256 threads = one 32-channel slice of E x a group of image passes
 template <int KST>
-__global__ __launch_bounds__(256) void k_irb_bwd_proj(IrbProjArgs a) {
+__global__ __launch_bounds__(256, 2) void k_irb_bwd_proj(IrbProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IrbGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -114,23 +114,34 @@ __global__ __launch_bounds__(256) void k_irb_bwd_proj(IrbProjArgs a) {
         const int n0 = pass * g.NI;
         const int npx = min(g.NI, g.N - n0) * g.HW;                  // valid pixels of this pass
         const size_t m0 = (size_t)n0 * g.HW;
-        // ---- stage dy3 (dy-on-load of G, y3) -- every chunk of the tile is written (zeros outside the image / channels)
-        for (int q0 = 0; q0 < KP * c8n; q0 += 256 * 4) {
-            uint4 gv[4], yv[4];
+        // ---- stage dy3 (dy-on-load of G, y3) and the raw y2 slice: every chunk of both tiles is written (zeros outside the
+        // image / channels); ALL global loads of the pass are issued before the first use (one memory round trip per pass)
+        {
+            constexpr int NCH = 12;                                 // chunks per thread and batch (one batch for C <= 96 at 14x14, C <= 192 at 7x7)
+            uint4 gv[NCH], yv[NCH], y2c[4];
+            const int nchunk = KP * c8n;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const int q = tid + 256 * j;
+                const int row = q >> 2, c8 = q & 3;
+                y2c[j] = make_uint4(0, 0, 0, 0);
+                if (q < KP * 4 && row < npx) y2c[j] = *(const uint4*)(a.y2 + (m0 + row) * g.E + e0 + c8 * 8);
+            }
+          for (int q0 = 0; q0 < nchunk; q0 += 256 * NCH) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
                 const int q = q0 + tid + 256 * j;
                 const int row = q / c8n, c8 = q - row * c8n;
                 gv[j] = make_uint4(0, 0, 0, 0); yv[j] = make_uint4(0, 0, 0, 0);
-                if (q < KP * c8n && row < npx && c8 * 8 < g.C) {
+                if (q < nchunk && row < npx && c8 * 8 < g.C) {
                     gv[j] = *(const uint4*)(a.gout + (m0 + row) * g.C + c8 * 8);
                     yv[j] = *(const uint4*)(a.y3 + (m0 + row) * g.C + c8 * 8);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NCH; ++j) {
                 const int q = q0 + tid + 256 * j;
-                if (q >= KP * c8n) continue;
+                if (q >= nchunk) continue;
                 const int row = q / c8n, c8 = q - row * c8n;
                 uint4 o = make_uint4(0, 0, 0, 0);
                 if (row < npx && c8 * 8 < g.C) {
@@ -146,13 +157,12 @@ __global__ __launch_bounds__(256) void k_irb_bwd_proj(IrbProjArgs a) {
                 }
                 *(uint4*)(t_dy3 + row * CP + c8 * 8) = o;
             }
-        }
-        // ---- stage the raw y2 slice
-        for (int q = tid; q < KP * 4; q += 256) {
-            const int row = q >> 2, c8 = q & 3;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < npx) v = *(const uint4*)(a.y2 + (m0 + row) * g.E + e0 + c8 * 8);
-            *(uint4*)(t_y2 + row * YP + c8 * 8) = v;
+          }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = tid + 256 * j;
+                if (q < KP * 4) *(uint4*)(t_y2 + (q >> 2) * YP + (q & 3) * 8) = y2c[j];
+            }
         }
         __syncthreads();
         // ---- da2 = dy3 . W3 for the slice, reduced on the spot: D[e][pix]
@@ -271,7 +281,7 @@ struct IrbDwArgs {
 };
 
 template <int KS, int WW, int KST>
-__global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
+__global__ __launch_bounds__(256, 2) void k_irb_bwd_dw(IrbDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IrbGeom& g = a.g;
     constexpr int P = KS / 2;
@@ -284,9 +294,12 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
     const int RH = g.H + 2 * P;
     const int CP = g.Kpad + 8, KP = g.npk * 32;
     const int img_dw = g.NI * RH * RW * 16;                          // dwords of one padded image set
-    const int xs_dw = (KP * CP) >> 1;
-    const int reg_dw = max(2 * img_dw, xs_dw);
-    uint32_t* a1p = (uint32_t*)smem;                                // [img_dw]   } region R, re-used as the x tile [KP][CP]
+    // region R: the two padded images, re-used after the depthwise sweep as the x tile [NI*HW rows][CP] of the P GEMM.  The
+    // GEMM's last 32-pixel step reads up to KP rows: the rows beyond the written ones hold other FINITE bf16 data of this
+    // workgroup (end of R, start of t_y1) and meet zero rows of dz1, i.e. contribute exactly 0.
+    const int xs_dw = (g.NI * g.HW * CP + 1) >> 1;
+    const int reg_dw = (max(2 * img_dw, xs_dw) + 3) & ~3;
+    uint32_t* a1p = (uint32_t*)smem;                                // [img_dw]   } region R
     uint32_t* dy2p = a1p + img_dw;                                  // [img_dw]   }
     uint16_t* xs = (uint16_t*)smem;
     uint16_t* t_y1 = (uint16_t*)(a1p + reg_dw);                     // [KP][YP]: y1 (bf16), then dz1 in place
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
     float* tab1 = tabx + 2 * g.Kpad;                                // [5][32]: b1, s1, t1, invstd1, -mean1*invstd1
     float* tab2 = tab1 + 5 * 32;                                    // [5][32]: s2, t2, c1, c2, c3
     float* tabw = tab2 + 5 * 32;                                    // [KS*KS][32] depthwise weights
-    float* lds_red = tabw + KS * KS * 32;                           // [16][KS][32]
+    float* lds_red = (float*)smem;                                  // [16][KS][32]: over region R, after the last pass
     const int c8n = g.Kpad >> 3;
     const bool hasx = a.x.scale != nullptr;
 
@@ -361,26 +374,31 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
         for (int i = tid; i < (2 * img_dw + 3) >> 2; i += 256) ((uint4*)a1p)[i] = make_uint4(0, 0, 0, 0);     // zero borders
         __syncthreads();
         // ---- y1 = W1 act(x) + b1 -> t_y1 (bf16) and a1 -> padded image;   da2 = dy3 W3 -> dy2 -> padded image
+        // all global loads of the pass (x, dy3 fragments and the y2 values of this lane's pixels) are issued up front
+        uint4 xv[4][KST], dv[4][KST];
+        uint2 y2v[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (wave + 4 * i >= g.npt) break;
             const bool live = ppix[i] >= 0 && ppix[i] < npx;
-            uint4 xv[KST], dv[KST];
-            uint2 y2v[2];
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
-                xv[ks] = make_uint4(0, 0, 0, 0); dv[ks] = make_uint4(0, 0, 0, 0);
+                xv[i][ks] = make_uint4(0, 0, 0, 0); dv[i][ks] = make_uint4(0, 0, 0, 0);
                 const int c = ks * 32 + lg * 8;
                 if (live && c < g.C) {
-                    xv[ks] = *(const uint4*)((const uint16_t*)a.x.data + (m0 + ppix[i]) * g.C + c);
-                    dv[ks] = *(const uint4*)(a.dy3 + (m0 + ppix[i]) * g.C + c);
+                    xv[i][ks] = *(const uint4*)((const uint16_t*)a.x.data + (m0 + ppix[i]) * g.C + c);
+                    dv[i][ks] = *(const uint4*)(a.dy3 + (m0 + ppix[i]) * g.C + c);
                 }
             }
 #pragma unroll
             for (int et = 0; et < 2; ++et) {
-                y2v[et] = make_uint2(0, 0);
-                if (live) y2v[et] = *(const uint2*)(a.y2 + (m0 + ppix[i]) * g.E + e0 + et * 16 + lg * 4);
+                y2v[i][et] = make_uint2(0, 0);
+                if (live) y2v[i][et] = *(const uint2*)(a.y2 + (m0 + ppix[i]) * g.E + e0 + et * 16 + lg * 4);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (wave + 4 * i >= g.npt) break;
+            const bool live = ppix[i] >= 0 && ppix[i] < npx;
             if (hasx) {
 #pragma unroll
                 for (int ks = 0; ks < KST; ++ks) {
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
                     float s[8], t[8];
                     *(float4*)&s[0] = *(const float4*)(tabx + c); *(float4*)&s[4] = *(const float4*)(tabx + c + 4);
                     *(float4*)&t[0] = *(const float4*)(tabx + g.Kpad + c); *(float4*)&t[4] = *(const float4*)(tabx + g.Kpad + c + 4);
-                    xv[ks] = live ? act8(xv[ks], s, t) : make_uint4(0, 0, 0, 0);
+                    xv[i][ks] = live ? act8(xv[i][ks], s, t) : make_uint4(0, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -400,8 +418,8 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
                     if (ks * 32 >= g.Kpad) break;
                     const bf16x8_t w1f = *(const bf16x8_t*)(t_w1 + (et * 16 + l15) * CP + ks * 32 + lg * 8);
                     const bf16x8_t w3f = *(const bf16x8_t*)(t_w3 + (et * 16 + l15) * CP + ks * 32 + lg * 8);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, *(const bf16x8_t*)&xv[ks], acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f, *(const bf16x8_t*)&dv[ks], acc2, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, *(const bf16x8_t*)&xv[i][ks], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f, *(const bf16x8_t*)&dv[i][ks], acc2, 0, 0, 0);
                 }
                 if (live) {
                     const int el = et * 16 + lg * 4;
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
                     const float4 c2v = *(const float4*)(tab2 + 96 + el), c3v = *(const float4*)(tab2 + 128 + el);
                     const float s2a[4] = {s2v.x, s2v.y, s2v.z, s2v.w}, t2a[4] = {t2v.x, t2v.y, t2v.z, t2v.w}, c1a[4] = {c1v.x, c1v.y, c1v.z, c1v.w};
                     const float c2a[4] = {c2v.x, c2v.y, c2v.z, c2v.w}, c3a[4] = {c3v.x, c3v.y, c3v.z, c3v.w};
-                    const float y2q[4] = {bf_lo(y2v[et].x), bf_hi(y2v[et].x), bf_lo(y2v[et].y), bf_hi(y2v[et].y)};
+                    const float y2q[4] = {bf_lo(y2v[i][et].x), bf_hi(y2v[i][et].x), bf_lo(y2v[i][et].y), bf_hi(y2v[i][et].y)};
                     float d[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -487,6 +505,7 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
                     }
                     wacc[dr * KS + dc] = s;
                 }
+                __builtin_amdgcn_sched_barrier(0);                  // keep the next row's LDS reads from being hoisted (registers)
             }
             // dz1 = da1 * mask1 (da1 rounded to bf16: it is what the unfused path stores), BatchNorm1-backward sums, g1
             const float2 iv = *(const float2*)(tab1 + 96 + pair * 2), nm = *(const float2*)(tab1 + 128 + pair * 2);
@@ -505,30 +524,34 @@ __global__ __launch_bounds__(256) void k_irb_bwd_dw(IrbDwArgs a) {
             }
         }
         __syncthreads();
-        // ---- x tile (act-on-load) over region R
-        for (int q0 = 0; q0 < KP * c8n; q0 += 256 * 4) {
-            uint4 xv[4];
+        // ---- x tile (act-on-load) over region R: rows of the pass only, all loads in flight
+        {
+            constexpr int NCH = 10;                                 // one batch for C <= 96 at 14x14 / C <= 192 at 7x7
+            uint4 xc[NCH];
+            const int nchunk = npx * c8n;
+          for (int q0 = 0; q0 < nchunk; q0 += 256 * NCH) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NCH; ++j) {
                 const int q = q0 + tid + 256 * j;
                 const int row = q / c8n, c8 = q - row * c8n;
-                xv[j] = make_uint4(0, 0, 0, 0);
-                if (q < KP * c8n && row < npx && c8 * 8 < g.C) xv[j] = *(const uint4*)((const uint16_t*)a.x.data + (m0 + row) * g.C + c8 * 8);
+                xc[j] = make_uint4(0, 0, 0, 0);
+                if (q < nchunk && c8 * 8 < g.C) xc[j] = *(const uint4*)((const uint16_t*)a.x.data + (m0 + row) * g.C + c8 * 8);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NCH; ++j) {
                 const int q = q0 + tid + 256 * j;
-                if (q >= KP * c8n) continue;
+                if (q >= nchunk) continue;
                 const int row = q / c8n, c8 = q - row * c8n;
-                uint4 o = xv[j];
+                uint4 o = xc[j];
                 if (hasx) {
                     float s[8], t[8];
                     *(float4*)&s[0] = *(const float4*)(tabx + c8 * 8); *(float4*)&s[4] = *(const float4*)(tabx + c8 * 8 + 4);
                     *(float4*)&t[0] = *(const float4*)(tabx + g.Kpad + c8 * 8); *(float4*)&t[4] = *(const float4*)(tabx + g.Kpad + c8 * 8 + 4);
-                    o = (row < npx && c8 * 8 < g.C) ? act8(o, s, t) : make_uint4(0, 0, 0, 0);
+                    o = (c8 * 8 < g.C) ? act8(o, s, t) : make_uint4(0, 0, 0, 0);
                 }
                 *(uint4*)(xs + row * CP + c8 * 8) = o;
             }
+          }
         }
         // rows of t_y1 of images missing from a short last pass must not carry stale dz1
         if (npx < g.NI * g.HW)
@@ -842,10 +865,12 @@ extern "C" int mnas_irb_bwd_dw(const MnasIrbBwd* c, void* stream) {
     const int CP = a.g.Kpad + 8, KP = a.g.npk * 32;
     const size_t img = (size_t)a.g.NI * RH * RW * 16 * 4;
     size_t region = 2 * img;
-    if ((size_t)KP * CP * 2 > region) region = (size_t)KP * CP * 2;
+    const size_t xs_b = (((size_t)a.g.NI * a.g.HW * CP + 1) / 2) * 4;
+    if (xs_b > region) region = xs_b;
+    if ((size_t)16 * c->k * 32 * 4 > region) region = (size_t)16 * c->k * 32 * 4;      // the final reductions alias region R
     region = (region + 15) & ~(size_t)15;
     const size_t lds = region + (size_t)KP * 40 * 2 + (size_t)2 * 32 * CP * 2 + (size_t)2 * a.g.Kpad * 4 + (size_t)10 * 32 * 4 +
-                       (size_t)c->k * c->k * 32 * 4 + (size_t)16 * c->k * 32 * 4;
+                       (size_t)c->k * c->k * 32 * 4;
     const dim3 grid(c->E / 32, c->nparts);
     hipStream_t s = (hipStream_t)stream;
     const int kst = a.g.Kpad <= 96 ? 3 : 6;

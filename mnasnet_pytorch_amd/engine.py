@@ -299,6 +299,56 @@ class Program:
             records.append(("conv", d_ci, h1, h2, Hi, Wi))
             return h2
 
+        def block_fwd_irb(e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
+            """expand + depthwise of an MBConv_block on the small maps (csrc/mnas_irb.hip): the expanded tensor y1 is NEVER written;
+            backward recomputes it (csrc/mnas_irb_bwd.hip).  BatchNorm1's statistics come from the covariance of the block input
+            (csrc/mnas_gram.hip); the Gram sums are kept for the expand conv's weight gradient.  Returns the depthwise output, or
+            None if the shape is not supported (then the per-layer kernels run)."""
+            C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
+            if e_ci.cout != E_ or not lib.mnas_irb_supported(N, Hi, Wi, C_, E_, k):
+                return None
+            M = N * Hi * Wi
+            econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
+            bn_e, bn_d = bnbuf(E_), bnbuf(E_)
+            gd = None
+            if training:
+                nsplit = max(1, min(128, _cdiv(M, 1024)))
+                gsc = eng.gram_scratch(C_, nsplit)
+                gd = torch.empty(C_ * C_ + C_, dtype=torch.float64, device=dev)       # G = sum a a^T, Sx = sum a (kept for backward)
+                self.keep.append(gd)
+                fwd.add(L.OP_GRAM, [C_, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
+                fwd.add(L.OP_GRAM_BN, [nsplit, C_, E_], [float(M), ebn.momentum, ebn.eps],
+                        [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
+                         econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
+                         ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
+                         gd.data_ptr(), bn_e.data_ptr()])
+            else:
+                fwd.add(L.OP_BN_FWD_FINALIZE, [1, E_, 0], [float(M), ebn.momentum, ebn.eps],
+                        [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
+                         ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
+            nparts = lib.mnas_irb_fwd_parts(N, Hi, Wi, C_, E_, k, max(1, eng.irb_workgroups // (E_ // 32)))
+            # "fwd" mode: the fused kernel also stores y1 and the per-layer backward kernels run (they read y1 and g2)
+            keep_y1 = training and eng.fuse_irb == "fwd"
+            y1 = new((N, Hi, Wi, E_)) if keep_y1 else None
+            y2 = new((N, Hi, Wi, E_))
+            stats = eng.scratch_stats.data_ptr() if training else None
+            fwd.add(L.OP_IRB_FWD, [N, Hi, Wi, C_, E_, k, nparts], [],
+                    a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                                       bn_e.data_ptr(), d_ci.w_fwd.data_ptr(),
+                                       dconv.bias.data_ptr() if dconv.bias is not None else None,
+                                       y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
+            fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, E_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
+                    [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
+                     dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
+            h1 = _Act(y1, bn_e, Hi, Wi, E_)                      # full mode: the expanded activation exists only on chip
+            h2 = _Act(y2, bn_d, Hi, Wi, E_)
+            records.append(("conv", e_ci, a_in, h1, Hi, Wi))
+            records.append(("conv", d_ci, h1, h2, Hi, Wi))
+            if training and not keep_y1:
+                irb_blocks[len(records) - 2] = (gd, nparts)
+            return h2
+
+        irb_blocks = {}          # index of the expand conv's record -> (Gram sums, image groups) of a fused block application
         step_records = []
         for op, m, stage in steps:
             start = len(records)
@@ -311,7 +361,12 @@ class Program:
                 a_in = cur
                 h = None
                 cis = [eng.info[id(cb)] for cb in m]
-                if eng.fuse_expand and len(cis) == 3 and cis[0].kind == "pw" and cis[1].kind == "dw" and cis[2].kind == "pw":
+                is_irb = len(cis) == 3 and cis[0].kind == "pw" and cis[1].kind == "dw" and cis[2].kind == "pw"
+                if eng.fuse_irb and is_irb:
+                    h = block_fwd_irb(cis[0], cis[1], a_in, Hc, Wc)
+                    if h is not None:
+                        h = conv_fwd(cis[2], h, Hc, Wc)
+                if h is None and eng.fuse_expand and is_irb:
                     h = block_fwd_fused(cis[0], cis[1], a_in, Hc, Wc)
                     if h is not None:
                         h = conv_fwd(cis[2], h, Hc, Wc)
@@ -526,6 +581,57 @@ class Program:
                 raise AssertionError("residual add into a depthwise dgrad does not occur")
             return gin, ncols
 
+        def block_bwd_irb(ops: _OpList, start, G, g_reduced, need_gin):
+            """Backward of a fused block application (csrc/mnas_irb_bwd.hip): three launches separated by the BatchNorm-backward
+            finalizes; g2 and y1 never exist in HBM.  Returns the gradient of the block input (skip gradient included) or None."""
+            re_, rd, rp = records[start], records[start + 1], records[start + 2]
+            gd, nparts = irb_blocks[start]
+            e_ci, d_ci, p_ci = re_[1], rd[1], rp[1]
+            a_in, Hi, Wi = re_[2], re_[4], re_[5]
+            C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
+            M = N * Hi * Wi
+            y2, bn_d = rd[3].data, rd[3].bn
+            y3, bn_p = rp[3].data, rp[3].bn
+            bn_e = re_[3].bn
+            econv, dconv = e_ci.mod.conv, d_ci.mod.conv
+            # ---- BatchNorm3 backward: sums of (G, y3) -- fused into G's producer when it could -- then the finalize
+            if g_reduced:
+                nred, red_buf = g_reduced, eng.scratch_red
+            else:
+                nred = max(1, min(1024, _cdiv(M * C_, 256 * 8 * 8)))
+                red_buf = eng.scratch_stats
+                ops.add(L.OP_BN_BWD_REDUCE, [C_, nred], [float(M)], [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), red_buf.data_ptr()])
+            if pend["ops"] is not None and pend["ops"] is not ops:
+                flush_post()
+            emit_post(ops, (red_buf.data_ptr(), bn_p.data_ptr(), eng.gptr(p_ci, 2), eng.gptr(p_ci, 3), nred, C_, float(M)))
+            common = a_in.act_ptrs() + [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), y2.data_ptr(), e_ci.w_fwd.data_ptr(),
+                                        p_ci.w_dgrad.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                                        bn_e.data_ptr(), bn_d.data_ptr(), d_ci.w_fwd.data_ptr()]
+            geo = [N, Hi, Wi, C_, E_, k, nparts]
+            dy3 = new((N, Hi, Wi, C_))
+            w3p = next_scratch()
+            ops.add(L.OP_IRB_BWD, geo + [0], [], common + [dy3.data_ptr(), w3p.data_ptr(), eng.scratch_red.data_ptr()], 0)
+            queue_wgrad(ops, w3p.data_ptr(), nparts, C_, E_, 1, False, eng.gptr(p_ci, 0))
+            emit_post(ops, (eng.scratch_red.data_ptr(), bn_d.data_ptr(), eng.gptr(d_ci, 2), eng.gptr(d_ci, 3), nparts, E_, float(M)))
+            g1 = new((N, Hi, Wi, E_))
+            dwp, pp = next_scratch(), next_scratch()
+
+            def split64(v):
+                return [v & 0xffffffff if (v & 0xffffffff) < 2 ** 31 else (v & 0xffffffff) - 2 ** 32,
+                        (v >> 32) if (v >> 32) < 2 ** 31 else (v >> 32) - 2 ** 32]
+            ops.add(L.OP_IRB_BWD, geo + [1] + split64(pp.data_ptr()) + split64(eng.scratch_red.data_ptr()), [],
+                    common + [dy3.data_ptr(), g1.data_ptr(), dwp.data_ptr()], 0)
+            queue_wgrad(ops, dwp.data_ptr(), nparts, E_, 1, k * k, True, eng.gptr(d_ci, 0))
+            emit_post(ops, (eng.scratch_red.data_ptr(), bn_e.data_ptr(), eng.gptr(e_ci, 2), eng.gptr(e_ci, 3), nparts, E_, float(M)))
+            ops.add(L.OP_IRB_W1_FIN, [nparts, E_, C_, 1], [],
+                    [pp.data_ptr(), gd.data_ptr(), econv.weight.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                     bn_e.data_ptr(), eng.gptr(e_ci, 0)], 0)
+            if not need_gin:
+                return None
+            gin = new((N, Hi, Wi, C_))
+            ops.add(L.OP_IRB_BWD, geo + [2], [], common + [g1.data_ptr(), gin.data_ptr(), None], 0)
+            return gin
+
         def target_of(act: Optional[_Act]):
             """(raw y tensor, bnbuf) of the ConvBlock that produced a VIRTUAL activation, else None."""
             if act is None or act.bn is None:
@@ -553,6 +659,12 @@ class Program:
             else:
                 re_, rd, rp = records[start], records[start + 1], records[start + 2]
                 G = g                                   # grad wrt the block output (materialised sum)
+                if start in irb_blocks:
+                    if not merge:
+                        raise NotImplementedError("the fused block backward needs Engine.merge_post")
+                    g = block_bwd_irb(ops, start, G, g_red, (not first) or need_dx)
+                    g_red = 0
+                    continue
                 g2, c2 = conv_bwd(ops, rp, G, None, True, g_red, target_of(rp[2]))
                 g1, c1 = conv_bwd(ops, rd, g2, None, True, c2, target_of(rd[2]))
                 need = (not first) or need_dx
@@ -738,6 +850,17 @@ class Engine:
         # sweeps are latency/issue-bound, not HBM-bound, so removing the expanded tensor's read does not pay for the MFMA stage
         # and the halved occupancy (166-250 VGPRs); see DESIGN.md.  Kept as an opt-in (eval mode never writes the expanded tensor).
         self.fuse_expand = False
+        # MBConv_block on the 14x14 / 7x7 maps as fused kernels with the expanded tensor kept off HBM (csrc/mnas_irb*.hip):
+        # forward expand+depthwise in one launch (y1 never written), backward in three launches that recompute y1 and the project
+        # conv's input gradient on the matrix cores instead of reading them
+        # Modes: "full" (True) = forward + backward fused; "fwd" = fused forward that also stores y1, per-layer backward kernels;
+        # False = per-layer kernels everywhere.  Validated against the mirror and against the per-layer path
+        # (tests/test_gpu_irb.py, test_gpu_model.py) -- and measured SLOWER at bs 256 (MI355X, round 3: 13.3 ms/step full,
+        # 12.1 fwd, 11.6 off): the depthwise sweep inside the fused backward is vector-ALU-bound (4700 VALU instructions per
+        # (image, 32-channel slice) against 2100 for the sweep itself), and the forward's saving is eaten by the Gram-matrix
+        # statistics pass.  Opt-in until the instruction count comes down; see DESIGN.md section 7.
+        self.fuse_irb = False
+        self.irb_workgroups = 512        # workgroups per fused-block launch ((E/32) channel slices x image groups)
         # depthwise kernel sizes whose backward runs as ONE fused sweep (input gradient + weight gradient + reduce).  5x5 too:
         # with 2-row DMA groups the fused form gets full-width strips and beats the two launches (155 vs 210 us at 56x56)
         # although it needs all 256 VGPRs; (3,) selects the split form (input gradient on main, weight gradient on side)
@@ -794,6 +917,8 @@ class Engine:
                 wmax = max(wmax, max(1, _cdiv(1024, slabs)) * ci.cout * K)
                 if ci.kind == "pw" and self.lib.mnas_pw_bwd_supported(ci.cin, ci.cout):
                     wmax = max(wmax, 1024 * ci.cout * ci.cin)      # one slab per workgroup of the fused 1x1 backward
+                if ci.kind == "pw":
+                    wmax = max(wmax, 64 * ci.cout * ci.cin)        # fused block backward: one slab per image group (<= 64)
             elif ci.kind == "dw":
                 ci.w_fwd = torch.empty(nbytes(L.PACK_DW, ci.cout, 1, ci.k, ci.k), dtype=torch.uint8, device=device)
                 wmax = max(wmax, 1024 * ci.k * ci.k * ci.cout)

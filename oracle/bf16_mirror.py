@@ -42,12 +42,22 @@ def _kind(spec: ConvSpec):
     return spec.kind
 
 
-def conv_fwd(spec: ConvSpec, a_in, st, train, image=None):
+def irb_supported(N, H, W, C, E, k):
+    """Shapes the HIP engine runs as a FUSED inverted-residual block (csrc/mnas_irb.hip: mnas_irb_supported): the 14x14 / 7x7
+    stages.  There the depthwise conv reads its input from an LDS image staged as bf16 and its backward reads dy staged as
+    bf16 -- two rounding points the per-layer depthwise kernels (act-/dy-on-read in fp32) do not have."""
+    if N < 1 or k not in (3, 5) or C % 8 or C < 16 or C > 192 or E % 32 or E < 32:
+        return False
+    return (W == 14 and 1 <= H <= 14) or (W == 7 and 1 <= H <= 7)
+
+
+def conv_fwd(spec: ConvSpec, a_in, st, train, image=None, dw_staged=False):
     p = spec.prefix
     if image is not None:
         a = round_bf16(image)
     else:
-        a = a_in.f32() if _kind(spec) == "dw" else a_in.staged()      # depthwise: act-on-read in fp32
+        # depthwise: act-on-read in fp32 -- except inside a fused block (dw_staged), where the activation is staged as bf16
+        a = a_in.f32() if (_kind(spec) == "dw" and not dw_staged) else a_in.staged()
     W = st[p + ".conv.weight"].detach()
     w = W if _kind(spec) == "dw" else round_bf16(W)
     y32 = F.conv2d(a, w, st[p + ".conv.bias"].detach(), stride=spec.stride, padding=spec.pad, groups=spec.groups)
@@ -71,7 +81,7 @@ def conv_fwd(spec: ConvSpec, a_in, st, train, image=None):
     y = round_bf16(y32)
     out = MAct(y, s, t)
     saved = dict(spec=spec, a=a, w=w, y=y, s=s, t=t, mean=mean.float(), invstd=invstd.float(), M=M,
-                 in_shape=tuple(a.shape))
+                 in_shape=tuple(a.shape), dw_staged=dw_staged)
     return out, saved
 
 
@@ -90,8 +100,9 @@ def conv_bwd(saved, g, grads, resid=None, need_gin=True):
     c2 = (-sd * isd * S2 / M).float()
     c3 = (sd * (md * isd * S2 / M - S1 / M)).float()
     dy = v(c1) * dz + (v(c2) * y + v(c3))
-    if _kind(spec) != "dw":
-        dy = round_bf16(dy)                 # staged into LDS as bf16 for the MFMA kernels; depthwise keeps fp32
+    if _kind(spec) != "dw" or saved.get("dw_staged"):
+        dy = round_bf16(dy)                 # staged into LDS as bf16 for the MFMA kernels (and inside a fused block); the
+                                            # per-layer depthwise kernels keep fp32
     p = spec.prefix
 
     def acc(name, val):
@@ -110,8 +121,9 @@ def conv_bwd(saved, g, grads, resid=None, need_gin=True):
     return round_bf16(gin)
 
 
-def run(program, st, x, train=True, cot=None, need_dx=False):
+def run(program, st, x, train=True, cot=None, need_dx=False, irb=False):
     """program: list of ("conv", spec) / ("block", [e,d,p]) (oracle.build_program or hand-made).
+    irb: mirror the engine's fused-block rounding points (Engine.fuse_irb = "full" / "fwd") on the shapes irb_supported() names.
     Returns dict(y=fp32 output, grads={name: tensor}, dx=fp32 or None)."""
     first = program[0][1] if program[0][0] == "conv" else program[0][1][0]
     is_image = first.kind == "dense" and first.cin == 3
@@ -125,8 +137,10 @@ def run(program, st, x, train=True, cot=None, need_dx=False):
             a_in = cur
             h = cur
             svs = []
+            N_, C_, H_, W_ = a_in.data.shape
+            fused = bool(irb) and len(arg) == 3 and arg[1].kind == "dw" and irb_supported(N_, H_, W_, C_, arg[1].cout, arg[1].k)
             for spec in arg:
-                h, sv = conv_fwd(spec, h, st, train)
+                h, sv = conv_fwd(spec, h, st, train, dw_staged=fused)
                 svs.append(sv)
             cur = MAct(round_bf16(a_in.f32() + h.f32()))
             tape.append(("block", svs))
