@@ -44,6 +44,8 @@ def parse():
                                                        "512x384); overrides --size")
     ap.add_argument("--k5", action="store_true", help="BASELINE config 4 (its 5x5 half): every MBConv stage with 5x5 depthwise convs "
                                                      "(the SE block of that config has no counterpart in the reference: not built)")
+    ap.add_argument("--se", action="store_true", help="BASELINE config 4 in full: 5x5 depthwise convs AND a squeeze-excite block "
+                                                     "(se_ratio 0.25, build-defined: the reference has none) in every MBConv_block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -76,7 +78,8 @@ def class_key(opc, ints, L):
              L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
              L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd", L.OP_GRAM: "k_gram", L.OP_DW_EXP_FWD: "k_dw_fwd_exp",
              L.OP_POOL_ACT: "k_pool", L.OP_POOL_BWD: "k_pool", L.OP_DY_MAT: "k_dy_mat",
-             L.OP_TCONV_DGRAD: "k_igemm<dgrad>", L.OP_IRB_FWD: "k_irb_fwd"}
+             L.OP_TCONV_DGRAD: "k_igemm<dgrad>", L.OP_IRB_FWD: "k_irb_fwd", L.OP_SE_SCALE: "k_se", L.OP_SE_BWD_REDUCE: "k_se",
+             L.OP_SE_BWD_APPLY: "k_se"}
     if opc == L.OP_IRB_BWD:         # i: N,H,W,C,E,k,nparts,which
         return ("k_irb_bwd_proj", "k_irb_bwd_dw", "k_irb_bwd_exp")[ints[7]]
     if opc == L.OP_CONV_GEMM:
@@ -134,7 +137,8 @@ def launch_work(opc, ints, L):
             nbytes, flops = 2 * 4 * px * E_, 4.0 * px * E_ * k_ * k_ + 3 * 2.0 * px * C_ * E_
         else:                       # expand conv input gradient (reads g, y of E; writes C) -- y1 recomputed: 2 GEMMs
             nbytes, flops = 2 * (2 * px * E_ + px * C_), 2 * 2.0 * px * C_ * E_
-    elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT, L.OP_GRAM, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT):
+    elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT, L.OP_GRAM, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_SE_SCALE,
+                 L.OP_SE_BWD_REDUCE, L.OP_SE_BWD_APPLY):
         nbytes, flops = 0, 0.0      # pure overhead in SURVEY 8(d)'s accounting
     else:                           # stem fwd / wgrad: fp32 image + bf16 output
         N_, H_, W_, Ho, Wo, Co = ints[:6]
@@ -183,13 +187,13 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(seconds):
+def cpu_baseline(seconds, kernel=None, se_ratio=0.0):
     """The oracle's train step on the host cores (fp32, bs=32, head '512', Adam) -- kind 'port'."""
     from oracle import mnasnet_oracle as O
     threads = os.cpu_count() or 1
     threads = min(threads, 64)          # oneDNN stops scaling on these tiny convs well before 64 threads
     torch.set_num_threads(threads)
-    net = O.OracleNet(ccf=False, head="512", num_classes=1000, seed=1).train()
+    net = O.OracleNet(ccf=False, head="512", num_classes=1000, seed=1, kernel=kernel, se_ratio=se_ratio).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     bs = 32
     g = torch.Generator().manual_seed(1234)
@@ -244,7 +248,10 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         base = load_model("mnasnet")
-    if args.k5:
+    if args.se:
+        from mnasnet_pytorch_amd import Mnasnet
+        base = Mnasnet(False, kernel_size=5, se_ratio=0.25)
+    elif args.k5:
         from mnasnet_pytorch_amd.mnasnet import ConvBlock, MBConv, SepConv, _Features
         cfg = [(16, 24, 3, 3, True), (24, 40, 3, 3, True), (40, 80, 6, 3, True), (80, 96, 6, 2, False), (96, 192, 6, 4, True),
                (192, 320, 6, 1, False)]
@@ -280,7 +287,7 @@ def main():
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
                L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD,
-               L.OP_IRB_FWD, L.OP_IRB_BWD}
+               L.OP_IRB_FWD, L.OP_IRB_BWD, L.OP_SE_SCALE, L.OP_SE_BWD_REDUCE, L.OP_SE_BWD_APPLY}
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size
@@ -356,7 +363,7 @@ def main():
         "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes%s) fwd+bwd+Adam, "
-                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (", all depthwise convs 5x5" if args.k5 else "", B, Hh, Ww),
+                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (", all depthwise convs 5x5 + squeeze-excite (build-defined)" if args.se else (", all depthwise convs 5x5" if args.k5 else ""), B, Hh, Ww),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss": round(lossv, 4)},
     }
     # ---- roofline of the dominant kernel class: events recorded inside the timed region (last timed step) -----------
@@ -391,7 +398,7 @@ def main():
                 sys.stderr.write("%-18s %-48s %8.1f us %8.1f GB/s\n" % (key, ",".join(map(str, ints)), msv * 1e3,
                                                                       nb_ / max(msv, 1e-9) / 1e6))
     if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 5 if (args.k5 or args.se) else None, 0.25 if args.se else 0.0)
     print(json.dumps(res))
     if distributed:
         import torch.distributed as dist

@@ -426,6 +426,16 @@ int mnas_head_dropout_mask(void* out_u8, int64_t n, float p, uint64_t seed, void
 int mnas_head_cross_entropy(const void* logits, const void* target, int N, int C, int64_t ignore_index,
                             void* loss_rows, void* loss, void* dlogits, void* bad_flag, void* stream);
 
+/* ---- squeeze-and-excitation of the SE variant of MBConv_block (BASELINE config 4; build-defined -- the reference has no SE
+ * block; csrc/mnas_se.hip, restated in oracle.se_apply).  a = the activated depthwise output (act-on-load of y2), u = the
+ * excite logits fp32 [N][C] (mnas_pool_act -> mnas_head_linear_fwd x2 produce them).
+ *   mnas_se_scale      : out = act(a) * sigmoid(u)[n][c]            (bf16 (N,HW,C): what the project conv then reads)
+ *   mnas_se_bwd_reduce : du[n][c] = (sum_hw gs * act(a)) * s (1 - s), s = sigmoid(u)   (gs = dL/d out, bf16)
+ *   mnas_se_bwd_apply  : out = gs * sigmoid(u) + dz[n][c] / HW      (dz = dL/d(pooled a) from the MLP backward; out = dL/d act(a)) */
+int mnas_se_scale(const MnasActIn* a, const float* u, int N, int HW, int C, void* out_bf16, void* stream);
+int mnas_se_bwd_reduce(const void* gs, const MnasActIn* a, const float* u, int N, int HW, int C, float* du, void* stream);
+int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16, void* stream);
+
 /* ---- weight packing (fp32 reference layout [Co][Ci/g][kh][kw] -> kernel layouts) -------------------- */
 #define MNAS_PACK_FWD   0   /* bf16 [Co_pad16][Kpad32], k = tap*Ci+ci            (mnas_conv_gemm mode 0) */
 #define MNAS_PACK_DGRAD 1   /* bf16 [Ci_pad16][Kpad32], k = tap*Co+co            (mnas_conv_gemm mode 1) */
@@ -478,6 +488,10 @@ int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 #define MNAS_OP_IRB_FWD 27
 #define MNAS_OP_IRB_BWD 28     /* i[7] selects the launch: 0 proj, 1 dw, 2 exp */
 #define MNAS_OP_IRB_W1_FIN 29
+#define MNAS_OP_HEAD_LINEAR 30  /* i[5]: 0 forward, 1 weight gradient, 2 input gradient */
+#define MNAS_OP_SE_SCALE 31
+#define MNAS_OP_SE_BWD_REDUCE 32
+#define MNAS_OP_SE_BWD_APPLY 33
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

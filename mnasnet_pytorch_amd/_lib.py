@@ -117,6 +117,7 @@ OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINA
 OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
 OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
 OP_BWD_POST, OP_TCONV_DGRAD, OP_IRB_FWD, OP_IRB_BWD, OP_IRB_W1_FIN = 25, 26, 27, 28, 29
+OP_HEAD_LINEAR, OP_SE_SCALE, OP_SE_BWD_REDUCE, OP_SE_BWD_APPLY = 30, 31, 32, 33
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 EINVAL = 10001      # MNAS_EINVAL
 
@@ -144,6 +145,9 @@ SYMBOLS = {
     "mnas_irb_bwd_exp": (c_int, [C.POINTER(MnasIrbBwd), c_void_p]),
     "mnas_irb_w1_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mnas_irb_fwd_parts": (c_int, [c_int] * 7),
+    "mnas_se_scale": (c_int, [C.POINTER(MnasActIn), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_se_bwd_reduce": (c_int, [c_void_p, C.POINTER(MnasActIn), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_se_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),
     "mnas_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),

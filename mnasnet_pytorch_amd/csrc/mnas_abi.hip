@@ -79,6 +79,10 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  IRB_BWD          i: N,H,W,C,E,k,nparts,which    p: x.data,x.scale,x.shift, gout.g,gout.y,gout.coef, y2,w1,w3t,b1,bn1,bn2,wdw,
 //                                                     dy3,g1,dx  + second op record? no: outputs by `which`: see below
 //  IRB_W1_FIN       i: nparts,E,C,accumulate       p: ppartial,gsum,w1,b1,bn1,grad
+//  HEAD_LINEAR      i: N,I,O,relu,accumulate,which   p: x,w,b,y,dz,dw,db,dx,relu_mask        (no dropout in launch lists)
+//  SE_SCALE         i: N,HW,C                      p: a.data,a.scale,a.shift, u, out
+//  SE_BWD_REDUCE    i: N,HW,C                      p: gs, a.data,a.scale,a.shift, u, du
+//  SE_BWD_APPLY     i: N,HW,C                      p: gs, u, dz, out
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -234,6 +238,25 @@ static int run_one(const MnasOp& o, void* stream) {
         case MNAS_OP_IRB_W1_FIN:
             return mnas_irb_w1_finalize((const float*)p[0], i[0], i[1], i[2], (const double*)p[1], (const float*)p[2], (const float*)p[3],
                                         (const float*)p[4], (float*)p[5], i[3], stream);
+        case MNAS_OP_HEAD_LINEAR: {
+            MnasHeadLinear a = {};
+            a.N = i[0]; a.I = i[1]; a.O = i[2]; a.relu = i[3]; a.accumulate = i[4]; a.drop_p = 0.f; a.seed = 0;
+            a.x = p[0]; a.w = p[1]; a.b = p[2]; a.y = p[3]; a.dz = p[4]; a.dw = p[5]; a.db = p[6]; a.dx = p[7]; a.relu_mask = p[8];
+            if (i[5] == 0) return mnas_head_linear_fwd(&a, stream);
+            if (i[5] == 1) return mnas_head_linear_bwd_w(&a, stream);
+            if (i[5] == 2) return mnas_head_linear_bwd_x(&a, stream);
+            return MNAS_EINVAL;
+        }
+        case MNAS_OP_SE_SCALE: {
+            MnasActIn a = {p[0], (const float*)p[1], (const float*)p[2]};
+            return mnas_se_scale(&a, (const float*)p[3], i[0], i[1], i[2], p[4], stream);
+        }
+        case MNAS_OP_SE_BWD_REDUCE: {
+            MnasActIn a = {p[1], (const float*)p[2], (const float*)p[3]};
+            return mnas_se_bwd_reduce(p[0], &a, (const float*)p[4], i[0], i[1], i[2], (float*)p[5], stream);
+        }
+        case MNAS_OP_SE_BWD_APPLY:
+            return mnas_se_bwd_apply(p[0], (const float*)p[1], (const float*)p[2], i[0], i[1], i[2], p[3], stream);
         case MNAS_OP_DY_MAT: {
             MnasGradIn d = {p[0], p[1], (const float*)p[2]};
             return mnas_dy_materialize(&d, (int64_t)o.d[0], i[0], p[3], stream);

@@ -278,6 +278,7 @@ struct IrbDwArgs {
     float* dwpartial;           // out [gridDim.y][k*k][E]
     float* ppartial;            // out [gridDim.y][E][C]
     float* red1;                // out [2][E][gridDim.y]
+    int lds_bytes;              // dynamic LDS of the launch (zeroed once: see the x tile note in the kernel)
 };
 
 template <int KS, int WW, int KST>
@@ -313,6 +314,11 @@ __global__ __launch_bounds__(256, 2) void k_irb_bwd_dw(IrbDwArgs a) {
     const int c8n = g.Kpad >> 3;
     const bool hasx = a.x.scale != nullptr;
 
+    // every byte of the workgroup's LDS starts as zero: the P GEMM's last 32-pixel step reads x-tile rows that alias whatever
+    // follows region R (t_y1, the PAD columns of the weight tiles): they meet zero rows of dz1, so they only have to be finite --
+    // uninitialised LDS (another kernel's leftovers) is not
+    for (int i = tid; i < (a.lds_bytes >> 4); i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
     for (int i = tid; i < 2 * g.Kpad; i += 256) {
         const int c = i < g.Kpad ? i : i - g.Kpad;
         tabx[i] = (hasx && c < g.C) ? (i < g.Kpad ? a.x.scale[c] : a.x.shift[c]) : 0.f;
@@ -334,7 +340,8 @@ __global__ __launch_bounds__(256, 2) void k_irb_bwd_dw(IrbDwArgs a) {
         *(uint4*)(t_w1 + r * CP + c8 * 8) = *(const uint4*)(a.w1 + (size_t)(e0 + r) * g.Kpad + c8 * 8);
         *(uint4*)(t_w3 + r * CP + c8 * 8) = *(const uint4*)(a.w3t + (size_t)(e0 + r) * g.Kpad + c8 * 8);
     }
-    for (int i = tid; i < ((KP * YP) >> 3); i += 256) ((uint4*)t_y1)[i] = make_uint4(0, 0, 0, 0);   // rows beyond the image stay zero
+    // (t_y1 rows beyond the image stay zero for the whole kernel; the x tile's rows of a SHORT last pass are not rewritten and
+    // keep finite values)
 
     // MFMA-phase pixels of this lane
     int poff[4], ppix[4];
@@ -375,10 +382,14 @@ __global__ __launch_bounds__(256, 2) void k_irb_bwd_dw(IrbDwArgs a) {
         __syncthreads();
         // ---- y1 = W1 act(x) + b1 -> t_y1 (bf16) and a1 -> padded image;   da2 = dy3 W3 -> dy2 -> padded image
         // all global loads of the pass (x, dy3 fragments and the y2 values of this lane's pixels) are issued up front
+        constexpr int IC = KST <= 3 ? 4 : 2;                        // pixel tiles whose loads are in flight together
+#pragma unroll
+      for (int ib = 0; ib < 4; ib += IC) {
+        if (wave + 4 * ib >= g.npt) break;
         uint4 xv[4][KST], dv[4][KST];
         uint2 y2v[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = ib; i < ib + IC; ++i) {
             const bool live = ppix[i] >= 0 && ppix[i] < npx;
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_irb_bwd_dw(IrbDwArgs a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = ib; i < ib + IC; ++i) {
             if (wave + 4 * i >= g.npt) break;
             const bool live = ppix[i] >= 0 && ppix[i] < npx;
             if (hasx) {
@@ -451,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_irb_bwd_dw(IrbDwArgs a) {
                 }
             }
         }
+      }
         __syncthreads();
         // ---- depthwise backward: input gradient (flipped filter over dy2) + weight gradient (dy2 row x a1 window), one sweep
         if (task && t_im < nimg) {
@@ -869,8 +881,10 @@ extern "C" int mnas_irb_bwd_dw(const MnasIrbBwd* c, void* stream) {
     if (xs_b > region) region = xs_b;
     if ((size_t)16 * c->k * 32 * 4 > region) region = (size_t)16 * c->k * 32 * 4;      // the final reductions alias region R
     region = (region + 15) & ~(size_t)15;
-    const size_t lds = region + (size_t)KP * 40 * 2 + (size_t)2 * 32 * CP * 2 + (size_t)2 * a.g.Kpad * 4 + (size_t)10 * 32 * 4 +
-                       (size_t)c->k * c->k * 32 * 4;
+    size_t lds = region + (size_t)KP * 40 * 2 + (size_t)2 * 32 * CP * 2 + (size_t)2 * a.g.Kpad * 4 + (size_t)10 * 32 * 4 +
+                 (size_t)c->k * c->k * 32 * 4;
+    lds = (lds + 15) & ~(size_t)15;
+    a.lds_bytes = (int)lds;
     const dim3 grid(c->E / 32, c->nparts);
     hipStream_t s = (hipStream_t)stream;
     const int kst = a.g.Kpad <= 96 ? 3 : 6;

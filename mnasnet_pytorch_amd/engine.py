@@ -74,8 +74,19 @@ class _ConvInfo:
         return ((H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1)
 
 
-def _trace(root):
-    """Flatten a module subtree into steps: ("conv", ConvBlock, stage) / ("block", [e,d,p], stage)."""
+class _SEInfo:
+    """One unique SqueezeExcite module (build-defined SE variant): parameter bookkeeping like _ConvInfo."""
+
+    def __init__(self, mod, stage):
+        self.mod, self.stage = mod, stage
+        self.channels, self.reduced = mod.fc1.in_features, mod.fc1.out_features
+        self.params = [mod.fc1.weight, mod.fc1.bias, mod.fc2.weight, mod.fc2.bias]
+        self.gslice = {}
+
+
+def _trace(root, se_map=None):
+    """Flatten a module subtree into steps: ("conv", ConvBlock, stage) / ("block", [e,d,p], stage).  se_map (optional dict)
+    receives id(expand ConvBlock) -> SqueezeExcite module for blocks that carry one."""
     steps = []
 
     def rec(m, stage):
@@ -84,6 +95,8 @@ def _trace(root):
             steps.append(("conv", m, stage))
         elif name == "MBConv_block":
             steps.append(("block", list(m.sequence), stage))
+            if se_map is not None and getattr(m, "se", None) is not None:
+                se_map[id(m.sequence[0])] = m.se
         elif name in ("SepConv", "MBConv"):
             for c in m.sequence:
                 rec(c, stage)
@@ -348,6 +361,23 @@ class Program:
                 irb_blocks[len(records) - 2] = (gd, nparts)
             return h2
 
+        def se_fwd(se: _SEInfo, h2: _Act, Hi, Wi):
+            """squeeze-excite on the activated depthwise output (csrc/mnas_se.hip): pooled mean -> fc1+ReLU -> fc2 -> a2 * sigmoid.
+            Returns the MATERIALISED scaled activation the project conv reads."""
+            E_, R_ = se.channels, se.reduced
+            z = new((N, E_), torch.float32)
+            hb = new((N, R_), torch.float32)
+            u = new((N, E_), torch.float32)
+            a2s = new((N, Hi, Wi, E_))
+            m_ = se.mod
+            fwd.add(L.OP_POOL_ACT, [N, Hi * Wi, E_], [], h2.act_ptrs() + [z.data_ptr()])
+            fwd.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 0], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), hb.data_ptr()])
+            fwd.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 0], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), m_.fc2.bias.data_ptr(), u.data_ptr()])
+            fwd.add(L.OP_SE_SCALE, [N, Hi * Wi, E_], [], h2.act_ptrs() + [u.data_ptr(), a2s.data_ptr()])
+            se_records[len(records)] = (se, h2, z, hb, u)        # keyed by the record index of the project conv that follows
+            return _Act(a2s, None, Hi, Wi, E_)
+
+        se_records = {}
         irb_blocks = {}          # index of the expand conv's record -> (Gram sums, image groups) of a fused block application
         step_records = []
         for op, m, stage in steps:
@@ -362,17 +392,22 @@ class Program:
                 h = None
                 cis = [eng.info[id(cb)] for cb in m]
                 is_irb = len(cis) == 3 and cis[0].kind == "pw" and cis[1].kind == "dw" and cis[2].kind == "pw"
-                if eng.fuse_irb and is_irb:
+                if eng.fuse_irb and is_irb and id(m[0]) not in eng.se_info:
                     h = block_fwd_irb(cis[0], cis[1], a_in, Hc, Wc)
                     if h is not None:
                         h = conv_fwd(cis[2], h, Hc, Wc)
-                if h is None and eng.fuse_expand and is_irb:
+                if h is None and eng.fuse_expand and is_irb and id(m[0]) not in eng.se_info:
                     h = block_fwd_fused(cis[0], cis[1], a_in, Hc, Wc)
                     if h is not None:
                         h = conv_fwd(cis[2], h, Hc, Wc)
+                se = eng.se_info.get(id(m[0]))
+                if se is not None:
+                    h = None                                # SE blocks run per layer (the fused paths have no SE stage)
                 if h is None:
                     h = cur
-                    for ci_ in cis:
+                    for j_, ci_ in enumerate(cis):
+                        if j_ == 2 and se is not None:
+                            h = se_fwd(se, h, Hc, Wc)
                         h = conv_fwd(ci_, h, Hc, Wc)
                 r = new((N, Hc, Wc, a_in.C))
                 fwd.add(L.OP_ADD_ACT, [a_in.C, Hc * Wc], [float(N * Hc * Wc)],
@@ -632,6 +667,31 @@ class Program:
             ops.add(L.OP_IRB_BWD, geo + [2], [], common + [g1.data_ptr(), gin.data_ptr(), None], 0)
             return gin
 
+        def se_bwd(ops: _OpList, rec_index, gs):
+            """Backward of the squeeze-excite stage: gs = dL/d(a2 * s) from the project conv's input gradient -> dL/d a2, and the
+            SE parameters' gradients (accumulated into the flat buffer; shared blocks sum their applications)."""
+            se, h2, z, hb, u = se_records[rec_index]
+            E_, R_ = se.channels, se.reduced
+            HWl = h2.H * h2.W
+            m_ = se.mod
+            du = new((N, E_), torch.float32)
+            dh = new((N, R_), torch.float32)
+            dzp = new((N, E_), torch.float32)
+            ga = new((N, h2.H, h2.W, E_))
+            ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr()], 0)
+            # fc2: dW2 += du^T hb, db2 += sum du ; dh = (du W2) * [hb > 0]
+            ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 1, 1], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
+                                                                eng.gptr(se, 2), eng.gptr(se, 3)], 0)
+            ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 2], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
+                                                                None, None, dh.data_ptr(), hb.data_ptr()], 0)
+            # fc1: dW1 += dh^T z, db1 += sum dh ; dz = dh W1
+            ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 1, 1], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
+                                                                eng.gptr(se, 0), eng.gptr(se, 1)], 0)
+            ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 2], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
+                                                                None, None, dzp.data_ptr(), None], 0)
+            ops.add(L.OP_SE_BWD_APPLY, [N, HWl, E_], [], [gs.data_ptr(), u.data_ptr(), dzp.data_ptr(), ga.data_ptr()], 0)
+            return ga
+
         def target_of(act: Optional[_Act]):
             """(raw y tensor, bnbuf) of the ConvBlock that produced a VIRTUAL activation, else None."""
             if act is None or act.bn is None:
@@ -666,6 +726,8 @@ class Program:
                     g_red = 0
                     continue
                 g2, c2 = conv_bwd(ops, rp, G, None, True, g_red, target_of(rp[2]))
+                if (start + 2) in se_records:
+                    g2, c2 = se_bwd(ops, start + 2, g2), 0          # g2 becomes dL/d(activated depthwise output)
                 g1, c1 = conv_bwd(ops, rd, g2, None, True, c2, target_of(rd[2]))
                 need = (not first) or need_dx
                 if need:
@@ -807,7 +869,8 @@ class Engine:
 
     def __init__(self, root: nn.Module):
         self.root = root
-        self.steps = _trace(root)
+        self._se_mods = {}
+        self.steps = _trace(root, self._se_mods)
         self.lib = None
         self.device = None
         self.programs: Dict[tuple, List[Program]] = {}
@@ -825,11 +888,23 @@ class Engine:
             for cb in ([m] if op == "conv" else m):
                 if self.info[id(cb)].kind == "stem" and n != 0:
                     raise NotImplementedError("a 3-channel stride-2 conv is only supported as the first layer")
+        # squeeze-excite modules (SE variant only): one _SEInfo per unique module, keyed by its block's expand ConvBlock
+        self.se_info: Dict[int, _SEInfo] = {}
+        self.ses: List[_SEInfo] = []
+        by_mod = {}
+        for op, m, stage in self.steps:
+            if op == "block" and id(m[0]) in self._se_mods:
+                se = self._se_mods[id(m[0])]
+                if id(se) not in by_mod:
+                    by_mod[id(se)] = _SEInfo(se, stage)
+                    self.ses.append(by_mod[id(se)])
+                self.se_info[id(m[0])] = by_mod[id(se)]
+        self.param_owners = self.convs + self.ses      # everything that owns parameters, in the flat-gradient order below
         # flat gradient layout: later stages first (their gradients are complete first in backward)
         self.params: List[nn.Parameter] = []
         off = 0
         self.stage_ranges: Dict[int, List[int]] = {}
-        for ci in sorted(self.convs, key=lambda c: -c.stage):
+        for ci in sorted(self.param_owners, key=lambda c: -c.stage):
             a = off
             for j, p in enumerate(ci.params):
                 ci.gslice[j] = (off, p.numel())
@@ -938,7 +1013,7 @@ class Engine:
         else:
             self.flat_grad = torch.zeros(self.grad_numel, dtype=torch.float32, device=device)
         self.grad_views = []
-        for ci in sorted(self.convs, key=lambda c: -c.stage):
+        for ci in sorted(self.param_owners, key=lambda c: -c.stage):
             for j, p in enumerate(ci.params):
                 o, n = ci.gslice[j]
                 self.grad_views.append(self.flat_grad[o:o + n].view(p.shape))
@@ -960,6 +1035,10 @@ class Engine:
                                     (name, t.dtype, "" if t.is_contiguous() else ", non-contiguous"))
             if bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype != torch.int64:
                 raise TypeError("bn.num_batches_tracked must be int64")
+        for se in self.ses:
+            for t in se.params:
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise TypeError("mnasnet_pytorch_amd: SqueezeExcite parameters must be contiguous float32")
 
     def _check_modes(self):
         """One mode per call: the launch list is compiled for root.training.  A submodule in a different mode (frozen-BN

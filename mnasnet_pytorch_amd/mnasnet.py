@@ -22,7 +22,7 @@ from .engine import Engine
 
 default_activation = nn.ReLU   # mnasnet.py:9
 
-__all__ = ["ConvBlock", "SepConv", "MBConv_block", "MBConv", "Mnasnet"]
+__all__ = ["ConvBlock", "SepConv", "MBConv_block", "MBConv", "Mnasnet", "SqueezeExcite"]
 
 
 class _EngineModule(nn.Module):
@@ -74,10 +74,25 @@ class SepConv(_EngineModule):
         self.sequence = nn.Sequential(*seq)
 
 
-class MBConv_block(_EngineModule):
-    """x + project(dw(expand(x)))  -- the inverted-residual block, mnasnet.py:105-137"""
+class SqueezeExcite(nn.Module):
+    """Squeeze-and-excitation on the activated depthwise output of an MBConv_block: a * sigmoid(fc2(relu(fc1(mean_hw a)))).
+    BUILD-DEFINED (BASELINE config 4's "SE-block variant"): the reference has no SE block; the definition is restated in
+    oracle.mnasnet_oracle.se_apply and that is what the parity tests check ("parity unpinned by the reference").  A parameter
+    container like ConvBlock's children: the HIP engine runs it (csrc/mnas_se.hip); its own forward is never called."""
 
-    def __init__(self, in_channels, channel_factor, kernel_size=3):
+    def __init__(self, channels, reduced):
+        super().__init__()
+        self.fc1 = nn.Linear(channels, reduced)
+        self.fc2 = nn.Linear(reduced, channels)
+
+
+class MBConv_block(_EngineModule):
+    """x + project(dw(expand(x)))  -- the inverted-residual block, mnasnet.py:105-137.
+    se_ratio > 0 (not in the reference): a SqueezeExcite with max(8, in_channels * se_ratio) hidden units between the depthwise
+    and the projection ConvBlocks (extra state_dict keys ``se.fc1.*`` / ``se.fc2.*``; with the default 0 the key set is the
+    reference's)."""
+
+    def __init__(self, in_channels, channel_factor, kernel_size=3, se_ratio=0.0):
         super().__init__()
         self.in_channels = in_channels
         padding = kernel_size // 2
@@ -86,18 +101,20 @@ class MBConv_block(_EngineModule):
             ConvBlock(in_channels, mid, kernel_size=1, stride=1),
             ConvBlock(mid, mid, kernel_size=kernel_size, stride=1, padding=padding, groups=mid),
             ConvBlock(mid, in_channels, kernel_size=1, stride=1))
+        if se_ratio and se_ratio > 0:
+            self.se = SqueezeExcite(mid, max(8, int(round(in_channels * se_ratio))))
 
 
 class MBConv(_EngineModule):
     """stage container  -- mnasnet.py:139-173 (list-multiply => ONE shared block applied `layers` times)"""
 
     def __init__(self, in_channels, out_channels, channel_factor, layers, kernel_size=3, reduce=True,
-                 cut_channels_first=True):
+                 cut_channels_first=True, se_ratio=0.0):
         super().__init__()
         block_channels = out_channels if cut_channels_first else in_channels
         stride = 2 if reduce else 1
         seq = [ConvBlock(in_channels, out_channels, kernel_size=3, stride=stride, padding=1)] + \
-              [MBConv_block(block_channels, channel_factor, kernel_size)] * layers
+              [MBConv_block(block_channels, channel_factor, kernel_size, se_ratio=se_ratio)] * layers
         if not cut_channels_first:
             seq = list(reversed(seq))
         self.sequence = nn.Sequential(*seq)
@@ -124,20 +141,24 @@ class _Features(nn.Sequential):
 
 
 class Mnasnet(nn.Module):
-    """mnasnet.py:175-213"""
+    """mnasnet.py:175-213.  ``Mnasnet(cut_channels_first=True)`` is the reference's signature and network.  The keyword-only
+    extras build BASELINE config 4's variant (not in the reference): ``kernel_size=5`` gives every MBConv stage 5x5 depthwise
+    convs, ``se_ratio=0.25`` adds a SqueezeExcite to every MBConv_block."""
 
-    def __init__(self, cut_channels_first=True):
+    def __init__(self, cut_channels_first=True, *, kernel_size=None, se_ratio=0.0):
         super().__init__()
         ccf = cut_channels_first
+        ks = (lambda k: k) if kernel_size is None else (lambda k: kernel_size)
+        kw = dict(cut_channels_first=ccf, se_ratio=se_ratio)
         self.features = _Features(
             ConvBlock(3, 32, kernel_size=3, stride=2, padding=1),
             SepConv(32, 16, kernel_size=3),
-            MBConv(16, 24, channel_factor=3, layers=3, kernel_size=3, reduce=True, cut_channels_first=ccf),
-            MBConv(24, 40, channel_factor=3, layers=3, kernel_size=5, reduce=True, cut_channels_first=ccf),
-            MBConv(40, 80, channel_factor=6, layers=3, kernel_size=5, reduce=True, cut_channels_first=ccf),
-            MBConv(80, 96, channel_factor=6, layers=2, kernel_size=3, reduce=False, cut_channels_first=ccf),
-            MBConv(96, 192, channel_factor=6, layers=4, kernel_size=5, reduce=True, cut_channels_first=ccf),
-            MBConv(192, 320, channel_factor=6, layers=1, kernel_size=3, reduce=False, cut_channels_first=ccf))
+            MBConv(16, 24, channel_factor=3, layers=3, kernel_size=ks(3), reduce=True, **kw),
+            MBConv(24, 40, channel_factor=3, layers=3, kernel_size=ks(5), reduce=True, **kw),
+            MBConv(40, 80, channel_factor=6, layers=3, kernel_size=ks(5), reduce=True, **kw),
+            MBConv(80, 96, channel_factor=6, layers=2, kernel_size=ks(3), reduce=False, **kw),
+            MBConv(96, 192, channel_factor=6, layers=4, kernel_size=ks(5), reduce=True, **kw),
+            MBConv(192, 320, channel_factor=6, layers=1, kernel_size=ks(3), reduce=False, **kw))
         self.init_params()
 
     def init_params(self):

@@ -217,7 +217,7 @@ class Trainer:
                 p.data = self.flat_p[off:off + k].view(p.shape)
                 p.grad = self.flat_g[off:off + k].view(p.shape)      # autograd accumulates in place
                 off += k
-            for ci in sorted(self.engine.convs, key=lambda c: -c.stage):
+            for ci in sorted(self.engine.param_owners, key=lambda c: -c.stage):
                 for j, p in enumerate(ci.params):
                     o, k = ci.gslice[j]
                     self.flat_p[n_head + o:n_head + o + k].copy_(p.reshape(-1))

@@ -121,6 +121,38 @@ def conv_bwd(saved, g, grads, resid=None, need_gin=True):
     return round_bf16(gin)
 
 
+def se_fwd(se, a2: "MAct", st):
+    """Squeeze-excite of the SE variant with the HIP path's rounding points (csrc/mnas_se.hip): pooled mean, MLP and sigmoid in
+    fp32 on the fp32 activation; the scaled activation is MATERIALISED as bf16 for the project conv."""
+    p = se.prefix
+    a = a2.f32()
+    z = a.mean((2, 3))
+    w1, b1 = st[p + ".fc1.weight"].detach(), st[p + ".fc1.bias"].detach()
+    w2, b2 = st[p + ".fc2.weight"].detach(), st[p + ".fc2.bias"].detach()
+    h = F.relu(F.linear(z, w1, b1))
+    sg = torch.sigmoid(F.linear(h, w2, b2))
+    out = MAct(round_bf16(a * sg[:, :, None, None]))
+    return out, dict(se=se, a=a, z=z, h=h, sg=sg, w1=w1, w2=w2)
+
+
+def se_bwd(saved, gs, grads):
+    """gs: bf16-valued dL/d(a * s).  Accumulates the SE parameters' gradients; returns bf16-valued dL/da."""
+    se, a, z, h, sg, w1, w2 = (saved[k] for k in ("se", "a", "z", "h", "sg", "w1", "w2"))
+    HW = a.shape[2] * a.shape[3]
+    du = (gs * a).sum((2, 3)) * sg * (1 - sg)
+    dh = (du @ w2) * (h > 0)
+    dz = dh @ w1
+    p = se.prefix
+
+    def acc(name, val):
+        grads[name] = grads.get(name, 0) + val
+    acc(p + ".fc2.weight", du.t() @ h)
+    acc(p + ".fc2.bias", du.sum(0))
+    acc(p + ".fc1.weight", dh.t() @ z)
+    acc(p + ".fc1.bias", dh.sum(0))
+    return round_bf16(gs * sg[:, :, None, None] + dz[:, :, None, None] / HW)
+
+
 def run(program, st, x, train=True, cot=None, need_dx=False, irb=False):
     """program: list of ("conv", spec) / ("block", [e,d,p]) (oracle.build_program or hand-made).
     irb: mirror the engine's fused-block rounding points (Engine.fuse_irb = "full" / "fwd") on the shapes irb_supported() names.
@@ -139,9 +171,13 @@ def run(program, st, x, train=True, cot=None, need_dx=False, irb=False):
             svs = []
             N_, C_, H_, W_ = a_in.data.shape
             fused = bool(irb) and len(arg) == 3 and arg[1].kind == "dw" and irb_supported(N_, H_, W_, C_, arg[1].cout, arg[1].k)
-            for spec in arg:
+            sse = None
+            for j, spec in enumerate(arg[:3]):
+                if j == 2 and len(arg) == 4:
+                    h, sse = se_fwd(arg[3], h, st)
                 h, sv = conv_fwd(spec, h, st, train, dw_staged=fused)
                 svs.append(sv)
+            svs.append(sse)
             cur = MAct(round_bf16(a_in.f32() + h.f32()))
             tape.append(("block", svs))
     out = dict(y=cur.f32(), grads={}, dx=None)
@@ -158,6 +194,8 @@ def run(program, st, x, train=True, cot=None, need_dx=False, irb=False):
         else:
             G = g
             g2 = conv_bwd(sv[2], G, grads)
+            if sv[3] is not None:
+                g2 = se_bwd(sv[3], g2, grads)
             g1 = conv_bwd(sv[1], g2, grads)
             need = (not first_step) or need_dx
             g = conv_bwd(sv[0], g1, grads, G if need else None, need)

@@ -126,16 +126,44 @@ class ConvSpec:
         return (self.cout, self.cin // self.groups, self.k, self.k)
 
 
-def _block_specs(prefix: str, c: int, t: int, k: int) -> List[ConvSpec]:
-    """MBConv_block: 1x1 C->tC, kxk depthwise tC, 1x1 tC->C (mnasnet.py:116-129)."""
-    return [
+class SESpec:
+    """Squeeze-and-excitation stage of the SE variant (BASELINE config 4).  BUILD-DEFINED: the reference has no SE block, so this
+    restates mnasnet_pytorch_amd.mnasnet.SqueezeExcite, not a reference line ("parity unpinned by the reference")."""
+    __slots__ = ("prefix", "aliases", "channels", "reduced")
+    kind = "se"
+
+    def __init__(self, prefix, channels, reduced):
+        self.prefix, self.channels, self.reduced = prefix, channels, reduced
+        self.aliases = [prefix]
+
+
+def se_reduced(c: int, se_ratio: float) -> int:
+    return max(8, int(round(c * se_ratio)))
+
+
+def _block_specs(prefix: str, c: int, t: int, k: int, se_ratio: float = 0.0) -> list:
+    """MBConv_block: 1x1 C->tC, kxk depthwise tC, 1x1 tC->C (mnasnet.py:116-129).  With se_ratio > 0 a 4th entry (SESpec) follows;
+    it is applied BETWEEN the depthwise and the projection ConvBlocks."""
+    specs = [
         ConvSpec(prefix + ".sequence.0", c, c * t, 1, 1, 0, 1),
         ConvSpec(prefix + ".sequence.1", c * t, c * t, k, 1, k // 2, c * t),
         ConvSpec(prefix + ".sequence.2", c * t, c, 1, 1, 0, 1),
     ]
+    if se_ratio and se_ratio > 0:
+        specs.append(SESpec(prefix + ".se", c * t, se_reduced(c, se_ratio)))
+    return specs
 
 
-def build_program(ccf: bool):
+def se_apply(a, st, se: SESpec):
+    """a * sigmoid(fc2(relu(fc1(mean_hw a))))  -- mnasnet_pytorch_amd.mnasnet.SqueezeExcite (build-defined)."""
+    p = se.prefix
+    z = a.mean((2, 3))
+    h = F.relu(F.linear(z, st[p + ".fc1.weight"], st[p + ".fc1.bias"]))
+    s = torch.sigmoid(F.linear(h, st[p + ".fc2.weight"], st[p + ".fc2.bias"]))
+    return a * s[:, :, None, None]
+
+
+def build_program(ccf: bool, kernel: Optional[int] = None, se_ratio: float = 0.0):
     """Returns (program, unique_specs).
 
     program is a list of steps, each one of
@@ -156,20 +184,24 @@ def build_program(ccf: bool):
     for si, (cin, cout, t, layers, k, reduce) in enumerate(STAGES):
         f = "features.%d" % (si + 2)
         stride = 2 if reduce else 1
+        if kernel is not None:
+            k = kernel            # config 4: every MBConv stage with k x k depthwise convs
         if ccf:   # [reduce conv] + [block]*layers, block at out width (mnasnet.py:150-153,157-166)
             prog.append(("conv", add(ConvSpec(f + ".sequence.0", cin, cout, 3, stride, 1, 1))))
-            blk = [add(s) for s in _block_specs(f + ".sequence.1", cout, t, k)]
+            blk = [add(s) for s in _block_specs(f + ".sequence.1", cout, t, k, se_ratio)]
             for li in range(layers):
                 if li > 0:
                     for j, s in enumerate(blk):
-                        s.aliases.append("%s.sequence.%d.sequence.%d" % (f, 1 + li, j))
+                        s.aliases.append("%s.sequence.%d.se" % (f, 1 + li) if s.kind == "se" else
+                                         "%s.sequence.%d.sequence.%d" % (f, 1 + li, j))
                 prog.append(("block", blk))
         else:     # reversed: [block]*layers at in width, then the 3x3 conv (mnasnet.py:167-168)
-            blk = [add(s) for s in _block_specs(f + ".sequence.0", cin, t, k)]
+            blk = [add(s) for s in _block_specs(f + ".sequence.0", cin, t, k, se_ratio)]
             for li in range(layers):
                 if li > 0:
                     for j, s in enumerate(blk):
-                        s.aliases.append("%s.sequence.%d.sequence.%d" % (f, li, j))
+                        s.aliases.append("%s.sequence.%d.se" % (f, li) if s.kind == "se" else
+                                         "%s.sequence.%d.sequence.%d" % (f, li, j))
                 prog.append(("block", blk))
             prog.append(("conv", add(ConvSpec("%s.sequence.%d" % (f, layers), cin, cout, 3, stride, 1, 1))))
     return prog, uniq
@@ -177,23 +209,31 @@ def build_program(ccf: bool):
 
 _SUFFIXES = ("conv.weight", "conv.bias", "bn.weight", "bn.bias", "bn.running_mean", "bn.running_var",
              "bn.num_batches_tracked")
+_SE_SUFFIXES = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
 
 
-def state_keys(ccf: bool) -> List[str]:
-    """All state_dict keys in the reference's order (399 of them)."""
-    _, uniq = build_program(ccf)
+def state_keys(ccf: bool, kernel: Optional[int] = None, se_ratio: float = 0.0) -> List[str]:
+    """All state_dict keys in the reference's order (399 of them); with se_ratio > 0 the SE variant's extra
+    ``...se.fc{1,2}.{weight,bias}`` keys follow (their position is not part of any contract)."""
+    _, uniq = build_program(ccf, kernel, se_ratio)
     entries = []
+    se_entries = []
     for s in uniq:
         for a in s.aliases:
-            entries.append((a, s))
+            if s.kind == "se":
+                se_entries.append(a)
+            else:
+                entries.append((a, s))
     # reference order = module registration order = lexicographic by numeric path components
     def sort_key(e):
         return [int(p) if p.isdigit() else -1 for p in e[0].split(".")]
     entries.sort(key=sort_key)
-    return ["%s.%s" % (a, suf) for a, _ in entries for suf in _SUFFIXES]
+    return ["%s.%s" % (a, suf) for a, _ in entries for suf in _SUFFIXES] + \
+        ["%s.%s" % (a, suf) for a in se_entries for suf in _SE_SUFFIXES]
 
 
-def init_state(ccf: bool, seed: int = 0, dtype=torch.float32, proj_gamma: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+def init_state(ccf: bool, seed: int = 0, dtype=torch.float32, proj_gamma: float = 1.0, kernel: Optional[int] = None,
+               se_ratio: float = 0.0) -> "OrderedDict[str, torch.Tensor]":
     """Deterministic state dict with every alias key present and aliases sharing storage.
 
     proj_gamma scales the BatchNorm weight of every MBConv_block's projection conv (``...sequence.2.bn.weight``).
@@ -201,9 +241,17 @@ def init_state(ccf: bool, seed: int = 0, dtype=torch.float32, proj_gamma: float 
     every block's un-damped ReLU(BN(.)) residual branch adds gain), which makes ANY reduced-precision
     implementation look 40 % off at the output; 0.1 gives a well-conditioned network (gain ~5) on which
     whole-network parity against the fp32 reference is meaningful."""
-    _, uniq = build_program(ccf)
+    _, uniq = build_program(ccf, kernel, se_ratio)
     by_alias = {}
     for s in uniq:
+        if s.kind == "se":
+            vals = {"fc1.weight": det_param(s.prefix + ".fc1.weight", (s.reduced, s.channels), seed),
+                    "fc1.bias": det_param(s.prefix + ".fc1.bias", (s.reduced,), seed),
+                    "fc2.weight": det_param(s.prefix + ".fc2.weight", (s.channels, s.reduced), seed),
+                    "fc2.bias": det_param(s.prefix + ".fc2.bias", (s.channels,), seed)}
+            for a in s.aliases:
+                by_alias[a] = vals
+            continue
         vals = {
             "conv.weight": det_param(s.prefix + ".conv.weight", s.weight_shape(), seed),
             "conv.bias": det_param(s.prefix + ".conv.bias", (s.cout,), seed),
@@ -217,7 +265,7 @@ def init_state(ccf: bool, seed: int = 0, dtype=torch.float32, proj_gamma: float 
         for a in s.aliases:
             by_alias[a] = vals
     out = OrderedDict()
-    for k in state_keys(ccf):
+    for k in state_keys(ccf, kernel, se_ratio):
         a, suf = k.rsplit(".", 2)[0], ".".join(k.rsplit(".", 2)[1:])
         out[k] = by_alias[a][suf]
     return out
@@ -241,15 +289,18 @@ def convblock(x, st, spec: ConvSpec, train: bool):
 def mbconv_block(x, st, specs, train: bool):
     """input + sequence(input)  -- mnasnet.py:131-137 (ReLU after the projection too)."""
     h = x
-    for s in specs:
+    for j, s in enumerate(specs[:3]):
+        if j == 2 and len(specs) == 4:
+            h = se_apply(h, st, specs[3])         # SE variant (build-defined): between depthwise and projection
         h = convblock(h, st, s, train)
     return x + h
 
 
-def features_forward(x, st, ccf: bool, train: bool, taps: Optional[dict] = None):
+def features_forward(x, st, ccf: bool, train: bool, taps: Optional[dict] = None, kernel: Optional[int] = None,
+                     se_ratio: float = 0.0):
     """Mnasnet.features(x)  -- mnasnet.py:211-213.  ``taps`` (optional dict) receives the output of
     every program step, keyed by step index, for layer-by-layer debugging."""
-    prog, _ = build_program(ccf)
+    prog, _ = build_program(ccf, kernel, se_ratio)
     h = x
     for i, (op, arg) in enumerate(prog):
         h = convblock(h, st, arg, train) if op == "conv" else mbconv_block(h, st, arg, train)
@@ -333,10 +384,11 @@ class OracleNet(torch.nn.Module):
     """nn.Module wrapper so torch.optim can drive the functional oracle (FineTuneModelPool over
     Mnasnet(ccf) -- what train.py:194-207 builds)."""
 
-    def __init__(self, ccf=False, head: Optional[str] = "512", num_classes=1000, seed=0):
+    def __init__(self, ccf=False, head: Optional[str] = "512", num_classes=1000, seed=0, kernel=None, se_ratio=0.0):
         super().__init__()
         self.ccf, self.head, self.num_classes = ccf, head, num_classes
-        st = init_state(ccf, seed)
+        self.kernel, self.se_ratio = kernel, se_ratio
+        st = init_state(ccf, seed, kernel=kernel, se_ratio=se_ratio)
         self._keys = list(st.keys())
         self._names = {}
         seen = {}
@@ -365,7 +417,7 @@ class OracleNet(torch.nn.Module):
         return {k: getattr(self, n) for k, n in self._hnames.items()}
 
     def features(self, x, taps=None):
-        return features_forward(x, self.state(), self.ccf, self.training, taps)
+        return features_forward(x, self.state(), self.ccf, self.training, taps, self.kernel, self.se_ratio)
 
     def forward(self, x, dropout=True):
         f = self.features(x)

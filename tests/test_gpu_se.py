@@ -1,0 +1,145 @@
+"""-m gpu: BASELINE config 4's SE variant (5x5 depthwise + squeeze-excite) on the HIP engine.  The reference has no SE block;
+the oracle is the build's own restatement (oracle.se_apply / bf16_mirror.se_fwd, se_bwd): "parity unpinned by the reference".
+Kernels through the C ABI against fp32 CPU math (bf16 outputs <= 6e-3 of max |ref|, fp32 reductions <= 2e-3); a stage and the
+whole variant network against the bf16 mirror with the tolerances of test_gpu_model.py."""
+import ctypes as C_
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+from cases import O
+from gpu_util import L, act_in, bf16r, from_nhwc, nhwc, relerr
+from oracle import bf16_mirror as M
+
+pytestmark = pytest.mark.gpu
+
+
+def rl2(a, b):
+    a, b = torch.as_tensor(np.asarray(a)).double().flatten(), torch.as_tensor(np.asarray(b)).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("shape", [(3, 14, 14, 48), (2, 7, 7, 1152), (5, 28, 28, 240), (2, 5, 9, 72)])
+@pytest.mark.parametrize("virt", [True, False])
+def test_se_kernels(shape, virt):
+    N, H, W, Cc = shape
+    lib = L.load()
+    HW = H * W
+    y = bf16r(O.det_uniform((N, Cc, H, W), 800))
+    s, t = 1 + 0.3 * O.det_uniform((Cc,), 801), 0.2 * O.det_uniform((Cc,), 802)
+    a = torch.relu(y * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)) if virt else y
+    u = 2.0 * O.det_uniform((N, Cc), 803)
+    sg = torch.sigmoid(u)
+    gs = bf16r(O.det_uniform((N, Cc, H, W), 804))
+    dz = O.det_uniform((N, Cc), 805)
+    yd, ud, gsd, dzd, sd, td = nhwc(y), u.cuda(), nhwc(gs), dz.cuda(), s.cuda(), t.cuda()     # keep every device tensor alive
+    ai = act_in(yd, sd, td) if virt else act_in(yd)
+    out = torch.full((N, H, W, Cc), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.mnas_se_scale(C_.byref(ai), ud.data_ptr(), N, HW, Cc, out.data_ptr(), L.cur_stream()), "se_scale")
+    assert relerr(from_nhwc(out), a * sg[:, :, None, None]) < 6e-3
+    du = torch.full((N, Cc), float("nan"), device="cuda")
+    L.check(lib.mnas_se_bwd_reduce(gsd.data_ptr(), C_.byref(ai), ud.data_ptr(), N, HW, Cc, du.data_ptr(), L.cur_stream()), "se_bwd_reduce")
+    assert relerr(du.cpu(), (gs * a).sum((2, 3)) * sg * (1 - sg)) < 2e-3
+    ga = torch.full((N, H, W, Cc), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.mnas_se_bwd_apply(gsd.data_ptr(), ud.data_ptr(), dzd.data_ptr(), N, HW, Cc, ga.data_ptr(), L.cur_stream()), "se_bwd_apply")
+    assert relerr(from_nhwc(ga), gs * sg[:, :, None, None] + dz[:, :, None, None] / HW) < 6e-3
+
+
+SE_STAGES = {
+    # (cin, cout, t, layers, k, reduce, ccf, N, H, W): shared SE block applied `layers` times, then the dense 3x3
+    "se_features2_16_24": (16, 24, 3, 3, 5, True, False, 4, 56, 56),
+    "se_features6_96_192": (96, 192, 6, 2, 5, True, False, 8, 14, 14),
+    "se_features7_192_320": (192, 320, 6, 1, 5, False, False, 16, 7, 7),
+}
+
+
+def _se_stage(name, pg=0.1):
+    from mnasnet_pytorch_amd import MBConv
+    cin, cout, t, layers, k, reduce, ccf, N, H, W = SE_STAGES[name]
+    m = MBConv(cin, cout, t, layers, kernel_size=k, reduce=reduce, cut_channels_first=ccf, se_ratio=0.25)
+    blk = O._block_specs("sequence.0", cin, t, k, 0.25)
+    conv = O.ConvSpec("sequence.%d" % layers, cin, cout, 3, 2 if reduce else 1, 1, 1)
+    st = {}
+    for s_ in [conv] + blk[:3]:
+        for suf, shp in (("conv.weight", s_.weight_shape()), ("conv.bias", (s_.cout,)), ("bn.weight", (s_.cout,)),
+                         ("bn.bias", (s_.cout,)), ("bn.running_mean", (s_.cout,)), ("bn.running_var", (s_.cout,))):
+            st[s_.prefix + "." + suf] = O.det_param("%s.%s.%s" % (name, s_.prefix, suf), shp, C.STATE_SEED)
+        st[s_.prefix + ".bn.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    st[blk[2].prefix + ".bn.weight"] = st[blk[2].prefix + ".bn.weight"] * pg
+    se = blk[3]
+    for suf, shp, gain in (("fc1.weight", (se.reduced, se.channels), 4.0), ("fc1.bias", (se.reduced,), 1.0),
+                           ("fc2.weight", (se.channels, se.reduced), 4.0), ("fc2.bias", (se.channels,), 1.0)):
+        st[se.prefix + "." + suf] = O.det_param("%s.%s.%s" % (name, se.prefix, suf), shp, C.STATE_SEED) * gain
+    sd = m.state_dict()
+    new = {}
+    for kk in sd:
+        parts = kk.split(".")
+        if parts[0] == "sequence" and int(parts[1]) < layers:       # aliases of the shared block
+            key = "sequence.0." + ".".join(parts[2:])
+        else:
+            key = kk
+        new[kk] = st[key].clone() if st[key].dim() else st[key].clone()
+    m.load_state_dict(new)
+    prog = [("block", blk)] * layers + [("conv", conv)]
+    return m.cuda().train(), prog, st, (N, cin, H, W)
+
+
+@pytest.mark.parametrize("name", sorted(SE_STAGES))
+def test_se_stage_vs_mirror(name):
+    m, prog, st, shp = _se_stage(name)
+    x0 = C.det_input(shp)
+    x = x0.cuda().requires_grad_(True)
+    y = m(x)
+    cot = C.cotangent(tuple(y.shape))
+    (y * cot.cuda()).sum().backward()
+    r = M.run(prog, st, x0, True, cot, need_dx=True)
+    ey, edx = rl2(y.detach().cpu(), r["y"]), rl2(x.grad.cpu(), r["dx"])
+    worst = 0.0
+    layers = SE_STAGES[name][3]
+    for kk, p in m.named_parameters():
+        if kk.endswith("conv.bias"):
+            continue
+        e = rl2(p.grad.cpu(), r["grads"][kk])
+        worst = max(worst, e)
+        assert e < (0.1 if kk.endswith("bn.weight") else 5e-2), (kk, e)
+    print(name, "SE stage vs mirror: y %.4f dx %.4f worst grad %.4f" % (ey, edx, worst))
+    assert ey < 1e-2 and edx < 5e-2
+    assert int(m.state_dict()["sequence.0.sequence.1.bn.num_batches_tracked"]) == layers
+
+
+def test_se_variant_network_step_vs_oracle():
+    """The whole config-4 variant (every MBConv stage 5x5 + SE, head '512'): eval logits vs the fp32 oracle <= 6e-2, then three
+    Trainer steps on a fixed batch: finite, decreasing, first loss within 3 % of the oracle's."""
+    import contextlib, io
+    from mnasnet_pytorch_amd import FineTuneModelPool, Mnasnet
+    from mnasnet_pytorch_amd.train_step import Trainer
+    base = Mnasnet(False, kernel_size=5, se_ratio=0.25)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = FineTuneModelPool(base, "mnasnet", 10, "512")
+    st = {**O.init_state(False, C.STATE_SEED, proj_gamma=0.1, kernel=5, se_ratio=0.25), **O.init_head_state("512", 10, C.STATE_SEED)}
+    m.load_state_dict(st)
+    m = m.cuda()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    net = O.OracleNet(ccf=False, head="512", num_classes=10, seed=C.STATE_SEED, kernel=5, se_ratio=0.25)
+    with torch.no_grad():
+        for k, v in st.items():
+            name = k.replace(".", "_")
+            if hasattr(net, name):
+                getattr(net, name).copy_(v)
+    x = C.det_input((8, 3, 64, 64))
+    t = torch.tensor([1, 3, 5, 7, 0, 2, 4, 6])
+    m.eval(); net.eval()
+    with torch.no_grad():
+        assert rl2(m(x.cuda()).cpu(), net(x, dropout=False)) < 6e-2
+    m.train(); net.train()
+    ref = float(torch.nn.CrossEntropyLoss()(net(x, dropout=False), t))
+    tr = Trainer(m, lr=1e-3)
+    losses = [float(tr.step(x.cuda(), t.cuda())) for _ in range(3)]
+    print("SE variant: losses", losses, "oracle first loss", ref)
+    assert np.isfinite(losses).all() and losses[2] < losses[0]
+    assert abs(losses[0] - ref) <= 3e-2 * abs(ref)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
