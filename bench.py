@@ -46,6 +46,9 @@ def parse():
                                                      "(the SE block of that config has no counterpart in the reference: not built)")
     ap.add_argument("--se", action="store_true", help="BASELINE config 4 in full: 5x5 depthwise convs AND a squeeze-excite block "
                                                      "(se_ratio 0.25, build-defined: the reference has none) in every MBConv_block")
+    ap.add_argument("--h2d", action="store_true", help="also report the PCIe-INCLUSIVE step rate (never `value`): pinned host batches, "
+                                                      "double-buffered upload on a copy stream under the previous step, as fp32 "
+                                                      "(what train.py:427 uploads) and as uint8 with the normalisation fused into the stem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -211,6 +214,57 @@ def cpu_baseline(seconds, kernel=None, se_ratio=0.0):
             "host_cpus": os.cpu_count(), "kind": "port",
             "sample": "%d train steps of bs=%d fp32 (same model/head/optimizer, oracle/mnasnet_oracle.py) in %.1f s"
                       % (n, bs, el)}
+
+
+def h2d_mode(trainer, model, x_dev, target, steps, dev):
+    """Step rate with the batch coming from the host every step (the reference hands a host tensor to the step: train.py:427
+    ``input.float().to(device)``).  Two pinned host buffers and two device buffers; the upload of batch i+1 runs on a copy
+    stream under step i.  Reported next to, never as, the resident-input `value`."""
+    out = {}
+    main = torch.cuda.current_stream(dev)
+    copy = torch.cuda.Stream(device=dev)
+    for kind in ("f32", "u8"):
+        if kind == "u8":
+            model.normalize_on_device()          # uint8 images: normalisation fused into the stem conv's load
+            host = [torch.randint(0, 256, tuple(x_dev.shape), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        else:
+            host = [torch.randn(tuple(x_dev.shape)).pin_memory() for _ in range(2)]
+        devb = [torch.empty(tuple(x_dev.shape), dtype=host[0].dtype, device=dev) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
+
+        def upload(i):
+            with torch.cuda.stream(copy):
+                copy.wait_event(done[i % 2])                     # the step that read this buffer has finished
+                devb[i % 2].copy_(host[i % 2], non_blocking=True)
+                ready[i % 2].record(copy)
+        for e in done:
+            e.record(main)
+        for it in range(3):                                      # warm-up (program build for the uint8 stem, allocator)
+            upload(it)
+            main.wait_event(ready[it % 2])
+            trainer.step(devb[it % 2], target)
+            done[it % 2].record(main)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        upload(0)
+        for it in range(steps):
+            if it + 1 < steps:
+                upload(it + 1)
+            main.wait_event(ready[it % 2])
+            trainer.step(devb[it % 2], target)
+            done[it % 2].record(main)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        mb = host[0].numel() * host[0].element_size() / 1e6
+        out[kind] = {"ms_per_step": round(dt / steps * 1e3, 3), "images_per_sec": round(x_dev.shape[0] * steps / dt, 1),
+                     "host_batch_MB": round(mb, 1)}
+        if kind == "u8":
+            model.normalize_on_device(False)
+    out["note"] = ("pinned host batch uploaded every step, double-buffered on a copy stream under the previous step; f32 = the "
+                   "reference's input.float().to(device) (train.py:427), u8 = raw uint8 images with Normalize(mean, std) fused "
+                   "into the stem conv's load (FineTuneModelPool.normalize_on_device)")
+    return out
 
 
 def main():
@@ -397,6 +451,8 @@ def main():
             for key, ints, msv, nb_ in calib["detail"]:
                 sys.stderr.write("%-18s %-48s %8.1f us %8.1f GB/s\n" % (key, ",".join(map(str, ints)), msv * 1e3,
                                                                       nb_ / max(msv, 1e-9) / 1e6))
+    if args.h2d and world == 1:
+        res["pcie_inclusive"] = h2d_mode(trainer, model, x, target, args.steps, dev)
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 5 if (args.k5 or args.se) else None, 0.25 if args.se else 0.0)
     print(json.dumps(res))

@@ -317,6 +317,12 @@ typedef struct MnasStemFwd {
     const float* bias;
     void*  out;              /* bf16 (N,Ho,Wo,Co) */
     float* stats;            /* float[2][Co][nparts] */
+    /* optional fused input pipeline (the normalisation the reference's dataset applies on the CPU: datasets.py:474-516
+     * transforms.Normalize with the mean / std of classifiers.py:91-92): the conv reads in_affine[0][c] * x + in_affine[1][c];
+     * in_u8 != 0: x is a uint8 NCHW image (a quarter of the PCIe / HBM bytes).  Band-kernel shapes only (Co == 32,
+     * W % 4 == 0), otherwise MNAS_EINVAL. */
+    const float* in_affine;  /* float[2][3] (scale, shift per input plane) or NULL */
+    int32_t in_u8, reserved;
 } MnasStemFwd;
 int mnas_stem_fwd(const MnasStemFwd* a, void* stream);
 typedef struct MnasStemWgrad {
@@ -325,6 +331,8 @@ typedef struct MnasStemWgrad {
     const float* x;
     MnasGradIn dy;
     float* partial;          /* float[nparts][Co][27], fully overwritten */
+    const float* in_affine;  /* as in MnasStemFwd: the weight gradient must see the same transformed input */
+    int32_t in_u8, reserved;
 } MnasStemWgrad;
 int mnas_stem_wgrad(const MnasStemWgrad* a, void* stream);
 /* Preferred nparts (persistent workgroups) for the stem launches: which = 0 forward, 1 weight gradient; -1 = caller's choice

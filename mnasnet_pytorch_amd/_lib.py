@@ -85,12 +85,13 @@ class MnasPackDesc(C.Structure):
 class MnasStemFwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("Co", C.c_int32), ("nparts", C.c_int32), ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p),
-                ("out", c_void_p), ("stats", c_void_p)]
+                ("out", c_void_p), ("stats", c_void_p), ("in_affine", c_void_p), ("in_u8", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasStemWgrad(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
-                ("Co", C.c_int32), ("nparts", C.c_int32), ("x", c_void_p), ("dy", MnasGradIn), ("partial", c_void_p)]
+                ("Co", C.c_int32), ("nparts", C.c_int32), ("x", c_void_p), ("dy", MnasGradIn), ("partial", c_void_p),
+                ("in_affine", c_void_p), ("in_u8", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasIrbFwd(C.Structure):

@@ -49,8 +49,8 @@ class FineTuneModelPool(nn.Module):
         self.native_head = True      # classifier on csrc/mnas_head.hip when it is a Dropout/Linear/ReLU chain
         self._head = None
         self._head_key = None
-        self.mean = (0.485, 0.456, 0.406)
-        self.std = (0.229, 0.224, 0.225)
+        self.mean = (0.485, 0.456, 0.406)             # classifiers.py:91-92 (the reference stores them and never uses them:
+        self.std = (0.229, 0.224, 0.225)              # its datasets normalise on the CPU)
 
     # The NativeHead cache holds the ctypes library handle: it is process-local state, not model state.  Keep it out of
     # pickles / deep copies (torch.save(model), copy.deepcopy(model) for EMA or best-model copies); it is rebuilt lazily.
@@ -58,6 +58,17 @@ class FineTuneModelPool(nn.Module):
         st = self.__dict__.copy()
         st["_head"], st["_head_key"] = None, None
         return st
+
+    def normalize_on_device(self, enable=True):
+        """Move the dataset's ``transforms.Normalize(self.mean, self.std)`` (datasets.py:474-516) into the stem conv's input load:
+        after this the model takes UN-normalised images -- float in [0, 1] or raw uint8 (then the batch crosses PCIe at a quarter
+        of the bytes of train.py:427's fp32 upload).  Off by default: the reference's loaders hand over normalised floats."""
+        eng = self.features._engine()
+        if enable:
+            eng.set_input_normalization(self.mean, self.std)
+        else:
+            eng.set_input_normalization(None, None)
+        return self
 
     def freeze(self):
         print("Features frozen")

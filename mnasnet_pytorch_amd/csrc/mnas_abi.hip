@@ -57,8 +57,8 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  DW_FWD           i: N,H,W,C,k,nparts      p: in.data,in.scale,in.shift, w,bias,out,stats
 //  DW_BWD           i: N,H,W,C,k,nparts,phase p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial, red_bn,red_partial
 //  DW_WGRAD_FINALIZE i: nparts,C,k,accumulate p: wpartial,grad
-//  STEM_FWD         i: N,H,W,Ho,Wo,Co,nparts p: x,w,bias,out,stats
-//  STEM_WGRAD       i: N,H,W,Ho,Wo,Co,nparts p: x, dy.g,dy.y,dy.coef, partial
+//  STEM_FWD         i: N,H,W,Ho,Wo,Co,nparts,in_u8 p: x,w,bias,out,stats,in_affine
+//  STEM_WGRAD       i: N,H,W,Ho,Wo,Co,nparts,in_u8 p: x, dy.g,dy.y,dy.coef, partial,in_affine
 //  BN_FWD_FINALIZE  i: nparts,C,training  d: count,momentum,eps   p: partial,gamma,beta,rmean,rvar,nbt,bnbuf
 //  BN_BWD_REDUCE    i: C,nparts           d: rows                 p: g,y,bnbuf,partial
 //  BN_BWD_FINALIZE  i: nparts,C,accumulate d: count               p: partial,bnbuf,dgamma,dbeta
@@ -165,6 +165,7 @@ static int run_one(const MnasOp& o, void* stream) {
             MnasStemFwd a = {};
             a.N = i[0]; a.H = i[1]; a.W = i[2]; a.Ho = i[3]; a.Wo = i[4]; a.Co = i[5]; a.nparts = i[6];
             a.x = (const float*)p[0]; a.w = p[1]; a.bias = (const float*)p[2]; a.out = p[3]; a.stats = (float*)p[4];
+            a.in_affine = (const float*)p[5]; a.in_u8 = i[7];
             return mnas_stem_fwd(&a, stream);
         }
         case MNAS_OP_STEM_WGRAD: {
@@ -173,6 +174,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.x = (const float*)p[0];
             a.dy.g = p[1]; a.dy.y = p[2]; a.dy.coef = (const float*)p[3];
             a.partial = (float*)p[4];
+            a.in_affine = (const float*)p[5]; a.in_u8 = i[7];
             return mnas_stem_wgrad(&a, stream);
         }
         case MNAS_OP_BN_FWD_FINALIZE:

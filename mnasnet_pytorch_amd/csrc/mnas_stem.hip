@@ -32,6 +32,8 @@ struct StemArgs {
     MnasGradIn dy;           // wgrad
     float* partial;          // wgrad: [gridDim.x][32][27]
     int nt;
+    const float* in_affine;  // [2][3] or NULL: x -> scale[c] * x + shift[c] (fused input normalisation)
+    int in_u8;               // x is uint8 NCHW
 };
 
 // input rows 2*oy0-1 .. 2*oy0+2*RB-1 of the three planes of image n -> tile[(c*R + r)*LW + iw + 2] (bf16)
@@ -44,7 +46,18 @@ __device__ __forceinline__ void stem_stage_input(const StemArgs& a, uint16_t* ti
         const int ih = 2 * oy0 - 1 + r;
         uint2 pk = make_uint2(0, 0);
         if (ih >= 0 && ih < a.H) {
-            const float4 v = *(const float4*)(a.x + (((size_t)n * 3 + c) * a.H + ih) * a.W + 4 * q);
+            const size_t e = (((size_t)n * 3 + c) * a.H + ih) * a.W + 4 * q;
+            float4 v;
+            if (a.in_u8) {
+                const uint32_t u = *(const uint32_t*)((const uint8_t*)a.x + e);
+                v = make_float4((float)(u & 0xffu), (float)((u >> 8) & 0xffu), (float)((u >> 16) & 0xffu), (float)(u >> 24));
+            } else {
+                v = *(const float4*)(a.x + e);
+            }
+            if (a.in_affine) {                                      // zero padding stays zero: it pads the NORMALISED image
+                const float sc = a.in_affine[c], sh = a.in_affine[3 + c];
+                v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+            }
             pk.x = pack_bf16(v.x, v.y);
             pk.y = pack_bf16(v.z, v.w);
         }
@@ -316,6 +329,7 @@ int mnas_stem_fwd_band(const MnasStemFwd* c, void* stream) {
     a.nbh = (c->Ho + a.RB - 1) / a.RB;
     a.LW = (c->W + 4 + 1) & ~1;
     a.x = c->x; a.w = (const uint16_t*)c->w; a.bias = c->bias; a.out = c->out; a.stats = c->stats;
+    a.in_affine = c->in_affine; a.in_u8 = c->in_u8;
     a.nt = (mnas_nt_mask() & MNAS_NT_STEM) ? 1 : 0;
     hipLaunchKernelGGL(k_stem_fwd, dim3(c->nparts), dim3(256), lds, (hipStream_t)stream, a);
     MNAS_CHECK_LAUNCH();
@@ -334,6 +348,7 @@ int mnas_stem_wgrad_band(const MnasStemWgrad* c, void* stream) {
     a.nbh = (c->Ho + a.RB - 1) / a.RB;
     a.LW = (c->W + 4 + 1) & ~1;
     a.x = c->x; a.dy = c->dy; a.partial = c->partial;
+    a.in_affine = c->in_affine; a.in_u8 = c->in_u8;
     hipLaunchKernelGGL(k_stem_wgrad, dim3(c->nparts), dim3(256), lds, (hipStream_t)stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;

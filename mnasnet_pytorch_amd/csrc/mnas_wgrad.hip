@@ -270,6 +270,7 @@ extern "C" int mnas_stem_wgrad(const MnasStemWgrad* c, void* stream) {
         const int rc = mnas_stem_wgrad_band(c, stream);
         if (rc != MNAS_EINVAL) return rc;
     }
+    if (c->in_affine || c->in_u8) return MNAS_EINVAL;               // the fused input pipeline exists in the band kernels only
     WgradArgs a;
     a.M = c->N * c->Ho * c->Wo;
     a.Hi = c->H; a.Wi = c->W; a.Ci = 27; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co;

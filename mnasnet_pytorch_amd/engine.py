@@ -174,9 +174,15 @@ class _OpList:
 class Program:
     """All buffers + launch lists for one (N, H, W, training, need_dx) configuration."""
 
-    def __init__(self, eng: "Engine", N, H, W, training, need_dx, pooled=False):
+    def __init__(self, eng: "Engine", N, H, W, training, need_dx, pooled=False, in_u8=False):
         self.eng, self.N, self.H, self.W, self.training, self.need_dx = eng, N, H, W, training, need_dx
         self.pooled = pooled
+        self.in_u8 = bool(in_u8)
+        # fused input pipeline of the stem (Engine.set_input_normalization): per-plane affine, uint8 images
+        aff = eng.input_affine(self.in_u8)
+        aff_ptr = aff.data_ptr() if aff is not None else None
+        if self.in_u8 and aff is None:
+            raise RuntimeError("uint8 images need Engine.set_input_normalization(mean, std)")
         self.busy = False
         dev = eng.device
         self.keep = []                      # tensors owned by this program
@@ -247,8 +253,8 @@ class Program:
             if ci.kind == "stem":
                 sp = lib.mnas_stem_parts(0, N, Hi, Wi, ci.cout)
                 nparts = sp if sp > 0 else nparts
-                j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts], [],
-                            [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
+                j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts, 1 if self.in_u8 else 0], [],
+                            [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats, aff_ptr])
                 self.patch_x.append((j, 0))
             elif ci.kind == "dw":
                 nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 2)))
@@ -531,7 +537,8 @@ class Program:
                 nsp = min(sp if sp > 0 else nsp, _STEM_WGRAD_PARTS_MAX)
                 if nsp * Co * 27 > eng.scratch_wgrad.numel():
                     raise RuntimeError("stem weight-gradient scratch too small (%d splits)" % nsp)
-                jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp], [], [None] + gy + [eng.scratch_wgrad.data_ptr()], WS)
+                jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp, 1 if self.in_u8 else 0], [],
+                             [None] + gy + [eng.scratch_wgrad.data_ptr(), aff_ptr], WS)
                 self.patch_x_bwd = (ops, jx, 0)
                 ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
             elif ci.kind == "dw":
@@ -836,7 +843,7 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, eng, track, pooled, x, *params):
         need_dx = track and x.requires_grad
         training = eng.root.training
-        prog = eng.program(x.shape[0], x.shape[2], x.shape[3], training, need_dx, pooled)
+        prog = eng.program(x.shape[0], x.shape[2], x.shape[3], training, need_dx, pooled, x.dtype == torch.uint8)
         out = prog.run_forward(x)
         ctx.eng = eng
         ctx.lease = _Lease(prog) if (training and track) else None
@@ -953,6 +960,7 @@ class Engine:
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
         self.pw_bwd_parts_small = 85     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)
         self.side_stream = None
+        self._in_norm, self._in_aff = None, {}
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_filter = None       # optional predicate (opcode, ints) -> bool narrowing the bracketed launches
         self.profile_events = []         # [(tag, start_handle, stop_handle)]
@@ -1117,8 +1125,38 @@ class Engine:
     def gptr(self, ci: _ConvInfo, j: int):
         return self.flat_grad.data_ptr() + 4 * ci.gslice[j][0]
 
-    def program(self, N, H, W, training, need_dx, pooled=False) -> Program:
-        key = (N, H, W, training, need_dx, pooled)
+    def set_input_normalization(self, mean=None, std=None):
+        """Fuse the dataset's ``transforms.Normalize(mean, std)`` (datasets.py:474-516 with the constants of classifiers.py:91-92)
+        into the stem conv's input load: float images are read as (x - mean) / std, uint8 images as (x / 255 - mean) / std
+        (a quarter of the PCIe / HBM bytes of the fp32 batch train.py:427 uploads).  None, None removes the transform."""
+        if not self.starts_with_stem:
+            raise RuntimeError("input normalisation is fused into the stem conv: this engine does not start with one")
+        if mean is None or std is None:
+            self._in_norm = None
+        else:
+            m = torch.as_tensor(mean, dtype=torch.float64).flatten()
+            s = torch.as_tensor(std, dtype=torch.float64).flatten()
+            if m.numel() != 3 or s.numel() != 3 or bool((s <= 0).any()):
+                raise ValueError("mean / std must have 3 entries, std > 0")
+            self._in_norm = (m, s)
+        self._in_aff = {}
+        if self.programs:
+            self.reset_programs()
+
+    def input_affine(self, u8: bool):
+        """device float[2][3] (scale, shift) of the stem's fused input transform for float / uint8 images, or None"""
+        if getattr(self, "_in_norm", None) is None:
+            return None
+        t = self._in_aff.get((u8, self.device))
+        if t is None:
+            m, s = self._in_norm
+            k = 255.0 if u8 else 1.0
+            t = torch.stack([1.0 / (k * s), -m / s]).to(torch.float32).to(self.device).contiguous()
+            self._in_aff[(u8, self.device)] = t
+        return t
+
+    def program(self, N, H, W, training, need_dx, pooled=False, in_u8=False) -> Program:
+        key = (N, H, W, training, need_dx, pooled, bool(in_u8))
         lst = self.programs.setdefault(key, [])
         for p in lst:
             if not p.busy:
@@ -1128,7 +1166,7 @@ class Engine:
                 "%d forwards of shape %s are alive at once (their autograd graphs are still referenced and no backward "
                 "has run): each holds a full set of activation buffers.  Drop the old outputs / call backward, or run "
                 "under torch.no_grad()." % (len(lst), (N, self.in_channels_hint, H, W)))
-        p = Program(self, N, H, W, training, need_dx, pooled)
+        p = Program(self, N, H, W, training, need_dx, pooled, in_u8)
         lst.append(p)
         return p
 
@@ -1187,7 +1225,10 @@ class Engine:
             # images do not require grad): fail loudly instead of returning a missing gradient
             raise NotImplementedError("gradient w.r.t. the input image is not implemented by the HIP engine (the stem's "
                                       "dgrad is skipped); pass the image with requires_grad=False")
-        x = x.float().contiguous()          # train.py:427 input.float()
+        if x.dtype == torch.uint8 and self.starts_with_stem and getattr(self, "_in_norm", None) is not None:
+            x = x.contiguous()              # uint8 images stay uint8: the stem converts and normalises on load
+        else:
+            x = x.float().contiguous()      # train.py:427 input.float()
         self.ensure_setup(x.device)
         self._check_modes()
         return _EngineFn.apply(self, track, bool(pooled), x, *self.params)

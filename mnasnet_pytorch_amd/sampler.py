@@ -22,7 +22,7 @@ from typing import Iterator, List, Sequence
 
 from torch.utils.data.sampler import Sampler
 
-__all__ = ["ClusterRandomSampler", "DistributedClusterSampler"]
+__all__ = ["ClusterRandomSampler", "DistributedClusterSampler", "ProgressiveResize"]
 
 
 def _full_batches(indices: Sequence[int], batch_size: int) -> List[List[int]]:
@@ -125,3 +125,31 @@ class DistributedClusterSampler(Sampler):
 
     def __len__(self) -> int:
         return sum(self._steps_per_cluster) * self.batch_size
+
+
+class ProgressiveResize:
+    """The progressive-resizing schedule of the reference's epoch loop (train.py:304-317): every ``epochs_grow_size`` epochs,
+    while the dataset's ``size_ratio`` is still below 1.0, the ratio doubles and the batch size is divided by 4 (the loaders are
+    rebuilt with the new values).  Pure host logic; the HIP engine keeps one compiled program per (batch, height, width), so a
+    size switch costs one program build and nothing else (the kernels take H, W at run time).
+
+        sched = ProgressiveResize(size_ratio=0.25, batch_size=256, epochs_grow_size=10)
+        for epoch in range(epochs):
+            ratio, bs, changed = sched.step(epoch)          # call at the top of the epoch, like train.py:306-317
+            if changed: rebuild the loaders with size_ratio=ratio, batch_size=bs
+    """
+
+    def __init__(self, size_ratio: float, batch_size: int, epochs_grow_size: int):
+        self.size_ratio, self.batch_size, self.epochs_grow_size = float(size_ratio), int(batch_size), int(epochs_grow_size)
+
+    def step(self, epoch: int):
+        changed = False
+        if self.epochs_grow_size > 0 and (epoch + 1) % self.epochs_grow_size == 0 and self.size_ratio < 1.0:
+            self.size_ratio *= 2                       # train.py:315
+            self.batch_size = int(self.batch_size // 4)  # train.py:313
+            changed = True
+        return self.size_ratio, self.batch_size, changed
+
+    def cluster_shapes(self, clusters=((384, 512), (512, 512), (512, 384))):
+        """(H, W) of every resolution cluster (datasets.py:331-335) at the current size_ratio"""
+        return [(int(h * self.size_ratio), int(w * self.size_ratio)) for h, w in clusters]

@@ -315,10 +315,11 @@ class Trainer:
             eng.check_input(x)                               # same checks as Engine.forward: the launch lists take raw pointers
             if not isinstance(target, torch.Tensor) or target.device != x.device:
                 raise RuntimeError("target must be a tensor on the input's device (%s)" % (x.device,))
-            x = x.float().contiguous()
+            u8 = x.dtype == torch.uint8 and eng._in_norm is not None
+            x = x.contiguous() if u8 else x.float().contiguous()
             eng.ensure_setup(x.device)
             eng._check_modes()
-            prog = eng.program(x.shape[0], x.shape[2], x.shape[3], True, False, True)
+            prog = eng.program(x.shape[0], x.shape[2], x.shape[3], True, False, True, u8)
             f = prog.run_forward(x)
             head.calls = self.optimizer.step_count           # dropout masks follow the CHECKPOINTED step count: a resumed run does
                                                              # not replay the masks of the first steps

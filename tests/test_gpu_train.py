@@ -340,3 +340,48 @@ def test_fused_pool_matches_two_step_path():
         m.fuse_pool = False
         b = m(x)
     assert rl2(a.cpu(), b.cpu()) < 1e-5
+
+
+def test_input_pipeline_on_device_normalisation_and_uint8():
+    """SURVEY 8(f) row 4, input half: the dataset's transforms.Normalize(mean, std) (datasets.py:474-516, constants
+    classifiers.py:91-92) fused into the stem conv's load, for float [0,1] and raw uint8 images.  Reference semantics: the model
+    sees (u8 / 255 - mean) / std.  Three routes must agree: normalised floats computed on the host (the reference's route), float
+    [0,1] images normalised on load, uint8 images normalised on load -- logits <= 2e-2 relative L2 (bf16 rounding of a value
+    computed as fma on load vs two fp32 ops on the host), stem weight gradients <= 2e-2."""
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (8, 3, 64, 64), generator=g, dtype=torch.uint8)
+    t = torch.tensor([1, 3, 5, 7, 0, 2, 4, 6]).cuda()
+    crit = torch.nn.CrossEntropyLoss()
+    outs = []
+    for route in ("host", "float", "uint8"):
+        m = build("512", 10, proj_gamma=0.1).train()
+        _no_dropout(m)
+        mean = torch.tensor(m.mean).view(1, 3, 1, 1)
+        std = torch.tensor(m.std).view(1, 3, 1, 1)
+        if route == "host":
+            x = ((u8.float() / 255.0 - mean) / std).cuda()
+        elif route == "float":
+            m.normalize_on_device()
+            x = (u8.float() / 255.0).cuda()
+        else:
+            m.normalize_on_device()
+            x = u8.cuda()
+        out = m(x)
+        loss = crit(out, t)
+        loss.backward()
+        outs.append((out.detach().cpu(), m.features[0].conv.weight.grad.cpu().clone(), float(loss)))
+    for o, gw, l in outs[1:]:
+        assert rl2(o, outs[0][0]) < 2e-2 and rl2(gw, outs[0][1]) < 2e-2, (rl2(o, outs[0][0]), rl2(gw, outs[0][1]))
+        assert abs(l - outs[0][2]) < 1e-2 * abs(outs[0][2])
+    # the autograd-free Trainer step takes uint8 batches too
+    from mnasnet_pytorch_amd.train_step import Trainer
+    m = build("512", 10, proj_gamma=0.1).train()
+    _no_dropout(m)
+    m.normalize_on_device()
+    tr = Trainer(m, lr=1e-3)
+    l0 = float(tr.step(u8.cuda(), t)); l1 = float(tr.step(u8.cuda(), t))
+    assert abs(l0 - outs[0][2]) < 1e-2 * abs(l0) and l1 < l0
+    # without the transform a uint8 batch is converted with .float() (train.py:427), nothing else
+    m2 = build("512", 10, proj_gamma=0.1).eval()
+    with torch.no_grad():
+        assert rl2(m2(u8.cuda()).cpu(), m2(u8.float().cuda()).cpu()) < 1e-6
