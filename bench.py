@@ -178,6 +178,21 @@ def pmc_traffic(kernel_class):
         return None, None
 
 
+def pmc_mfma_busy(kernel_class):
+    """Matrix-pipe busy fraction of a kernel class from the newest committed counter summary (profiles/*_mfma_per_class.json:
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), tools/pmc_sq.sh pass 3 + tools/mfma_summary.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_mfma_per_class.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d["classes"][kernel_class]["mfma_busy_frac"], "profiles/" + os.path.basename(files[-1])
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -427,8 +442,14 @@ def main():
         tot = sum(a[0] for a in calib["agg"].values())
         gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dom_key)
+        mfma_busy, mfma_src = pmc_mfma_busy(dom_key)
+        # every kernel class of this path sits left of the bf16 MFMA ridge (AI 4-165 flop/B < 312): HBM is the
+        # binding roofline; the matrix-pipe busy fraction from the SQ counters is reported next to it
         res["roofline"] = {"kernel": dom_key, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                           "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
+                           "mfma_achieved_TFLOPps": round(fl / (tms * 1e-3) / 1e12, 1) if tms > 0 else 0.0,
+                           "mfma_peak_TFLOPps": MFMA_PEAK_TFLOPS,
                            "algorithmic_bytes_per_launch": round(nb / cnt),
                            "launches_per_step": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
                            "ms_per_step": round(tms, 3),

@@ -19,6 +19,7 @@ def key(name):
     m = re.match(r"void k_dimg<(\d)", name)
     if m:
         return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"
+    if name.startswith("void k_tconv"): return "k_igemm<dgrad>"
     if name.startswith("k_stem_fwd"): return "k_igemm<stem>"
     if name.startswith("k_stem_wgrad"): return "k_wgrad<stem>"
     if name.startswith("k_dy_mat"): return "k_dy_mat"
@@ -32,6 +33,12 @@ def key(name):
         dg, wg = m.group(1) == "true", m.group(2) == "true"
         return "k_dw_bwd" if dg and wg else ("k_dw_conv<dgrad>" if dg else "k_dw_wgrad")
     if name.startswith("k_add_act"): return "k_add_act"
+    if name.startswith("void k_irb_fwd"): return "k_irb_fwd"
+    if name.startswith("void k_irb_bwd_proj"): return "k_irb_bwd_proj"
+    if name.startswith("void k_irb_bwd_dw"): return "k_irb_bwd_dw"
+    if name.startswith("void k_irb_bwd_exp"): return "k_irb_bwd_exp"
+    if name.startswith("k_gram") or name.startswith("void k_gram"): return "k_gram"
+    if name.startswith("k_se_") or name.startswith("void k_se_"): return "k_se"
     return "other"
 
 
@@ -47,15 +54,20 @@ def load(path, counter):
     return out
 
 
-f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-res, tot = {}, 0.0
-for k in sorted(set(f) | set(w)):
-    calls = f.get(k, w.get(k))[0]
-    fetch_b = 2.0 * f.get(k, [0, 0])[1] * 1024.0
-    write_b = w.get(k, [0, 0])[1] * 1024.0
-    tot += fetch_b + write_b
-    res[k] = {"launches_per_step": calls, "fetch_bytes_per_step": fetch_b, "write_bytes_per_step": write_b,
-              "hbm_bytes_per_launch": (fetch_b + write_b) / max(calls, 1.0)}
-print(json.dumps({"note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, separate --pmc passes of "
-                          "bench.py --steps 2 --warmup 2; per training step (bs 256, 1 GPU)",
-                  "total_GB_per_step": round(tot / 1e9, 2), "classes": res}, indent=1))
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    res, tot = {}, 0.0
+    for k in sorted(set(f) | set(w)):
+        calls = f.get(k, w.get(k))[0]
+        fetch_b = 2.0 * f.get(k, [0, 0])[1] * 1024.0
+        write_b = w.get(k, [0, 0])[1] * 1024.0
+        tot += fetch_b + write_b
+        res[k] = {"launches_per_step": calls, "fetch_bytes_per_step": fetch_b, "write_bytes_per_step": write_b,
+                  "hbm_bytes_per_launch": (fetch_b + write_b) / max(calls, 1.0)}
+    print(json.dumps({"note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, separate --pmc passes of "
+                              "bench.py --steps 2 --warmup 2; per training step (bs 256, 1 GPU)",
+                      "total_GB_per_step": round(tot / 1e9, 2), "classes": res}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
