@@ -438,10 +438,13 @@ int mnas_head_cross_entropy(const void* logits, const void* target, int N, int C
  * block; csrc/mnas_se.hip, restated in oracle.se_apply).  a = the activated depthwise output (act-on-load of y2), u = the
  * excite logits fp32 [N][C] (mnas_pool_act -> mnas_head_linear_fwd x2 produce them).
  *   mnas_se_scale      : out = act(a) * sigmoid(u)[n][c]            (bf16 (N,HW,C): what the project conv then reads)
- *   mnas_se_bwd_reduce : du[n][c] = (sum_hw gs * act(a)) * s (1 - s), s = sigmoid(u)   (gs = dL/d out, bf16)
+ *   mnas_se_bwd_reduce : du[n][c] = (sum_hw gs * act(a)) * s (1 - s), s = sigmoid(u)   (gs = dL/d out, bf16); scratch =
+ *                        mnas_se_scratch_bytes(N, HW, C) bytes of partial sums (pixel splits, added in a fixed order)
  *   mnas_se_bwd_apply  : out = gs * sigmoid(u) + dz[n][c] / HW      (dz = dL/d(pooled a) from the MLP backward; out = dL/d act(a)) */
 int mnas_se_scale(const MnasActIn* a, const float* u, int N, int HW, int C, void* out_bf16, void* stream);
-int mnas_se_bwd_reduce(const void* gs, const MnasActIn* a, const float* u, int N, int HW, int C, float* du, void* stream);
+int mnas_se_bwd_reduce(const void* gs, const MnasActIn* a, const float* u, int N, int HW, int C, float* du, float* scratch,
+                       void* stream);
+int64_t mnas_se_scratch_bytes(int N, int HW, int C);
 int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16, void* stream);
 
 /* ---- weight packing (fp32 reference layout [Co][Ci/g][kh][kw] -> kernel layouts) -------------------- */

@@ -14,102 +14,144 @@
 
 __device__ __forceinline__ float se_sigmoid(float u) { return 1.f / (1.f + __expf(-u)); }
 
-// one thread per 16-byte channel group of one pixel
-__global__ __launch_bounds__(256) void k_se_scale(MnasActIn a, const float* __restrict__ u, int N, int HW, int C, uint4* __restrict__ out) {
-    const int G = C >> 3;
-    const size_t total = (size_t)N * HW * G;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cg = (int)(i % G);
-        const size_t pix = i / G;
-        const int n = (int)(pix / HW);
+// Common geometry: a workgroup = (image n, pixel range); a thread keeps ONE 16-byte channel group for its whole range, so the
+// BatchNorm coefficients and sigmoid(u[n][c]) of its 8 channels are registers computed once (the naive form re-evaluated 8
+// exponentials per pixel and channel group).  R = 256 / G pixel rows are in flight per workgroup step (G = C / 8).
+struct SeGeom { int G, R, HW, C, chunk; };      // chunk = pixels per workgroup (multiple of R)
+
+__global__ __launch_bounds__(256) void k_se_scale(MnasActIn a, const float* __restrict__ u, SeGeom g, uint4* __restrict__ out) {
+    const int n = blockIdx.x, cg = threadIdx.x % g.G, pr = threadIdx.x / g.G;
+    if (pr >= g.R) return;
+    float s[8], t[8], sg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s[j] = a.scale ? a.scale[cg * 8 + j] : 1.f;
+        t[j] = a.scale ? a.shift[cg * 8 + j] : 0.f;
+        sg[j] = se_sigmoid(u[(size_t)n * g.C + cg * 8 + j]);
+    }
+    const int p0 = blockIdx.y * g.chunk, p1 = min(g.HW, p0 + g.chunk);
+    const uint4* src = (const uint4*)a.data + (size_t)n * g.HW * g.G + cg;
+    uint4* dst = out + (size_t)n * g.HW * g.G + cg;
+    for (int p = p0 + pr; p < p1; p += g.R) {
         float f[8];
-        unpack8(((const uint4*)a.data)[i], f);
-        const float* up = u + (size_t)n * C + cg * 8;
+        unpack8(src[(size_t)p * g.G], f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = f[j];
-            if (a.scale) v = fmaxf(fmaf(v, a.scale[cg * 8 + j], a.shift[cg * 8 + j]), 0.f);
-            f[j] = v * se_sigmoid(up[j]);
+            const float v = a.scale ? fmaxf(fmaf(f[j], s[j], t[j]), 0.f) : f[j];
+            f[j] = v * sg[j];
         }
-        out[i] = pack8(f);
+        dst[(size_t)p * g.G] = pack8(f);
     }
 }
 
-// one workgroup per (image, 64-channel block): thread (pg = tid >> 3 in 0..31 walks the pixels, cg = tid & 7 one channel group)
-__global__ __launch_bounds__(256) void k_se_bwd_reduce(const uint4* __restrict__ gs, MnasActIn a, const float* __restrict__ u, int HW,
-                                                       int C, float* __restrict__ du) {
-    __shared__ float red[32][65];
-    const int n = blockIdx.x, cb = blockIdx.y * 64;
-    const int cg = threadIdx.x & 7, pg = threadIdx.x >> 3;
-    const int c0 = cb + cg * 8;
-    const int G = C >> 3;
+// du partial sums: every workgroup reduces its pixel range in registers, its R rows through LDS in fixed order, and writes
+// dupart[split][n][c]; k_se_bwd_finish adds the splits in order and applies s (1 - s).  Deterministic.
+__global__ __launch_bounds__(256) void k_se_bwd_reduce(const uint4* __restrict__ gs, MnasActIn a, SeGeom g, float* __restrict__ dupart,
+                                                       int N) {
+    extern __shared__ float red[];                                  // [R][C]
+    const int n = blockIdx.x, cg = threadIdx.x % g.G, pr = threadIdx.x / g.G;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (c0 < C) {
+    if (pr < g.R) {
         float s[8], t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s[j] = a.scale ? a.scale[c0 + j] : 1.f; t[j] = a.scale ? a.shift[c0 + j] : 0.f; }
-        for (int p = pg; p < HW; p += 32) {
-            const size_t idx = ((size_t)n * HW + p) * G + (c0 >> 3);
-            float g[8], y[8];
-            unpack8(gs[idx], g);
-            unpack8(((const uint4*)a.data)[idx], y);
+        for (int j = 0; j < 8; ++j) { s[j] = a.scale ? a.scale[cg * 8 + j] : 1.f; t[j] = a.scale ? a.shift[cg * 8 + j] : 0.f; }
+        const int p0 = blockIdx.y * g.chunk, p1 = min(g.HW, p0 + g.chunk);
+        const size_t base = (size_t)n * g.HW * g.G + cg;
+        for (int p = p0 + pr; p < p1; p += g.R) {
+            float gq[8], y[8];
+            unpack8(gs[base + (size_t)p * g.G], gq);
+            unpack8(((const uint4*)a.data)[base + (size_t)p * g.G], y);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = a.scale ? fmaxf(fmaf(y[j], s[j], t[j]), 0.f) : y[j];
-                acc[j] = fmaf(g[j], v, acc[j]);
+                acc[j] = fmaf(gq[j], v, acc[j]);
             }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[pg][cg * 8 + j] = acc[j];
-    __syncthreads();
-    if (threadIdx.x < 64 && cb + threadIdx.x < C) {
-        float v = 0.f;
-        for (int r = 0; r < 32; ++r) v += red[r][threadIdx.x];         // fixed order: deterministic
-        const float sg = se_sigmoid(u[(size_t)n * C + cb + threadIdx.x]);
-        du[(size_t)n * C + cb + threadIdx.x] = v * sg * (1.f - sg);
+        for (int j = 0; j < 8; ++j) red[pr * g.C + cg * 8 + j] = acc[j];
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < g.C; c += 256) {
+        float v = 0.f;
+        for (int r = 0; r < g.R; ++r) v += red[r * g.C + c];
+        dupart[((size_t)blockIdx.y * N + n) * g.C + c] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_se_bwd_finish(const float* __restrict__ dupart, const float* __restrict__ u, int splits, int NC,
+                                                       float* __restrict__ du) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += dupart[(size_t)s * NC + i];
+    const float sg = se_sigmoid(u[i]);
+    du[i] = v * sg * (1.f - sg);
 }
 
 __global__ __launch_bounds__(256) void k_se_bwd_apply(const uint4* __restrict__ gs, const float* __restrict__ u, const float* __restrict__ dz,
-                                                      int N, int HW, int C, uint4* __restrict__ out) {
-    const int G = C >> 3;
-    const size_t total = (size_t)N * HW * G;
-    const float inv = 1.f / (float)HW;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cg = (int)(i % G);
-        const int n = (int)((i / G) / HW);
-        float g[8];
-        unpack8(gs[i], g);
-        const float* up = u + (size_t)n * C + cg * 8;
-        const float* zp = dz + (size_t)n * C + cg * 8;
+                                                      SeGeom g, uint4* __restrict__ out) {
+    const int n = blockIdx.x, cg = threadIdx.x % g.G, pr = threadIdx.x / g.G;
+    if (pr >= g.R) return;
+    float sg[8], zz[8];
+    const float inv = 1.f / (float)g.HW;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = fmaf(g[j], se_sigmoid(up[j]), zp[j] * inv);
-        out[i] = pack8(g);
+    for (int j = 0; j < 8; ++j) {
+        sg[j] = se_sigmoid(u[(size_t)n * g.C + cg * 8 + j]);
+        zz[j] = dz[(size_t)n * g.C + cg * 8 + j] * inv;
+    }
+    const int p0 = blockIdx.y * g.chunk, p1 = min(g.HW, p0 + g.chunk);
+    const size_t base = (size_t)n * g.HW * g.G + cg;
+    for (int p = p0 + pr; p < p1; p += g.R) {
+        float gq[8];
+        unpack8(gs[base + (size_t)p * g.G], gq);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gq[j] = fmaf(gq[j], sg[j], zz[j]);
+        out[base + (size_t)p * g.G] = pack8(gq);
     }
 }
 
-static int se_grid(size_t total) {
-    size_t b = (total + 255) / 256;
-    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+// pixel splits per image: enough workgroups to fill the chip (>= ~2048), whole multiples of R pixels each
+static bool se_geom(int N, int HW, int C, SeGeom* g, int* splits) {
+    if (N < 1 || HW < 1 || C < 8 || (C & 7) || C > 2048) return false;
+    g->G = C >> 3; g->R = 256 / g->G; g->HW = HW; g->C = C;
+    if (g->R < 1) return false;
+    int sp = (2048 + N - 1) / N;
+    const int maxsp = (HW + g->R * 4 - 1) / (g->R * 4);              // at least 4 pixels per thread
+    if (sp > maxsp) sp = maxsp;
+    if (sp < 1) sp = 1;
+    int chunk = (HW + sp - 1) / sp;
+    chunk = (chunk + g->R - 1) / g->R * g->R;
+    g->chunk = chunk;
+    *splits = (HW + chunk - 1) / chunk;
+    return true;
+}
+// bytes of scratch mnas_se_bwd_reduce needs (partial sums float[splits][N][C])
+extern "C" int64_t mnas_se_scratch_bytes(int N, int HW, int C) {
+    SeGeom g; int sp;
+    if (!se_geom(N, HW, C, &g, &sp)) return -1;
+    return (int64_t)sp * N * C * sizeof(float);
 }
 extern "C" int mnas_se_scale(const MnasActIn* a, const float* u, int N, int HW, int C, void* out_bf16, void* stream) {
-    if (!a || !a->data || !u || !out_bf16 || N < 1 || HW < 1 || C < 8 || (C & 7)) return MNAS_EINVAL;
+    SeGeom g; int sp;
+    if (!a || !a->data || !u || !out_bf16 || !se_geom(N, HW, C, &g, &sp)) return MNAS_EINVAL;
     if ((a->scale == nullptr) != (a->shift == nullptr)) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_se_scale, dim3(se_grid((size_t)N * HW * (C >> 3))), dim3(256), 0, (hipStream_t)stream, *a, u, N, HW, C, (uint4*)out_bf16);
+    hipLaunchKernelGGL(k_se_scale, dim3(N, sp), dim3(256), 0, (hipStream_t)stream, *a, u, g, (uint4*)out_bf16);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
-extern "C" int mnas_se_bwd_reduce(const void* gs, const MnasActIn* a, const float* u, int N, int HW, int C, float* du, void* stream) {
-    if (!gs || !a || !a->data || !u || !du || N < 1 || HW < 1 || C < 8 || (C & 7)) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_se_bwd_reduce, dim3(N, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const uint4*)gs, *a, u, HW, C, du);
+extern "C" int mnas_se_bwd_reduce(const void* gs, const MnasActIn* a, const float* u, int N, int HW, int C, float* du, float* scratch,
+                                  void* stream) {
+    SeGeom g; int sp;
+    if (!gs || !a || !a->data || !u || !du || !scratch || !se_geom(N, HW, C, &g, &sp)) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_se_bwd_reduce, dim3(N, sp), dim3(256), (size_t)g.R * C * sizeof(float), (hipStream_t)stream, (const uint4*)gs, *a, g,
+                       scratch, N);
+    hipLaunchKernelGGL(k_se_bwd_finish, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, u, sp, N * C, du);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
 extern "C" int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16, void* stream) {
-    if (!gs || !u || !dz || !out_bf16 || N < 1 || HW < 1 || C < 8 || (C & 7)) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_se_bwd_apply, dim3(se_grid((size_t)N * HW * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const uint4*)gs, u, dz, N, HW,
-                       C, (uint4*)out_bf16);
+    SeGeom g; int sp;
+    if (!gs || !u || !dz || !out_bf16 || !se_geom(N, HW, C, &g, &sp)) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_se_bwd_apply, dim3(N, sp), dim3(256), 0, (hipStream_t)stream, (const uint4*)gs, u, dz, g, (uint4*)out_bf16);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }

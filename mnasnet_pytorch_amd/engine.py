@@ -685,7 +685,11 @@ class Program:
             dh = new((N, R_), torch.float32)
             dzp = new((N, E_), torch.float32)
             ga = new((N, h2.H, h2.W, E_))
-            ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr()], 0)
+            sb = lib.mnas_se_scratch_bytes(N, HWl, E_)
+            if sb < 0:
+                raise RuntimeError("unsupported squeeze-excite shape %s" % ((N, HWl, E_),))
+            dup = new((sb // 4,), torch.float32)
+            ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr(), dup.data_ptr()], 0)
             # fc2: dW2 += du^T hb, db2 += sum du ; dh = (du W2) * [hb > 0]
             ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 1, 1], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
                                                                 eng.gptr(se, 2), eng.gptr(se, 3)], 0)

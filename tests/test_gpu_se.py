@@ -21,7 +21,7 @@ def rl2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("shape", [(3, 14, 14, 48), (2, 7, 7, 1152), (5, 28, 28, 240), (2, 5, 9, 72)])
+@pytest.mark.parametrize("shape", [(3, 14, 14, 48), (2, 7, 7, 1152), (5, 28, 28, 240), (2, 5, 9, 72), (4, 112, 112, 48)])
 @pytest.mark.parametrize("virt", [True, False])
 def test_se_kernels(shape, virt):
     N, H, W, Cc = shape
@@ -40,7 +40,9 @@ def test_se_kernels(shape, virt):
     L.check(lib.mnas_se_scale(C_.byref(ai), ud.data_ptr(), N, HW, Cc, out.data_ptr(), L.cur_stream()), "se_scale")
     assert relerr(from_nhwc(out), a * sg[:, :, None, None]) < 6e-3
     du = torch.full((N, Cc), float("nan"), device="cuda")
-    L.check(lib.mnas_se_bwd_reduce(gsd.data_ptr(), C_.byref(ai), ud.data_ptr(), N, HW, Cc, du.data_ptr(), L.cur_stream()), "se_bwd_reduce")
+    scr = torch.full((lib.mnas_se_scratch_bytes(N, HW, Cc) // 4,), float("nan"), device="cuda")
+    L.check(lib.mnas_se_bwd_reduce(gsd.data_ptr(), C_.byref(ai), ud.data_ptr(), N, HW, Cc, du.data_ptr(), scr.data_ptr(),
+                                   L.cur_stream()), "se_bwd_reduce")
     assert relerr(du.cpu(), (gs * a).sum((2, 3)) * sg * (1 - sg)) < 2e-3
     ga = torch.full((N, H, W, Cc), float("nan"), dtype=torch.bfloat16, device="cuda")
     L.check(lib.mnas_se_bwd_apply(gsd.data_ptr(), ud.data_ptr(), dzd.data_ptr(), N, HW, Cc, ga.data_ptr(), L.cur_stream()), "se_bwd_apply")
