@@ -469,6 +469,14 @@ int64_t mnas_packed_bytes(int kind, int Co, int Ci, int kh, int kw);
 int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* The other two optimizers train.py offers (:222-228), same flat buffers and grad_scale convention:
+ * torch.optim.RMSprop (centered = False; momentum_buf may be NULL when momentum == 0) and torch.optim.SGD (step = 1 initialises
+ * the momentum buffer with the gradient, as torch does; momentum_buf may be NULL when momentum == 0). */
+int mnas_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buf, int64_t n, float lr, float alpha,
+                      float eps, float weight_decay, float momentum, float grad_scale, void* stream);
+int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                  float weight_decay, int nesterov, int step, float grad_scale, void* stream);
+
 /* ---- batched launch: run a pre-built list of the calls above with ONE host->library transition ------- */
 #define MNAS_OP_CONV_GEMM 1
 #define MNAS_OP_CONV_WGRAD 2

@@ -191,6 +191,10 @@ SYMBOLS = {
     "mnas_packed_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "mnas_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),
+    "mnas_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                  c_float, c_void_p]),
+    "mnas_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int, c_float,
+                              c_void_p]),
     "mnas_run_ops": (c_int, [C.POINTER(MnasOp), c_int, c_void_p, C.POINTER(c_int)]),
     "mnas_run_ops_multi": (c_int, [C.POINTER(MnasOp), c_int, C.POINTER(c_void_p), c_int, C.POINTER(c_int)]),
     "mnas_event_create": (c_int, [C.POINTER(c_void_p)]),

@@ -707,6 +707,64 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
         p[i] = pi - (lr / bc1) * (mi / denom);
     }
 }
+// torch.optim.RMSprop (train.py:222-224; centered = False) and torch.optim.SGD (train.py:226-228) over the same flat buffers
+__global__ __launch_bounds__(256) void k_rmsprop(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                 float* __restrict__ buf, int64_t n, float lr, float alpha, float eps, float wd,
+                                                 float momentum, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float s = fmaf(alpha, sq[i], (1.f - alpha) * gi * gi);
+        sq[i] = s;
+        const float avg = sqrtf(s) + eps;
+        if (momentum > 0.f) {
+            const float b = fmaf(momentum, buf[i], gi / avg);
+            buf[i] = b;
+            p[i] = pi - lr * b;
+        } else {
+            p[i] = pi - lr * (gi / avg);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n,
+                                             float lr, float momentum, float dampening, float wd, int nesterov, int first,
+                                             float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        if (momentum != 0.f) {
+            const float b = first ? gi : fmaf(momentum, buf[i], (1.f - dampening) * gi);
+            buf[i] = b;
+            gi = nesterov ? fmaf(momentum, b, gi) : b;
+        }
+        p[i] = pi - lr * gi;
+    }
+}
+static unsigned opt_blocks(int64_t n) {
+    int64_t blocks = (n + 255) / 256;
+    return (unsigned)(blocks > 2048 ? 2048 : blocks);
+}
+extern "C" int mnas_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buf, int64_t n, float lr, float alpha,
+                                 float eps, float weight_decay, float momentum, float grad_scale, void* stream) {
+    if (n < 0 || !p || !g || !square_avg || (momentum > 0.f && !momentum_buf)) return MNAS_EINVAL;
+    if (n == 0) return MNAS_OK;
+    hipLaunchKernelGGL(k_rmsprop, dim3(opt_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, square_avg, momentum_buf, n, lr, alpha,
+                       eps, weight_decay, momentum, grad_scale);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+extern "C" int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                             float weight_decay, int nesterov, int step, float grad_scale, void* stream) {
+    if (n < 0 || step < 1 || !p || !g || (momentum != 0.f && !momentum_buf)) return MNAS_EINVAL;
+    if (n == 0) return MNAS_OK;
+    hipLaunchKernelGGL(k_sgd, dim3(opt_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, momentum_buf, n, lr, momentum, dampening,
+                       weight_decay, nesterov, step == 1 ? 1 : 0, grad_scale);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 extern "C" int mnas_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
     if (step < 1 || n < 0) return MNAS_EINVAL;

@@ -155,12 +155,15 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.step_count += 1
         for a, b in self._trainable_runs():
-            L.check(self._lib.mnas_adam_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a,
-                                             self.flat_m.data_ptr() + 4 * a, self.flat_v.data_ptr() + 4 * a, b - a,
-                                             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                             float(g["weight_decay"]), self.step_count, float(self.grad_scale),
-                                             L.cur_stream()), "adam_step")
+            self._launch(a, b, g)
         return loss
+
+    def _launch(self, a, b, g):
+        L.check(self._lib.mnas_adam_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a,
+                                         self.flat_m.data_ptr() + 4 * a, self.flat_v.data_ptr() + 4 * a, b - a,
+                                         float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                         float(g["weight_decay"]), self.step_count, float(self.grad_scale),
+                                         L.cur_stream()), "adam_step")
 
     def state_dict(self):
         g = self.param_groups[0]
@@ -179,6 +182,45 @@ class FlatAdam(torch.optim.Optimizer):
                 self.param_groups[0][k] = v
 
 
+class FlatRMSprop(FlatAdam):
+    """``torch.optim.RMSprop`` (train.py:222-224: ``--optimizer rmsprop``; alpha 0.99, eps 1e-8, centered = False) over the flat
+    buffers: one fused launch (``mnas_rmsprop_step``).  Same Optimizer contract as :class:`FlatAdam`."""
+
+    def __init__(self, params, flat_p, flat_g, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False,
+                 grad_scale=1.0):
+        if centered:
+            raise NotImplementedError("centered RMSprop is not fused (the reference never asks for it: train.py:222-224)")
+        super().__init__(params, flat_p, flat_g, lr=lr, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+        self.param_groups[0].pop("betas", None)
+        self.param_groups[0].update(alpha=alpha, momentum=momentum, centered=False)
+        # flat_m = momentum buffer, flat_v = square average (same checkpoint layout as FlatAdam: exp_avg / exp_avg_sq)
+
+    def _launch(self, a, b, g):
+        L.check(self._lib.mnas_rmsprop_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a,
+                                            self.flat_v.data_ptr() + 4 * a, self.flat_m.data_ptr() + 4 * a, b - a, float(g["lr"]),
+                                            float(g["alpha"]), float(g["eps"]), float(g["weight_decay"]), float(g["momentum"]),
+                                            float(self.grad_scale), L.cur_stream()), "rmsprop_step")
+
+
+class FlatSGD(FlatAdam):
+    """``torch.optim.SGD`` (train.py:226-228: ``--optimizer sgd``; momentum 0 by default) over the flat buffers
+    (``mnas_sgd_step``).  ``flat_m`` is the momentum buffer (initialised with the first gradient, as torch does)."""
+
+    def __init__(self, params, flat_p, flat_g, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, grad_scale=1.0):
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(params, flat_p, flat_g, lr=lr, weight_decay=weight_decay, grad_scale=grad_scale)
+        for k in ("betas", "eps"):
+            self.param_groups[0].pop(k, None)
+        self.param_groups[0].update(momentum=momentum, dampening=dampening, nesterov=nesterov)
+
+    def _launch(self, a, b, g):
+        L.check(self._lib.mnas_sgd_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a,
+                                        self.flat_m.data_ptr() + 4 * a, b - a, float(g["lr"]), float(g["momentum"]),
+                                        float(g["dampening"]), float(g["weight_decay"]), 1 if g["nesterov"] else 0, self.step_count,
+                                        float(self.grad_scale), L.cur_stream()), "sgd_step")
+
+
 class Trainer:
     """Owns flat parameter / gradient / Adam-moment buffers for ``model`` (a FineTuneModelPool or anything with
     a ``features`` engine module plus ordinary PyTorch head parameters) and runs train.py's step.
@@ -187,7 +229,7 @@ class Trainer:
 
     def __init__(self, model: nn.Module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  criterion: Optional[nn.Module] = None, distributed: bool = False, process_group=None,
-                 early_bucket_stage: int = 5):
+                 early_bucket_stage: int = 5, optimizer: str = "adam", **optimizer_kwargs):
         self.model = model
         self.native_step = True          # see _native_head()
         self.last_logits = None
@@ -240,8 +282,18 @@ class Trainer:
             # bucket 0 is all-reduced as soon as its last stage is done: its side-stream weight gradients must be in
             self.engine.join_stages = self.schedule.join_stages
             self.engine.reset_programs()
-        self.optimizer = FlatAdam(head + eng_params, self.flat_p, self.flat_g, lr=lr, betas=betas, eps=eps,
-                                  weight_decay=weight_decay, grad_scale=1.0 / self.world)
+        # train.py:218-231: --optimizer adam | rmsprop | sgd, each constructed with lr only
+        if optimizer.startswith("adam"):
+            self.optimizer = FlatAdam(head + eng_params, self.flat_p, self.flat_g, lr=lr, betas=betas, eps=eps,
+                                      weight_decay=weight_decay, grad_scale=1.0 / self.world, **optimizer_kwargs)
+        elif optimizer.startswith("rmsprop"):
+            self.optimizer = FlatRMSprop(head + eng_params, self.flat_p, self.flat_g, lr=lr, weight_decay=weight_decay,
+                                         grad_scale=1.0 / self.world, **optimizer_kwargs)
+        elif optimizer.startswith("sgd"):
+            self.optimizer = FlatSGD(head + eng_params, self.flat_p, self.flat_g, lr=lr, weight_decay=weight_decay,
+                                     grad_scale=1.0 / self.world, **optimizer_kwargs)
+        else:
+            raise ValueError("Optimizer not supported")            # train.py:231
 
     # convenience mirrors of the optimizer's hyper-parameters / state
     @property

@@ -385,3 +385,44 @@ def test_input_pipeline_on_device_normalisation_and_uint8():
     m2 = build("512", 10, proj_gamma=0.1).eval()
     with torch.no_grad():
         assert rl2(m2(u8.cuda()).cpu(), m2(u8.float().cuda()).cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("kind,kw", [("rmsprop", {}), ("rmsprop", {"momentum": 0.9}), ("sgd", {}), ("sgd", {"momentum": 0.9}),
+                                     ("sgd", {"momentum": 0.9, "nesterov": True}), ("adam", {})])
+def test_flat_optimizers_match_torch(kind, kw):
+    """train.py:218-231 offers Adam, RMSprop and SGD (each constructed with lr only).  The fused flat-buffer updates
+    (mnas_adam_step / mnas_rmsprop_step / mnas_sgd_step) against the stock torch optimizers on the same gradient sequence, five
+    steps with weight decay: parameters equal to 1e-6 relative (fp32 arithmetic, same formulas)."""
+    from mnasnet_pytorch_amd import _lib as Lb
+    from mnasnet_pytorch_amd.train_step import FlatAdam, FlatRMSprop, FlatSGD
+    n = 10007
+    g0 = torch.Generator().manual_seed(7)
+    p0 = torch.randn(n, generator=g0)
+    grads = [torch.randn(n, generator=g0) * (0.5 + 0.2 * i) for i in range(5)]
+    ref = torch.nn.Parameter(p0.clone())
+    cls = {"adam": torch.optim.Adam, "rmsprop": torch.optim.RMSprop, "sgd": torch.optim.SGD}[kind]
+    opt_ref = cls([ref], lr=1e-2, weight_decay=1e-2, **kw)
+    flat_p, flat_g = p0.clone().cuda(), torch.zeros(n, device="cuda")
+    par = torch.nn.Parameter(flat_p.view(n))
+    par.data = flat_p.view(n)
+    fcls = {"adam": FlatAdam, "rmsprop": FlatRMSprop, "sgd": FlatSGD}[kind]
+    opt = fcls([par], flat_p, flat_g, lr=1e-2, weight_decay=1e-2, **kw)
+    assert isinstance(opt, torch.optim.Optimizer)
+    for g in grads:
+        ref.grad = g.clone()
+        opt_ref.step()
+        flat_g.copy_(g.cuda())
+        opt.step()
+    torch.cuda.synchronize()
+    assert rl2(flat_p.cpu(), ref.detach()) < 1e-6, (kind, kw)
+    # the Trainer builds them by name, like train.py's --optimizer flag
+    from mnasnet_pytorch_amd.train_step import Trainer
+    m = build("512", 10, proj_gamma=0.1).train()
+    _no_dropout(m)
+    tr = Trainer(m, lr=1e-3, optimizer=kind, **kw)
+    x = C.det_input((4, 3, 64, 64)).cuda()
+    t = torch.tensor([1, 3, 5, 7]).cuda()
+    losses = [float(tr.step(x, t)) for _ in range(3)]
+    assert np.isfinite(losses).all() and type(tr.optimizer) is fcls
+    with pytest.raises(ValueError):
+        Trainer(build("512", 10).train(), optimizer="adagrad")
