@@ -180,7 +180,7 @@ class Program:
         self.in_u8 = bool(in_u8)
         # fused input pipeline of the stem (Engine.set_input_normalization): per-plane affine, uint8 images
         aff = eng.input_affine(self.in_u8)
-        aff_ptr = aff.data_ptr() if aff is not None else None
+        self._aff_ptr = aff.data_ptr() if aff is not None else None
         if self.in_u8 and aff is None:
             raise RuntimeError("uint8 images need Engine.set_input_normalization(mean, std)")
         self.busy = False
@@ -188,17 +188,9 @@ class Program:
         self.keep = []                      # tensors owned by this program
         lib = eng.lib
 
-        def new(shape, dtype=torch.bfloat16):
-            t = torch.empty(shape, dtype=dtype, device=dev)
-            self.keep.append(t)
-            return t
 
-        def bnbuf(C_):
-            t = torch.zeros((L_BN_ROWS, C_), dtype=torch.float32, device=dev)
-            self.keep.append(t)
-            return t
 
-        fwd = _OpList(eng, "fwd")
+        fwd = self._fwd = _OpList(eng, "fwd")
         # ---- weight packing (once per forward; weights change every optimizer step): one batched launch
         descs = []
         for ci in eng.convs:
@@ -224,173 +216,30 @@ class Program:
         first_kind = eng.info[id(steps[0][1] if steps[0][0] == "conv" else steps[0][1][0])].kind
         self.x_is_image = first_kind == "stem"
         self.patch_x = []       # (op index, pointer slot) receiving the input pointer
-        records = []            # forward applications, for the backward builder
+        records = self._records = []   # forward applications, for the backward builder
         Hc, Wc = H, W
         if self.x_is_image:
             cur = None          # the stem reads the fp32 NCHW input directly
         else:
             Cin = eng.info[id(steps[0][1] if steps[0][0] == "conv" else steps[0][1][0])].cin
-            xb = new((N, H, W, Cin))
+            xb = self._new((N, H, W, Cin))
             j = fwd.add(L.OP_NCHW_TO_NHWC, [N, Cin, H * W], [], [None, xb.data_ptr()])
             self.patch_x.append((j, 0))
             cur = _Act(xb, None, H, W, Cin)
         self.in_channels = 3 if self.x_is_image else cur.C
 
-        def conv_fwd(ci: _ConvInfo, a_in: Optional[_Act], Hi, Wi):
-            Ho, Wo = ci.out_hw(Hi, Wi)
-            M = N * Ho * Wo
-            y = new((N, Ho, Wo, ci.cout))
-            bn = bnbuf(ci.cout)
-            conv, bnm = ci.mod.conv, ci.mod.bn
-            bias = conv.bias.data_ptr() if conv.bias is not None else None
-            nparts = lib.mnas_conv_gemm_parts(0, M, ci.cin, ci.cout, ci.k * ci.k) if ci.kind in ("pw", "dense") else -1
-            if nparts < 1:
-                nparts = max(1, min(1024, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
-            if ci.kind == "dense":       # small maps: one image per workgroup (csrc/mnas_dimg.hip)
-                ip = lib.mnas_conv_img_parts(0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.stride, ci.pad)
-                nparts = ip if ip > 0 else nparts
-            stats = eng.scratch_stats.data_ptr() if training else None
-            if ci.kind == "stem":
-                sp = lib.mnas_stem_parts(0, N, Hi, Wi, ci.cout)
-                nparts = sp if sp > 0 else nparts
-                j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts, 1 if self.in_u8 else 0], [],
-                            [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats, aff_ptr])
-                self.patch_x.append((j, 0))
-            elif ci.kind == "dw":
-                nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 2)))
-                fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nlaunch], [],
-                        a_in.act_ptrs() + [ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
-                nparts = lib.mnas_dw_rows(N, Hi, Wi, ci.cout, ci.k, nlaunch, 0)      # columns of the stats table
-                if nparts < 1:
-                    raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, ci.cout, ci.k),))
-            else:
-                fwd.add(L.OP_CONV_GEMM, [0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
-                        a_in.act_ptrs() + [None, None, None, ci.w_fwd.data_ptr(), bias, None, y.data_ptr(), stats])
-            fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, ci.cout, 1 if training else 0], [float(M), bnm.momentum, bnm.eps],
-                    [stats, bnm.weight.data_ptr(), bnm.bias.data_ptr(), bnm.running_mean.data_ptr(),
-                     bnm.running_var.data_ptr(), bnm.num_batches_tracked.data_ptr(), bn.data_ptr()])
-            out = _Act(y, bn, Ho, Wo, ci.cout)
-            records.append(("conv", ci, a_in, out, Hi, Wi))
-            return out
 
-        def block_fwd_fused(e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
-            """expand (1x1) + depthwise of an MBConv_block in ONE kernel (csrc/mnas_dw.hip, EXP forms): the expand conv's
-            BatchNorm statistics come from the covariance of the block input (csrc/mnas_gram.hip), so the expanded tensor
-            is produced straight into the depthwise kernel's LDS rings.  It is still written to HBM in training (backward
-            reads it); in eval mode it never leaves the chip.  Returns the depthwise output, or None if unsupported."""
-            M = N * Hi * Wi
-            C_, k = d_ci.cout, d_ci.k
-            nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * C_, 256 * 16 * 2)))
-            rows = lib.mnas_dw_exp_rows(N, Hi, Wi, C_, k, e_ci.cin, nlaunch)
-            if rows < 1:
-                return None
-            econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
-            bn_e, bn_d = bnbuf(C_), bnbuf(C_)
-            if training:
-                nsplit = max(1, min(512, _cdiv(M, 2048)))
-                gsc = eng.gram_scratch(e_ci.cin, nsplit)
-                gd = torch.empty(e_ci.cin * e_ci.cin + e_ci.cin, dtype=torch.float64, device=dev)
-                self.keep.append(gd)
-                fwd.add(L.OP_GRAM, [e_ci.cin, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
-                fwd.add(L.OP_GRAM_BN, [nsplit, e_ci.cin, C_], [float(M), ebn.momentum, ebn.eps],
-                        [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
-                         econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
-                         ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
-                         gd.data_ptr(), bn_e.data_ptr()])
-            else:
-                fwd.add(L.OP_BN_FWD_FINALIZE, [1, C_, 0], [float(M), ebn.momentum, ebn.eps],
-                        [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
-                         ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
-            y1 = new((N, Hi, Wi, C_)) if training else None
-            y2 = new((N, Hi, Wi, C_))
-            stats = eng.scratch_stats.data_ptr() if training else None
-            fwd.add(L.OP_DW_EXP_FWD, [N, Hi, Wi, C_, k, e_ci.cin, nlaunch], [],
-                    a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                                       bn_e.data_ptr(), bn_e.data_ptr() + 4 * C_, d_ci.w_fwd.data_ptr(),
-                                       dconv.bias.data_ptr() if dconv.bias is not None else None,
-                                       y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
-            fwd.add(L.OP_BN_FWD_FINALIZE, [rows, C_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
-                    [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
-                     dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
-            h1 = _Act(y1, bn_e, Hi, Wi, C_)
-            h2 = _Act(y2, bn_d, Hi, Wi, C_)
-            records.append(("conv", e_ci, a_in, h1, Hi, Wi))
-            records.append(("conv", d_ci, h1, h2, Hi, Wi))
-            return h2
 
-        def block_fwd_irb(e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
-            """expand + depthwise of an MBConv_block on the small maps (csrc/mnas_irb.hip): the expanded tensor y1 is NEVER written;
-            backward recomputes it (csrc/mnas_irb_bwd.hip).  BatchNorm1's statistics come from the covariance of the block input
-            (csrc/mnas_gram.hip); the Gram sums are kept for the expand conv's weight gradient.  Returns the depthwise output, or
-            None if the shape is not supported (then the per-layer kernels run)."""
-            C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
-            if e_ci.cout != E_ or not lib.mnas_irb_supported(N, Hi, Wi, C_, E_, k):
-                return None
-            M = N * Hi * Wi
-            econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
-            bn_e, bn_d = bnbuf(E_), bnbuf(E_)
-            gd = None
-            if training:
-                nsplit = max(1, min(128, _cdiv(M, 1024)))
-                gsc = eng.gram_scratch(C_, nsplit)
-                gd = torch.empty(C_ * C_ + C_, dtype=torch.float64, device=dev)       # G = sum a a^T, Sx = sum a (kept for backward)
-                self.keep.append(gd)
-                fwd.add(L.OP_GRAM, [C_, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
-                fwd.add(L.OP_GRAM_BN, [nsplit, C_, E_], [float(M), ebn.momentum, ebn.eps],
-                        [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
-                         econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
-                         ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
-                         gd.data_ptr(), bn_e.data_ptr()])
-            else:
-                fwd.add(L.OP_BN_FWD_FINALIZE, [1, E_, 0], [float(M), ebn.momentum, ebn.eps],
-                        [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
-                         ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
-            nparts = lib.mnas_irb_fwd_parts(N, Hi, Wi, C_, E_, k, max(1, eng.irb_workgroups // (E_ // 32)))
-            # "fwd" mode: the fused kernel also stores y1 and the per-layer backward kernels run (they read y1 and g2)
-            keep_y1 = training and eng.fuse_irb == "fwd"
-            y1 = new((N, Hi, Wi, E_)) if keep_y1 else None
-            y2 = new((N, Hi, Wi, E_))
-            stats = eng.scratch_stats.data_ptr() if training else None
-            fwd.add(L.OP_IRB_FWD, [N, Hi, Wi, C_, E_, k, nparts], [],
-                    a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                                       bn_e.data_ptr(), d_ci.w_fwd.data_ptr(),
-                                       dconv.bias.data_ptr() if dconv.bias is not None else None,
-                                       y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
-            fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, E_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
-                    [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
-                     dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
-            h1 = _Act(y1, bn_e, Hi, Wi, E_)                      # full mode: the expanded activation exists only on chip
-            h2 = _Act(y2, bn_d, Hi, Wi, E_)
-            records.append(("conv", e_ci, a_in, h1, Hi, Wi))
-            records.append(("conv", d_ci, h1, h2, Hi, Wi))
-            if training and not keep_y1:
-                irb_blocks[len(records) - 2] = (gd, nparts)
-            return h2
 
-        def se_fwd(se: _SEInfo, h2: _Act, Hi, Wi):
-            """squeeze-excite on the activated depthwise output (csrc/mnas_se.hip): pooled mean -> fc1+ReLU -> fc2 -> a2 * sigmoid.
-            Returns the MATERIALISED scaled activation the project conv reads."""
-            E_, R_ = se.channels, se.reduced
-            z = new((N, E_), torch.float32)
-            hb = new((N, R_), torch.float32)
-            u = new((N, E_), torch.float32)
-            a2s = new((N, Hi, Wi, E_))
-            m_ = se.mod
-            fwd.add(L.OP_POOL_ACT, [N, Hi * Wi, E_], [], h2.act_ptrs() + [z.data_ptr()])
-            fwd.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 0], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), hb.data_ptr()])
-            fwd.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 0], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), m_.fc2.bias.data_ptr(), u.data_ptr()])
-            fwd.add(L.OP_SE_SCALE, [N, Hi * Wi, E_], [], h2.act_ptrs() + [u.data_ptr(), a2s.data_ptr()])
-            se_records[len(records)] = (se, h2, z, hb, u)        # keyed by the record index of the project conv that follows
-            return _Act(a2s, None, Hi, Wi, E_)
 
-        se_records = {}
-        irb_blocks = {}          # index of the expand conv's record -> (Gram sums, image groups) of a fused block application
+        self._se_records = {}    # record index of a project conv -> its block's squeeze-excite tensors
+        self._irb_blocks = {}    # index of the expand conv's record -> (Gram sums, image groups) of a fused block application
         step_records = []
         for op, m, stage in steps:
             start = len(records)
             if op == "conv":
                 ci = eng.info[id(m)]
-                cur = conv_fwd(ci, cur, Hc, Wc)
+                cur = self._conv_fwd(ci, cur, Hc, Wc)
                 Hc, Wc = cur.H, cur.W
                 step_records.append(("conv", stage, start, None, None))
             else:
@@ -399,13 +248,13 @@ class Program:
                 cis = [eng.info[id(cb)] for cb in m]
                 is_irb = len(cis) == 3 and cis[0].kind == "pw" and cis[1].kind == "dw" and cis[2].kind == "pw"
                 if eng.fuse_irb and is_irb and id(m[0]) not in eng.se_info:
-                    h = block_fwd_irb(cis[0], cis[1], a_in, Hc, Wc)
+                    h = self._block_fwd_irb(cis[0], cis[1], a_in, Hc, Wc)
                     if h is not None:
-                        h = conv_fwd(cis[2], h, Hc, Wc)
+                        h = self._conv_fwd(cis[2], h, Hc, Wc)
                 if h is None and eng.fuse_expand and is_irb and id(m[0]) not in eng.se_info:
-                    h = block_fwd_fused(cis[0], cis[1], a_in, Hc, Wc)
+                    h = self._block_fwd_fused(cis[0], cis[1], a_in, Hc, Wc)
                     if h is not None:
-                        h = conv_fwd(cis[2], h, Hc, Wc)
+                        h = self._conv_fwd(cis[2], h, Hc, Wc)
                 se = eng.se_info.get(id(m[0]))
                 if se is not None:
                     h = None                                # SE blocks run per layer (the fused paths have no SE stage)
@@ -413,9 +262,9 @@ class Program:
                     h = cur
                     for j_, ci_ in enumerate(cis):
                         if j_ == 2 and se is not None:
-                            h = se_fwd(se, h, Hc, Wc)
-                        h = conv_fwd(ci_, h, Hc, Wc)
-                r = new((N, Hc, Wc, a_in.C))
+                            h = self._se_fwd(se, h, Hc, Wc)
+                        h = self._conv_fwd(ci_, h, Hc, Wc)
+                r = self._new((N, Hc, Wc, a_in.C))
                 fwd.add(L.OP_ADD_ACT, [a_in.C, Hc * Wc], [float(N * Hc * Wc)],
                         a_in.act_ptrs() + h.act_ptrs() + [r.data_ptr(), None])
                 cur = _Act(r, None, Hc, Wc, a_in.C)
@@ -438,283 +287,48 @@ class Program:
         self.bwd_segments = []      # [(stage, ops, n)]
         self.patch_gout = None
         self.patch_dx = None
-        if not training:
-            return
-        seg_ops: Dict[int, _OpList] = {}
-        order: List[int] = []
+        self.patch_x_bwd = None
+        if training:
+            self._build_backward(step_records, cur)
 
-        def seg(stage):
-            if stage not in seg_ops:
-                seg_ops[stage] = _OpList(eng, "bwd")
-                order.append(stage)
-            return seg_ops[stage]
+    def _build_backward(self, step_records, cur):
+        """The backward launch lists, one per features.<stage> segment, from the forward's records (reverse order)."""
+        eng, lib, N, H, W, need_dx, pooled, records = self.eng, self.eng.lib, self.N, self.H, self.W, self.need_dx, self.pooled, self._records
+        self._seg_ops: Dict[int, _OpList] = {}
+        self._order: List[int] = []
+        seg_ops, order = self._seg_ops, self._order
+
 
         last_stage = step_records[-1][1]
-        g_final = new((N, cur.H, cur.W, cur.C))
+        g_final = self._new((N, cur.H, cur.W, cur.C))
         if pooled:
-            j = seg(last_stage).add(L.OP_POOL_BWD, [N, cur.H * cur.W, cur.C], [], [None, g_final.data_ptr()])
+            j = self._seg(last_stage).add(L.OP_POOL_BWD, [N, cur.H * cur.W, cur.C], [], [None, g_final.data_ptr()])
         else:
-            j = seg(last_stage).add(L.OP_NCHW_TO_NHWC, [N, cur.C, cur.H * cur.W], [], [None, g_final.data_ptr()])
+            j = self._seg(last_stage).add(L.OP_NCHW_TO_NHWC, [N, cur.C, cur.H * cur.W], [], [None, g_final.data_ptr()])
         self.patch_gout = (last_stage, j, 0)
 
         # ---- merged bookkeeping launches (mnas_bwd_post): the weight-gradient reductions of the main-stream kernel that just
         # ran ride in the SAME launch as the next layer's BatchNorm-backward finalize (and the second level of a two-level
         # reduction in the one after that), instead of 2-3 tiny dependent launches in every gap of the main stream
         merge = eng.merge_post
-        pend = {"w1": None, "w2": None, "ops": None}
-        rot = [0]
-        rot_bufs = [eng.scratch_wgrad2, eng.scratch_wgrad3, eng.scratch_wgrad4]
+        self._pend = {"w1": None, "w2": None, "ops": None}
+        self._rot = 0
+        self._rot_bufs = [eng.scratch_wgrad2, eng.scratch_wgrad3, eng.scratch_wgrad4]
 
-        def next_scratch():
-            b = rot_bufs[rot[0] % 3]
-            rot[0] += 1
-            return b
 
-        def emit_post(ops: _OpList, bn=None):
-            w1, w2 = pend["w1"], pend["w2"]
-            pend["w1"] = pend["w2"] = None
-            if w1 is not None and w1[7] == 2:
-                pend["w2"] = w1[:7] + (3,)
-            if bn is None and w1 is None and w2 is None:
-                return
-            none = (None, None, 0, 0, 0, 0, 0, 0)
-            w1 = w1 or none
-            w2 = w2 or none
-            bn = bn or (None, None, None, None, 0, 0, 0.0)
-            ops.add(L.OP_BWD_POST, [bn[4], bn[5]] + list(w1[2:]) + list(w2[2:]), [bn[6]],
-                    list(bn[:4]) + [w1[0], w1[1], w2[0], w2[1]], 0)
-            pend["ops"] = ops
 
-        def flush_post():
-            while pend["w1"] is not None or pend["w2"] is not None:
-                emit_post(pend["ops"])
 
-        def queue_wgrad(ops, partial, nsplit, Co_, Ci_, taps, dw, grad_ptr):
-            pend["w1"] = (partial, grad_ptr, nsplit, Co_, Ci_, taps, 1 if dw else 0, 1 if nsplit <= 256 else 2)
-            pend["ops"] = ops
 
-        def conv_bwd(ops: _OpList, rec, g, resid, need_gin, g_reduced=False, red_target=None):
-            """Backward of one ConvBlock application.  g: bf16 grad wrt its activated output.
-            g_reduced: the producer of g already wrote this layer's BN-backward partial sums into
-            eng.scratch_red (fused epilogue) with `g_reduced` columns.  red_target: (y, bn, C) of the ConvBlock
-            whose activated output is THIS layer's input -- the dgrad epilogue then does that reduce.
-            Returns (gin, ncols) : bf16 grad wrt the (activated) input or None, and the number of partial
-            columns written for red_target (0 if not fused)."""
-            _, ci, a_in, out, Hi, Wi = rec
-            Ho, Wo, Co = out.H, out.W, ci.cout
-            M = N * Ho * Wo
-            gy = [g.data_ptr(), out.data.data_ptr(), out.bn.data_ptr()]
-            if g_reduced:
-                nred = g_reduced
-                red_buf = eng.scratch_red
-            else:
-                nred = max(1, min(1024, _cdiv(M * Co, 256 * 8 * 8)))
-                red_buf = eng.scratch_stats
-                ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), red_buf.data_ptr()])
-            if merge:
-                if pend["ops"] is not None and pend["ops"] is not ops:
-                    flush_post()               # a stage's gradients are complete inside its own launch list
-                emit_post(ops, (red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3), nred, Co, float(M)))
-            else:
-                ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
-                        [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
-            # the weight-gradient kernels only share READ-ONLY inputs (g, y, the dy coefficients just finalised, the
-            # forward activations) with the input-gradient chain: they go to the side stream and run concurrently
-            gyd = gy
-            if ci.kind == "dense" and eng.materialize_dy:
-                # dense 3x3: every dy element is gathered 2.25-10 times by the input/weight-gradient kernels; form it once
-                dyb = new((N, Ho, Wo, Co))
-                ops.add(L.OP_DY_MAT, [Co], [float(M)], gy + [dyb.data_ptr()], 0)
-                gyd = [dyb.data_ptr(), None, None]
-            WS = 1 if eng.use_side_stream else 0
-            if WS:
-                ops.fork()
-            gin, ncols = None, 0
-            rt = red_target if (red_target is not None and need_gin) else None
-            if ci.kind == "stem":
-                nsp = max(1, min(512, _cdiv(M, 1024)))
-                sp = lib.mnas_stem_parts(1, N, Hi, Wi, Co)
-                nsp = min(sp if sp > 0 else nsp, _STEM_WGRAD_PARTS_MAX)
-                if nsp * Co * 27 > eng.scratch_wgrad.numel():
-                    raise RuntimeError("stem weight-gradient scratch too small (%d splits)" % nsp)
-                jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp, 1 if self.in_u8 else 0], [],
-                             [None] + gy + [eng.scratch_wgrad.data_ptr(), aff_ptr], WS)
-                self.patch_x_bwd = (ops, jx, 0)
-                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
-            elif ci.kind == "dw":
-                nparts = max(64, min(1024, _cdiv(M * Co, 256 * 16 * 2)))
-                gin = new((N, Hi, Wi, ci.cin))
-                red = [None, None]
-                if rt is not None:
-                    red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
-                    ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 2)
-                wsc = (next_scratch() if merge else eng.scratch_wgrad2) if ci.k in eng.dw_fused_k else eng.scratch_wgrad     # fused: main stream
-                dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), wsc.data_ptr()] + red
-                wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 3)
-                if wrows < 1 or (rt is not None and ncols < 1):
-                    raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, Co, ci.k),))
-                if ci.k in eng.dw_fused_k:
-                    # one sweep: dgrad + wgrad (+ fused reduce); both partial tables have `wrows` rows
-                    if rt is not None:
-                        ncols = wrows
-                    ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0], [], dwp, 0)
-                    if merge:
-                        queue_wgrad(ops, wsc.data_ptr(), wrows, Co, 1, ci.k * ci.k, True, eng.gptr(ci, 0))
-                    else:
-                        ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
-                else:
-                    ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
-                    ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
-                    ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
-            elif (ci.kind == "pw" and need_gin and M >= eng.pw_fused_min_pixels and lib.mnas_pw_bwd_supported(ci.cin, Co)
-                  and not (M < eng.pw_split_max_pixels and resid is None and Co < ci.cin and Co <= 128
-                           and lib.mnas_conv_gemm_parts(1, M, Co, ci.cin, 1) > 0)):
-                # large-pixel-count 1x1 conv: ONE sweep produces the input gradient, the weight-gradient partials and the
-                # fused reduce (both former kernels stream the same g, y; see csrc/mnas_pwbwd.hip).  Main stream.
-                gin = new((N, Hi, Wi, ci.cin))
-                nparts = max(1, min(eng.pw_bwd_parts_large if M >= 800000 else (eng.pw_bwd_parts_mid if M >= 100000 else eng.pw_bwd_parts_small),
-                                    _cdiv(M, 128 if max(ci.cin, Co) <= 80 else 64)))
-                red = [None, None, None]
-                if rt is not None:
-                    red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
-                    ncols = nparts
-                wsc = next_scratch() if merge else eng.scratch_wgrad2
-                ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts], [],
-                        a_in.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
-                                                gin.data_ptr(), wsc.data_ptr()] + red, 0)
-                if merge:
-                    queue_wgrad(ops, wsc.data_ptr(), nparts, Co, ci.cin, 1, False, eng.gptr(ci, 0))
-                else:
-                    ops.add(L.OP_WGRAD_FINALIZE, [nparts, Co, ci.cin, 1, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
-            else:
-                K = ci.k * ci.k * ci.cin
-                slabs = _cdiv(Co, 64) * _cdiv(K, 64)
-                nsp = max(1, min(_cdiv(1024, slabs), _cdiv(M, 256)))
-                ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
-                        a_in.act_ptrs() + gyd + [eng.scratch_wgrad.data_ptr()], WS)
-                ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
-                if need_gin:
-                    gin = new((N, Hi, Wi, ci.cin))
-                    Min = N * Hi * Wi
-                    nparts = lib.mnas_conv_gemm_parts(1, Min, Co, ci.cin, ci.k * ci.k)
-                    if nparts < 1:
-                        nparts = max(1, min(1024, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
-                    tconv = (eng.use_tconv and ci.kind == "dense" and getattr(ci, "w_tconv", None) is not None and gyd is not gy and resid is None
-                             and Hi == 2 * Ho and Wi == 2 * Wo and lib.mnas_tconv_supported(Ho, Wo, Co, ci.cin))
-                    if tconv:
-                        nparts = lib.mnas_tconv_parts(N, Ho, Wo, Co, ci.cin)
-                    elif ci.kind == "dense" and gyd is not gy and resid is None:
-                        ip = lib.mnas_conv_img_parts(1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.stride, ci.pad)
-                        nparts = ip if ip > 0 else nparts
-                    red = [None, None, None]
-                    if rt is not None:
-                        red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
-                        ncols = nparts
-                    if tconv:
-                        # stride-2 3x3: transposed convolution over the materialised dy (csrc/mnas_tconv.hip)
-                        ops.add(L.OP_TCONV_DGRAD, [N, Ho, Wo, Co, ci.cin, nparts], [],
-                                [gyd[0], ci.w_tconv.data_ptr(), gin.data_ptr(), red[0], red[1], red[2]])
-                    else:
-                        ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
-                                [None, None, None] + gyd + [ci.w_dgrad.data_ptr(), None,
-                                                           resid.data_ptr() if resid is not None else None,
-                                                           gin.data_ptr(), red[0], red[1], red[2]])
-            if ci.kind == "dw" and resid is not None:
-                raise AssertionError("residual add into a depthwise dgrad does not occur")
-            return gin, ncols
 
-        def block_bwd_irb(ops: _OpList, start, G, g_reduced, need_gin):
-            """Backward of a fused block application (csrc/mnas_irb_bwd.hip): three launches separated by the BatchNorm-backward
-            finalizes; g2 and y1 never exist in HBM.  Returns the gradient of the block input (skip gradient included) or None."""
-            re_, rd, rp = records[start], records[start + 1], records[start + 2]
-            gd, nparts = irb_blocks[start]
-            e_ci, d_ci, p_ci = re_[1], rd[1], rp[1]
-            a_in, Hi, Wi = re_[2], re_[4], re_[5]
-            C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
-            M = N * Hi * Wi
-            y2, bn_d = rd[3].data, rd[3].bn
-            y3, bn_p = rp[3].data, rp[3].bn
-            bn_e = re_[3].bn
-            econv, dconv = e_ci.mod.conv, d_ci.mod.conv
-            # ---- BatchNorm3 backward: sums of (G, y3) -- fused into G's producer when it could -- then the finalize
-            if g_reduced:
-                nred, red_buf = g_reduced, eng.scratch_red
-            else:
-                nred = max(1, min(1024, _cdiv(M * C_, 256 * 8 * 8)))
-                red_buf = eng.scratch_stats
-                ops.add(L.OP_BN_BWD_REDUCE, [C_, nred], [float(M)], [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), red_buf.data_ptr()])
-            if pend["ops"] is not None and pend["ops"] is not ops:
-                flush_post()
-            emit_post(ops, (red_buf.data_ptr(), bn_p.data_ptr(), eng.gptr(p_ci, 2), eng.gptr(p_ci, 3), nred, C_, float(M)))
-            common = a_in.act_ptrs() + [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), y2.data_ptr(), e_ci.w_fwd.data_ptr(),
-                                        p_ci.w_dgrad.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                                        bn_e.data_ptr(), bn_d.data_ptr(), d_ci.w_fwd.data_ptr()]
-            geo = [N, Hi, Wi, C_, E_, k, nparts]
-            dy3 = new((N, Hi, Wi, C_))
-            w3p = next_scratch()
-            ops.add(L.OP_IRB_BWD, geo + [0], [], common + [dy3.data_ptr(), w3p.data_ptr(), eng.scratch_red.data_ptr()], 0)
-            queue_wgrad(ops, w3p.data_ptr(), nparts, C_, E_, 1, False, eng.gptr(p_ci, 0))
-            emit_post(ops, (eng.scratch_red.data_ptr(), bn_d.data_ptr(), eng.gptr(d_ci, 2), eng.gptr(d_ci, 3), nparts, E_, float(M)))
-            g1 = new((N, Hi, Wi, E_))
-            dwp, pp = next_scratch(), next_scratch()
 
-            def split64(v):
-                return [v & 0xffffffff if (v & 0xffffffff) < 2 ** 31 else (v & 0xffffffff) - 2 ** 32,
-                        (v >> 32) if (v >> 32) < 2 ** 31 else (v >> 32) - 2 ** 32]
-            ops.add(L.OP_IRB_BWD, geo + [1] + split64(pp.data_ptr()) + split64(eng.scratch_red.data_ptr()), [],
-                    common + [dy3.data_ptr(), g1.data_ptr(), dwp.data_ptr()], 0)
-            queue_wgrad(ops, dwp.data_ptr(), nparts, E_, 1, k * k, True, eng.gptr(d_ci, 0))
-            emit_post(ops, (eng.scratch_red.data_ptr(), bn_e.data_ptr(), eng.gptr(e_ci, 2), eng.gptr(e_ci, 3), nparts, E_, float(M)))
-            ops.add(L.OP_IRB_W1_FIN, [nparts, E_, C_, 1], [],
-                    [pp.data_ptr(), gd.data_ptr(), econv.weight.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                     bn_e.data_ptr(), eng.gptr(e_ci, 0)], 0)
-            if not need_gin:
-                return None
-            gin = new((N, Hi, Wi, C_))
-            ops.add(L.OP_IRB_BWD, geo + [2], [], common + [g1.data_ptr(), gin.data_ptr(), None], 0)
-            return gin
 
-        def se_bwd(ops: _OpList, rec_index, gs):
-            """Backward of the squeeze-excite stage: gs = dL/d(a2 * s) from the project conv's input gradient -> dL/d a2, and the
-            SE parameters' gradients (accumulated into the flat buffer; shared blocks sum their applications)."""
-            se, h2, z, hb, u = se_records[rec_index]
-            E_, R_ = se.channels, se.reduced
-            HWl = h2.H * h2.W
-            m_ = se.mod
-            du = new((N, E_), torch.float32)
-            dh = new((N, R_), torch.float32)
-            dzp = new((N, E_), torch.float32)
-            ga = new((N, h2.H, h2.W, E_))
-            sb = lib.mnas_se_scratch_bytes(N, HWl, E_)
-            if sb < 0:
-                raise RuntimeError("unsupported squeeze-excite shape %s" % ((N, HWl, E_),))
-            dup = new((sb // 4,), torch.float32)
-            ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr(), dup.data_ptr()], 0)
-            # fc2: dW2 += du^T hb, db2 += sum du ; dh = (du W2) * [hb > 0]
-            ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 1, 1], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
-                                                                eng.gptr(se, 2), eng.gptr(se, 3)], 0)
-            ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 2], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
-                                                                None, None, dh.data_ptr(), hb.data_ptr()], 0)
-            # fc1: dW1 += dh^T z, db1 += sum dh ; dz = dh W1
-            ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 1, 1], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
-                                                                eng.gptr(se, 0), eng.gptr(se, 1)], 0)
-            ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 2], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
-                                                                None, None, dzp.data_ptr(), None], 0)
-            ops.add(L.OP_SE_BWD_APPLY, [N, HWl, E_], [], [gs.data_ptr(), u.data_ptr(), dzp.data_ptr(), ga.data_ptr()], 0)
-            return ga
-
-        def target_of(act: Optional[_Act]):
-            """(raw y tensor, bnbuf) of the ConvBlock that produced a VIRTUAL activation, else None."""
-            if act is None or act.bn is None:
-                return None
-            return (act.data, act.bn)
 
         g = g_final
         g_red = 0            # number of fused-reduce partial columns already written for the layer g belongs to
         self.patch_x_bwd = None
         for si in range(len(step_records) - 1, -1, -1):
             kind, stage, start, a_in, a_out = step_records[si]
-            ops = seg(stage)
+            ops = self._seg(stage)
             first = si == 0
             # what produced the step's INPUT: a ConvBlock (virtual act) or a block's residual sum / the network input
             if kind == "conv":
@@ -725,42 +339,42 @@ class Program:
                     prev_p = records[step_records[si - 1][2] + 2]
                     tgt = (prev_p[3].data, prev_p[3].bn)
                 else:
-                    tgt = target_of(rec[2])
-                g, g_red = conv_bwd(ops, rec, g, None, need, g_red, tgt)
+                    tgt = self._target_of(rec[2])
+                g, g_red = self._conv_bwd(ops, rec, g, None, need, g_red, tgt)
             else:
                 re_, rd, rp = records[start], records[start + 1], records[start + 2]
                 G = g                                   # grad wrt the block output (materialised sum)
-                if start in irb_blocks:
+                if start in self._irb_blocks:
                     if not merge:
                         raise NotImplementedError("the fused block backward needs Engine.merge_post")
-                    g = block_bwd_irb(ops, start, G, g_red, (not first) or need_dx)
+                    g = self._block_bwd_irb(ops, start, G, g_red, (not first) or need_dx)
                     g_red = 0
                     continue
-                g2, c2 = conv_bwd(ops, rp, G, None, True, g_red, target_of(rp[2]))
-                if (start + 2) in se_records:
-                    g2, c2 = se_bwd(ops, start + 2, g2), 0          # g2 becomes dL/d(activated depthwise output)
-                g1, c1 = conv_bwd(ops, rd, g2, None, True, c2, target_of(rd[2]))
+                g2, c2 = self._conv_bwd(ops, rp, G, None, True, g_red, self._target_of(rp[2]))
+                if (start + 2) in self._se_records:
+                    g2, c2 = self._se_bwd(ops, start + 2, g2), 0          # g2 becomes dL/d(activated depthwise output)
+                g1, c1 = self._conv_bwd(ops, rd, g2, None, True, c2, self._target_of(rd[2]))
                 need = (not first) or need_dx
                 if need:
                     # expand dgrad (+ skip gradient fused in its epilogue) produces the gradient of the block INPUT:
                     # either a virtual activation (producer conv) or the previous block's sum (-> its project conv)
                     if a_in.bn is not None:
-                        tgt = target_of(a_in)
+                        tgt = self._target_of(a_in)
                     elif si > 0 and step_records[si - 1][0] == "block":
                         prev_p = records[step_records[si - 1][2] + 2]
                         tgt = (prev_p[3].data, prev_p[3].bn)
                     else:
                         tgt = None
-                    g, g_red = conv_bwd(ops, re_, g1, G, True, c1, tgt)
+                    g, g_red = self._conv_bwd(ops, re_, g1, G, True, c1, tgt)
                 else:
-                    conv_bwd(ops, re_, g1, None, False, c1, None)
+                    self._conv_bwd(ops, re_, g1, None, False, c1, None)
                     g, g_red = None, 0
         if need_dx and not self.x_is_image:
             Cin = self.in_channels
-            j = seg(step_records[0][1]).add(L.OP_ADD_ACT, [Cin, H * W], [float(N * H * W)],
+            j = self._seg(step_records[0][1]).add(L.OP_ADD_ACT, [Cin, H * W], [float(N * H * W)],
                                             [g.data_ptr(), None, None, None, None, None, None, None])
             self.patch_dx = (step_records[0][1], j, 7)
-        flush_post()
+        self._flush_post()
         built = {}
         for st in order:
             # the main stream waits for the side stream's weight gradients at the end of backward, and at the end of the
@@ -779,6 +393,432 @@ class Program:
             ops_obj, idx, slot = self.patch_x_bwd
             st = [s for s in order if seg_ops[s] is ops_obj][0]
             self.patch_x_bwd = (st, idx, slot)
+
+    def _new(self, shape, dtype=torch.bfloat16):
+        t = torch.empty(shape, dtype=dtype, device=self.eng.device)
+        self.keep.append(t)
+        return t
+
+    def _bnbuf(self, C_):
+        t = torch.zeros((L_BN_ROWS, C_), dtype=torch.float32, device=self.eng.device)
+        self.keep.append(t)
+        return t
+
+    def _conv_fwd(self, ci: _ConvInfo, a_in: Optional[_Act], Hi, Wi):
+        eng, lib, dev, N, H, W, training = self.eng, self.eng.lib, self.eng.device, self.N, self.H, self.W, self.training
+        new, bnbuf, fwd, records = self._new, self._bnbuf, self._fwd, self._records
+        Ho, Wo = ci.out_hw(Hi, Wi)
+        M = N * Ho * Wo
+        y = new((N, Ho, Wo, ci.cout))
+        bn = bnbuf(ci.cout)
+        conv, bnm = ci.mod.conv, ci.mod.bn
+        bias = conv.bias.data_ptr() if conv.bias is not None else None
+        nparts = lib.mnas_conv_gemm_parts(0, M, ci.cin, ci.cout, ci.k * ci.k) if ci.kind in ("pw", "dense") else -1
+        if nparts < 1:
+            nparts = max(1, min(1024, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
+        if ci.kind == "dense":       # small maps: one image per workgroup (csrc/mnas_dimg.hip)
+            ip = lib.mnas_conv_img_parts(0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.stride, ci.pad)
+            nparts = ip if ip > 0 else nparts
+        stats = eng.scratch_stats.data_ptr() if training else None
+        if ci.kind == "stem":
+            sp = lib.mnas_stem_parts(0, N, Hi, Wi, ci.cout)
+            nparts = sp if sp > 0 else nparts
+            j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts, 1 if self.in_u8 else 0], [],
+                        [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats, self._aff_ptr])
+            self.patch_x.append((j, 0))
+        elif ci.kind == "dw":
+            nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 2)))
+            fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nlaunch], [],
+                    a_in.act_ptrs() + [ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
+            nparts = lib.mnas_dw_rows(N, Hi, Wi, ci.cout, ci.k, nlaunch, 0)      # columns of the stats table
+            if nparts < 1:
+                raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, ci.cout, ci.k),))
+        else:
+            fwd.add(L.OP_CONV_GEMM, [0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
+                    a_in.act_ptrs() + [None, None, None, ci.w_fwd.data_ptr(), bias, None, y.data_ptr(), stats])
+        fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, ci.cout, 1 if training else 0], [float(M), bnm.momentum, bnm.eps],
+                [stats, bnm.weight.data_ptr(), bnm.bias.data_ptr(), bnm.running_mean.data_ptr(),
+                 bnm.running_var.data_ptr(), bnm.num_batches_tracked.data_ptr(), bn.data_ptr()])
+        out = _Act(y, bn, Ho, Wo, ci.cout)
+        records.append(("conv", ci, a_in, out, Hi, Wi))
+        return out
+
+    def _block_fwd_fused(self, e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
+        """expand (1x1) + depthwise of an MBConv_block in ONE kernel (csrc/mnas_dw.hip, EXP forms): the expand conv's
+        BatchNorm statistics come from the covariance of the block input (csrc/mnas_gram.hip), so the expanded tensor
+        is produced straight into the depthwise kernel's LDS rings.  It is still written to HBM in training (backward
+        reads it); in eval mode it never leaves the chip.  Returns the depthwise output, or None if unsupported."""
+        eng, lib, dev, N, H, W, training = self.eng, self.eng.lib, self.eng.device, self.N, self.H, self.W, self.training
+        new, bnbuf, fwd, records = self._new, self._bnbuf, self._fwd, self._records
+        M = N * Hi * Wi
+        C_, k = d_ci.cout, d_ci.k
+        nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * C_, 256 * 16 * 2)))
+        rows = lib.mnas_dw_exp_rows(N, Hi, Wi, C_, k, e_ci.cin, nlaunch)
+        if rows < 1:
+            return None
+        econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
+        bn_e, bn_d = bnbuf(C_), bnbuf(C_)
+        if training:
+            nsplit = max(1, min(512, _cdiv(M, 2048)))
+            gsc = eng.gram_scratch(e_ci.cin, nsplit)
+            gd = torch.empty(e_ci.cin * e_ci.cin + e_ci.cin, dtype=torch.float64, device=dev)
+            self.keep.append(gd)
+            fwd.add(L.OP_GRAM, [e_ci.cin, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
+            fwd.add(L.OP_GRAM_BN, [nsplit, e_ci.cin, C_], [float(M), ebn.momentum, ebn.eps],
+                    [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
+                     econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
+                     ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
+                     gd.data_ptr(), bn_e.data_ptr()])
+        else:
+            fwd.add(L.OP_BN_FWD_FINALIZE, [1, C_, 0], [float(M), ebn.momentum, ebn.eps],
+                    [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
+                     ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
+        y1 = new((N, Hi, Wi, C_)) if training else None
+        y2 = new((N, Hi, Wi, C_))
+        stats = eng.scratch_stats.data_ptr() if training else None
+        fwd.add(L.OP_DW_EXP_FWD, [N, Hi, Wi, C_, k, e_ci.cin, nlaunch], [],
+                a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                                   bn_e.data_ptr(), bn_e.data_ptr() + 4 * C_, d_ci.w_fwd.data_ptr(),
+                                   dconv.bias.data_ptr() if dconv.bias is not None else None,
+                                   y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
+        fwd.add(L.OP_BN_FWD_FINALIZE, [rows, C_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
+                [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
+                 dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
+        h1 = _Act(y1, bn_e, Hi, Wi, C_)
+        h2 = _Act(y2, bn_d, Hi, Wi, C_)
+        records.append(("conv", e_ci, a_in, h1, Hi, Wi))
+        records.append(("conv", d_ci, h1, h2, Hi, Wi))
+        return h2
+
+    def _block_fwd_irb(self, e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
+        """expand + depthwise of an MBConv_block on the small maps (csrc/mnas_irb.hip): the expanded tensor y1 is NEVER written;
+        backward recomputes it (csrc/mnas_irb_bwd.hip).  BatchNorm1's statistics come from the covariance of the block input
+        (csrc/mnas_gram.hip); the Gram sums are kept for the expand conv's weight gradient.  Returns the depthwise output, or
+        None if the shape is not supported (then the per-layer kernels run)."""
+        eng, lib, dev, N, H, W, training = self.eng, self.eng.lib, self.eng.device, self.N, self.H, self.W, self.training
+        new, bnbuf, fwd, records = self._new, self._bnbuf, self._fwd, self._records
+        C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
+        if e_ci.cout != E_ or not lib.mnas_irb_supported(N, Hi, Wi, C_, E_, k):
+            return None
+        M = N * Hi * Wi
+        econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
+        bn_e, bn_d = bnbuf(E_), bnbuf(E_)
+        gd = None
+        if training:
+            nsplit = max(1, min(128, _cdiv(M, 1024)))
+            gsc = eng.gram_scratch(C_, nsplit)
+            gd = torch.empty(C_ * C_ + C_, dtype=torch.float64, device=dev)       # G = sum a a^T, Sx = sum a (kept for backward)
+            self.keep.append(gd)
+            fwd.add(L.OP_GRAM, [C_, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
+            fwd.add(L.OP_GRAM_BN, [nsplit, C_, E_], [float(M), ebn.momentum, ebn.eps],
+                    [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
+                     econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
+                     ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
+                     gd.data_ptr(), bn_e.data_ptr()])
+        else:
+            fwd.add(L.OP_BN_FWD_FINALIZE, [1, E_, 0], [float(M), ebn.momentum, ebn.eps],
+                    [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
+                     ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
+        nparts = lib.mnas_irb_fwd_parts(N, Hi, Wi, C_, E_, k, max(1, eng.irb_workgroups // (E_ // 32)))
+        # "fwd" mode: the fused kernel also stores y1 and the per-layer backward kernels run (they read y1 and g2)
+        keep_y1 = training and eng.fuse_irb == "fwd"
+        y1 = new((N, Hi, Wi, E_)) if keep_y1 else None
+        y2 = new((N, Hi, Wi, E_))
+        stats = eng.scratch_stats.data_ptr() if training else None
+        fwd.add(L.OP_IRB_FWD, [N, Hi, Wi, C_, E_, k, nparts], [],
+                a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                                   bn_e.data_ptr(), d_ci.w_fwd.data_ptr(),
+                                   dconv.bias.data_ptr() if dconv.bias is not None else None,
+                                   y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
+        fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, E_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
+                [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
+                 dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
+        h1 = _Act(y1, bn_e, Hi, Wi, E_)                      # full mode: the expanded activation exists only on chip
+        h2 = _Act(y2, bn_d, Hi, Wi, E_)
+        records.append(("conv", e_ci, a_in, h1, Hi, Wi))
+        records.append(("conv", d_ci, h1, h2, Hi, Wi))
+        if training and not keep_y1:
+            self._irb_blocks[len(records) - 2] = (gd, nparts)
+        return h2
+
+    def _se_fwd(self, se: _SEInfo, h2: _Act, Hi, Wi):
+        """squeeze-excite on the activated depthwise output (csrc/mnas_se.hip): pooled mean -> fc1+ReLU -> fc2 -> a2 * sigmoid.
+        Returns the MATERIALISED scaled activation the project conv reads."""
+        eng, lib, dev, N, H, W, training = self.eng, self.eng.lib, self.eng.device, self.N, self.H, self.W, self.training
+        new, bnbuf, fwd, records = self._new, self._bnbuf, self._fwd, self._records
+        E_, R_ = se.channels, se.reduced
+        z = new((N, E_), torch.float32)
+        hb = new((N, R_), torch.float32)
+        u = new((N, E_), torch.float32)
+        a2s = new((N, Hi, Wi, E_))
+        m_ = se.mod
+        fwd.add(L.OP_POOL_ACT, [N, Hi * Wi, E_], [], h2.act_ptrs() + [z.data_ptr()])
+        fwd.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 0], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), hb.data_ptr()])
+        fwd.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 0], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), m_.fc2.bias.data_ptr(), u.data_ptr()])
+        fwd.add(L.OP_SE_SCALE, [N, Hi * Wi, E_], [], h2.act_ptrs() + [u.data_ptr(), a2s.data_ptr()])
+        self._se_records[len(records)] = (se, h2, z, hb, u)        # keyed by the record index of the project conv that follows
+        return _Act(a2s, None, Hi, Wi, E_)
+
+    def _seg(self, stage):
+        if stage not in self._seg_ops:
+            self._seg_ops[stage] = _OpList(self.eng, "bwd")
+            self._order.append(stage)
+        return self._seg_ops[stage]
+
+    def _next_scratch(self):
+        b = self._rot_bufs[self._rot % 3]
+        self._rot += 1
+        return b
+
+    def _emit_post(self, ops: _OpList, bn=None):
+        pend = self._pend
+        w1, w2 = pend["w1"], pend["w2"]
+        pend["w1"] = pend["w2"] = None
+        if w1 is not None and w1[7] == 2:
+            pend["w2"] = w1[:7] + (3,)
+        if bn is None and w1 is None and w2 is None:
+            return
+        none = (None, None, 0, 0, 0, 0, 0, 0)
+        w1 = w1 or none
+        w2 = w2 or none
+        bn = bn or (None, None, None, None, 0, 0, 0.0)
+        ops.add(L.OP_BWD_POST, [bn[4], bn[5]] + list(w1[2:]) + list(w2[2:]), [bn[6]],
+                list(bn[:4]) + [w1[0], w1[1], w2[0], w2[1]], 0)
+        pend["ops"] = ops
+
+    def _flush_post(self):
+        pend = self._pend
+        while pend["w1"] is not None or pend["w2"] is not None:
+            self._emit_post(pend["ops"])
+
+    def _queue_wgrad(self, ops, partial, nsplit, Co_, Ci_, taps, dw, grad_ptr):
+        pend = self._pend
+        pend["w1"] = (partial, grad_ptr, nsplit, Co_, Ci_, taps, 1 if dw else 0, 1 if nsplit <= 256 else 2)
+        pend["ops"] = ops
+
+    def _conv_bwd(self, ops: _OpList, rec, g, resid, need_gin, g_reduced=False, red_target=None):
+        """Backward of one ConvBlock application.  g: bf16 grad wrt its activated output.
+        g_reduced: the producer of g already wrote this layer's BN-backward partial sums into
+        eng.scratch_red (fused epilogue) with `g_reduced` columns.  red_target: (y, bn, C) of the ConvBlock
+        whose activated output is THIS layer's input -- the dgrad epilogue then does that reduce.
+        Returns (gin, ncols) : bf16 grad wrt the (activated) input or None, and the number of partial
+        columns written for red_target (0 if not fused)."""
+        eng, lib, N, merge, pend, records = self.eng, self.eng.lib, self.N, self.eng.merge_post, self._pend, self._records
+        new = self._new
+        _, ci, a_in, out, Hi, Wi = rec
+        Ho, Wo, Co = out.H, out.W, ci.cout
+        M = N * Ho * Wo
+        gy = [g.data_ptr(), out.data.data_ptr(), out.bn.data_ptr()]
+        if g_reduced:
+            nred = g_reduced
+            red_buf = eng.scratch_red
+        else:
+            nred = max(1, min(1024, _cdiv(M * Co, 256 * 8 * 8)))
+            red_buf = eng.scratch_stats
+            ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), red_buf.data_ptr()])
+        if merge:
+            if pend["ops"] is not None and pend["ops"] is not ops:
+                self._flush_post()               # a stage's gradients are complete inside its own launch list
+            self._emit_post(ops, (red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3), nred, Co, float(M)))
+        else:
+            ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
+                    [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
+        # the weight-gradient kernels only share READ-ONLY inputs (g, y, the dy coefficients just finalised, the
+        # forward activations) with the input-gradient chain: they go to the side stream and run concurrently
+        gyd = gy
+        if ci.kind == "dense" and eng.materialize_dy:
+            # dense 3x3: every dy element is gathered 2.25-10 times by the input/weight-gradient kernels; form it once
+            dyb = new((N, Ho, Wo, Co))
+            ops.add(L.OP_DY_MAT, [Co], [float(M)], gy + [dyb.data_ptr()], 0)
+            gyd = [dyb.data_ptr(), None, None]
+        WS = 1 if eng.use_side_stream else 0
+        if WS:
+            ops.fork()
+        gin, ncols = None, 0
+        rt = red_target if (red_target is not None and need_gin) else None
+        if ci.kind == "stem":
+            nsp = max(1, min(512, _cdiv(M, 1024)))
+            sp = lib.mnas_stem_parts(1, N, Hi, Wi, Co)
+            nsp = min(sp if sp > 0 else nsp, _STEM_WGRAD_PARTS_MAX)
+            if nsp * Co * 27 > eng.scratch_wgrad.numel():
+                raise RuntimeError("stem weight-gradient scratch too small (%d splits)" % nsp)
+            jx = ops.add(L.OP_STEM_WGRAD, [N, Hi, Wi, Ho, Wo, Co, nsp, 1 if self.in_u8 else 0], [],
+                         [None] + gy + [eng.scratch_wgrad.data_ptr(), self._aff_ptr], WS)
+            self.patch_x_bwd = (ops, jx, 0)
+            ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+        elif ci.kind == "dw":
+            nparts = max(64, min(1024, _cdiv(M * Co, 256 * 16 * 2)))
+            gin = new((N, Hi, Wi, ci.cin))
+            red = [None, None]
+            if rt is not None:
+                red = [rt[1].data_ptr(), eng.scratch_red.data_ptr()]
+                ncols = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 2)
+            wsc = (self._next_scratch() if merge else eng.scratch_wgrad2) if ci.k in eng.dw_fused_k else eng.scratch_wgrad     # fused: main stream
+            dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), wsc.data_ptr()] + red
+            wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 1 if ci.k in eng.dw_fused_k else 3)
+            if wrows < 1 or (rt is not None and ncols < 1):
+                raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, Co, ci.k),))
+            if ci.k in eng.dw_fused_k:
+                # one sweep: dgrad + wgrad (+ fused reduce); both partial tables have `wrows` rows
+                if rt is not None:
+                    ncols = wrows
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0], [], dwp, 0)
+                if merge:
+                    self._queue_wgrad(ops, wsc.data_ptr(), wrows, Co, 1, ci.k * ci.k, True, eng.gptr(ci, 0))
+                else:
+                    ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
+            else:
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
+                ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
+        elif (ci.kind == "pw" and need_gin and M >= eng.pw_fused_min_pixels and lib.mnas_pw_bwd_supported(ci.cin, Co)
+              and not (M < eng.pw_split_max_pixels and resid is None and Co < ci.cin and Co <= 128
+                       and lib.mnas_conv_gemm_parts(1, M, Co, ci.cin, 1) > 0)):
+            # large-pixel-count 1x1 conv: ONE sweep produces the input gradient, the weight-gradient partials and the
+            # fused reduce (both former kernels stream the same g, y; see csrc/mnas_pwbwd.hip).  Main stream.
+            gin = new((N, Hi, Wi, ci.cin))
+            nparts = max(1, min(eng.pw_bwd_parts_large if M >= 800000 else (eng.pw_bwd_parts_mid if M >= 100000 else eng.pw_bwd_parts_small),
+                                _cdiv(M, 128 if max(ci.cin, Co) <= 80 else 64)))
+            red = [None, None, None]
+            if rt is not None:
+                red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
+                ncols = nparts
+            wsc = self._next_scratch() if merge else eng.scratch_wgrad2
+            ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts], [],
+                    a_in.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                            gin.data_ptr(), wsc.data_ptr()] + red, 0)
+            if merge:
+                self._queue_wgrad(ops, wsc.data_ptr(), nparts, Co, ci.cin, 1, False, eng.gptr(ci, 0))
+            else:
+                ops.add(L.OP_WGRAD_FINALIZE, [nparts, Co, ci.cin, 1, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
+        else:
+            K = ci.k * ci.k * ci.cin
+            slabs = _cdiv(Co, 64) * _cdiv(K, 64)
+            nsp = max(1, min(_cdiv(1024, slabs), _cdiv(M, 256)))
+            ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
+                    a_in.act_ptrs() + gyd + [eng.scratch_wgrad.data_ptr()], WS)
+            ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+            if need_gin:
+                gin = new((N, Hi, Wi, ci.cin))
+                Min = N * Hi * Wi
+                nparts = lib.mnas_conv_gemm_parts(1, Min, Co, ci.cin, ci.k * ci.k)
+                if nparts < 1:
+                    nparts = max(1, min(1024, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
+                tconv = (eng.use_tconv and ci.kind == "dense" and getattr(ci, "w_tconv", None) is not None and gyd is not gy and resid is None
+                         and Hi == 2 * Ho and Wi == 2 * Wo and lib.mnas_tconv_supported(Ho, Wo, Co, ci.cin))
+                if tconv:
+                    nparts = lib.mnas_tconv_parts(N, Ho, Wo, Co, ci.cin)
+                elif ci.kind == "dense" and gyd is not gy and resid is None:
+                    ip = lib.mnas_conv_img_parts(1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.stride, ci.pad)
+                    nparts = ip if ip > 0 else nparts
+                red = [None, None, None]
+                if rt is not None:
+                    red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
+                    ncols = nparts
+                if tconv:
+                    # stride-2 3x3: transposed convolution over the materialised dy (csrc/mnas_tconv.hip)
+                    ops.add(L.OP_TCONV_DGRAD, [N, Ho, Wo, Co, ci.cin, nparts], [],
+                            [gyd[0], ci.w_tconv.data_ptr(), gin.data_ptr(), red[0], red[1], red[2]])
+                else:
+                    ops.add(L.OP_CONV_GEMM, [1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
+                            [None, None, None] + gyd + [ci.w_dgrad.data_ptr(), None,
+                                                       resid.data_ptr() if resid is not None else None,
+                                                       gin.data_ptr(), red[0], red[1], red[2]])
+        if ci.kind == "dw" and resid is not None:
+            raise AssertionError("residual add into a depthwise dgrad does not occur")
+        return gin, ncols
+
+    def _block_bwd_irb(self, ops: _OpList, start, G, g_reduced, need_gin):
+        """Backward of a fused block application (csrc/mnas_irb_bwd.hip): three launches separated by the BatchNorm-backward
+        finalizes; g2 and y1 never exist in HBM.  Returns the gradient of the block input (skip gradient included) or None."""
+        eng, lib, N, merge, pend, records = self.eng, self.eng.lib, self.N, self.eng.merge_post, self._pend, self._records
+        new = self._new
+        re_, rd, rp = records[start], records[start + 1], records[start + 2]
+        gd, nparts = self._irb_blocks[start]
+        e_ci, d_ci, p_ci = re_[1], rd[1], rp[1]
+        a_in, Hi, Wi = re_[2], re_[4], re_[5]
+        C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
+        M = N * Hi * Wi
+        y2, bn_d = rd[3].data, rd[3].bn
+        y3, bn_p = rp[3].data, rp[3].bn
+        bn_e = re_[3].bn
+        econv, dconv = e_ci.mod.conv, d_ci.mod.conv
+        # ---- BatchNorm3 backward: sums of (G, y3) -- fused into G's producer when it could -- then the finalize
+        if g_reduced:
+            nred, red_buf = g_reduced, eng.scratch_red
+        else:
+            nred = max(1, min(1024, _cdiv(M * C_, 256 * 8 * 8)))
+            red_buf = eng.scratch_stats
+            ops.add(L.OP_BN_BWD_REDUCE, [C_, nred], [float(M)], [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), red_buf.data_ptr()])
+        if pend["ops"] is not None and pend["ops"] is not ops:
+            self._flush_post()
+        self._emit_post(ops, (red_buf.data_ptr(), bn_p.data_ptr(), eng.gptr(p_ci, 2), eng.gptr(p_ci, 3), nred, C_, float(M)))
+        common = a_in.act_ptrs() + [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), y2.data_ptr(), e_ci.w_fwd.data_ptr(),
+                                    p_ci.w_dgrad.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                                    bn_e.data_ptr(), bn_d.data_ptr(), d_ci.w_fwd.data_ptr()]
+        geo = [N, Hi, Wi, C_, E_, k, nparts]
+        dy3 = new((N, Hi, Wi, C_))
+        w3p = self._next_scratch()
+        ops.add(L.OP_IRB_BWD, geo + [0], [], common + [dy3.data_ptr(), w3p.data_ptr(), eng.scratch_red.data_ptr()], 0)
+        self._queue_wgrad(ops, w3p.data_ptr(), nparts, C_, E_, 1, False, eng.gptr(p_ci, 0))
+        self._emit_post(ops, (eng.scratch_red.data_ptr(), bn_d.data_ptr(), eng.gptr(d_ci, 2), eng.gptr(d_ci, 3), nparts, E_, float(M)))
+        g1 = new((N, Hi, Wi, E_))
+        dwp, pp = self._next_scratch(), self._next_scratch()
+
+        def split64(v):
+            return [v & 0xffffffff if (v & 0xffffffff) < 2 ** 31 else (v & 0xffffffff) - 2 ** 32,
+                    (v >> 32) if (v >> 32) < 2 ** 31 else (v >> 32) - 2 ** 32]
+        ops.add(L.OP_IRB_BWD, geo + [1] + split64(pp.data_ptr()) + split64(eng.scratch_red.data_ptr()), [],
+                common + [dy3.data_ptr(), g1.data_ptr(), dwp.data_ptr()], 0)
+        self._queue_wgrad(ops, dwp.data_ptr(), nparts, E_, 1, k * k, True, eng.gptr(d_ci, 0))
+        self._emit_post(ops, (eng.scratch_red.data_ptr(), bn_e.data_ptr(), eng.gptr(e_ci, 2), eng.gptr(e_ci, 3), nparts, E_, float(M)))
+        ops.add(L.OP_IRB_W1_FIN, [nparts, E_, C_, 1], [],
+                [pp.data_ptr(), gd.data_ptr(), econv.weight.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
+                 bn_e.data_ptr(), eng.gptr(e_ci, 0)], 0)
+        if not need_gin:
+            return None
+        gin = new((N, Hi, Wi, C_))
+        ops.add(L.OP_IRB_BWD, geo + [2], [], common + [g1.data_ptr(), gin.data_ptr(), None], 0)
+        return gin
+
+    def _se_bwd(self, ops: _OpList, rec_index, gs):
+        """Backward of the squeeze-excite stage: gs = dL/d(a2 * s) from the project conv's input gradient -> dL/d a2, and the
+        SE parameters' gradients (accumulated into the flat buffer; shared blocks sum their applications)."""
+        eng, lib, N, merge, pend, records = self.eng, self.eng.lib, self.N, self.eng.merge_post, self._pend, self._records
+        new = self._new
+        se, h2, z, hb, u = self._se_records[rec_index]
+        E_, R_ = se.channels, se.reduced
+        HWl = h2.H * h2.W
+        m_ = se.mod
+        du = new((N, E_), torch.float32)
+        dh = new((N, R_), torch.float32)
+        dzp = new((N, E_), torch.float32)
+        ga = new((N, h2.H, h2.W, E_))
+        sb = lib.mnas_se_scratch_bytes(N, HWl, E_)
+        if sb < 0:
+            raise RuntimeError("unsupported squeeze-excite shape %s" % ((N, HWl, E_),))
+        dup = new((sb // 4,), torch.float32)
+        ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr(), dup.data_ptr()], 0)
+        # fc2: dW2 += du^T hb, db2 += sum du ; dh = (du W2) * [hb > 0]
+        ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 1, 1], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
+                                                            eng.gptr(se, 2), eng.gptr(se, 3)], 0)
+        ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 2], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
+                                                            None, None, dh.data_ptr(), hb.data_ptr()], 0)
+        # fc1: dW1 += dh^T z, db1 += sum dh ; dz = dh W1
+        ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 1, 1], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
+                                                            eng.gptr(se, 0), eng.gptr(se, 1)], 0)
+        ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 2], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
+                                                            None, None, dzp.data_ptr(), None], 0)
+        ops.add(L.OP_SE_BWD_APPLY, [N, HWl, E_], [], [gs.data_ptr(), u.data_ptr(), dzp.data_ptr(), ga.data_ptr()], 0)
+        return ga
+
+    @staticmethod
+    def _target_of(act: Optional[_Act]):
+        """(raw y tensor, bnbuf) of the ConvBlock that produced a VIRTUAL activation, else None."""
+        if act is None or act.bn is None:
+            return None
+        return (act.data, act.bn)
+
 
     # ------------------------------------------------------------------------------------------
     def _run(self, arr, n, what):
