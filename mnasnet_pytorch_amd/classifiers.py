@@ -45,6 +45,7 @@ class FineTuneModelPool(nn.Module):
                                             nn.Dropout(), nn.Linear(512, num_classes))
         else:
             raise ValueError("Finetuning not supported on this architecture yet")
+        self.input_norm_on_device = False     # see normalize_on_device()
         self.fuse_pool = True        # see forward()
         self.native_head = True      # classifier on csrc/mnas_head.hip when it is a Dropout/Linear/ReLU chain
         self._head = None
@@ -63,12 +64,22 @@ class FineTuneModelPool(nn.Module):
         """Move the dataset's ``transforms.Normalize(self.mean, self.std)`` (datasets.py:474-516) into the stem conv's input load:
         after this the model takes UN-normalised images -- float in [0, 1] or raw uint8 (then the batch crosses PCIe at a quarter
         of the bytes of train.py:427's fp32 upload).  Off by default: the reference's loaders hand over normalised floats."""
-        eng = self.features._engine()
-        if enable:
-            eng.set_input_normalization(self.mean, self.std)
-        else:
-            eng.set_input_normalization(None, None)
+        self.input_norm_on_device = bool(enable)       # module state: survives pickling / deepcopy, re-applied to a rebuilt engine
+        self._sync_input_norm()
         return self
+
+    def _sync_input_norm(self):
+        """Make the (lazily built, never pickled) engine of ``features`` agree with ``input_norm_on_device``."""
+        if not hasattr(self.features, "_engine"):
+            return
+        want = (tuple(self.mean), tuple(self.std)) if getattr(self, "input_norm_on_device", False) else None
+        eng = self.features._engine()
+        if getattr(eng, "_in_norm_key", None) != want:
+            if want is None:
+                eng.set_input_normalization(None, None)
+            else:
+                eng.set_input_normalization(*want)
+            eng._in_norm_key = want
 
     def freeze(self):
         print("Features frozen")
@@ -89,6 +100,7 @@ class FineTuneModelPool(nn.Module):
         # classifiers.py:107-111.  features -> AdaptiveAvgPool2d(1) -> flatten is ONE engine call: the pool is fused with the
         # last BatchNorm+ReLU (mnas_pool_act) and the N x 320 x H/32 x W/32 fp32 feature map is never materialised; backward
         # starts from the pooled gradient (mnas_pool_bwd).  Any other pooling module takes the two-step path.
+        self._sync_input_norm()
         hooked = bool(self.features._forward_hooks or self.features._forward_pre_hooks or self.pooling._forward_hooks
                       or self.pooling._forward_pre_hooks)       # hooks on features / pooling must fire: take the module path
         if self.fuse_pool and not hooked and hasattr(self.features, "_engine") and self._pool_is_global_average():

@@ -364,6 +364,8 @@ class Trainer:
             # features -> pool -> head -> cross-entropy -> head backward -> features backward as plain launch lists: no
             # autograd graph, no ATen kernels (csrc/mnas_head.hip); same arithmetic as the module path below
             eng = self.engine
+            if hasattr(self.model, "_sync_input_norm"):
+                self.model._sync_input_norm()
             eng.check_input(x)                               # same checks as Engine.forward: the launch lists take raw pointers
             if not isinstance(target, torch.Tensor) or target.device != x.device:
                 raise RuntimeError("target must be a tensor on the input's device (%s)" % (x.device,))
