@@ -505,7 +505,7 @@ int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 #define MNAS_OP_BWD_POST 25
 #define MNAS_OP_TCONV_DGRAD 26
 #define MNAS_OP_IRB_FWD 27
-#define MNAS_OP_IRB_BWD 28     /* i[7] selects the launch: 0 proj, 1 dw, 2 exp */
+#define MNAS_OP_IRB_BWD 28     /* i[7] selects the launch (0 proj, 1 dw, 2 exp) and with it the pointer list: csrc/mnas_abi.hip */
 #define MNAS_OP_IRB_W1_FIN 29
 #define MNAS_OP_HEAD_LINEAR 30  /* i[5]: 0 forward, 1 weight gradient, 2 input gradient */
 #define MNAS_OP_SE_SCALE 31

@@ -1,7 +1,6 @@
 // ABI glue: version query and the batched launcher (one host->library transition per forward / backward
 // segment instead of ~450 ctypes calls per training step).
 #include "mnas_common.h"
-#include <cstring>
 
 #define MNAS_NT_DEFAULT MNAS_NT_PWF
 int mnas_nt_mask() {
@@ -76,8 +75,7 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //                   p: bn_partial,bnbuf,dgamma,dbeta, w1.partial,w1.grad, w2.partial,w2.grad
 //  TCONV_DGRAD      i: N,Ho,Wo,Co,Ci,nparts                       p: dy,w,out,stats,red_y,red_bn
 //  IRB_FWD          i: N,H,W,C,E,k,nparts          p: x.data,x.scale,x.shift, w1,b1,bn1,wdw,bdw,y1,y2,stats
-//  IRB_BWD          i: N,H,W,C,E,k,nparts,which    p: x.data,x.scale,x.shift, gout.g,gout.y,gout.coef, y2,w1,w3t,b1,bn1,bn2,wdw,
-//                                                     dy3,g1,dx  + second op record? no: outputs by `which`: see below
+//  IRB_BWD          i: N,H,W,C,E,k,nparts,which    p: per launch (which = 0 proj, 1 dw, 2 exp): listed at the case below
 //  IRB_W1_FIN       i: nparts,E,C,accumulate       p: ppartial,gsum,w1,b1,bn1,grad
 //  HEAD_LINEAR      i: N,I,O,relu,accumulate,which   p: x,w,b,y,dz,dw,db,dx,relu_mask        (no dropout in launch lists)
 //  SE_SCALE         i: N,HW,C                      p: a.data,a.scale,a.shift, u, out
@@ -218,23 +216,26 @@ static int run_one(const MnasOp& o, void* stream) {
             return mnas_irb_fwd(&a, stream);
         }
         case MNAS_OP_IRB_BWD: {
-            // outputs share p[13..15] by launch: proj: dy3, w3partial, red2; dw: (dy3 in p[13]) g1 p[14], dwpartial p[15] and
-            // ppartial, red1 in d[] is not possible -> the dw launch takes its two extra tables from the int-encoded offsets:
-            // to keep MnasOp flat, the dw launch's ppartial / red1 ride in i[8..11] as two 64-bit pointers.
             MnasIrbBwd a = {};
             a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.E = i[4]; a.k = i[5]; a.nparts = i[6];
-            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
-            a.gout.g = p[3]; a.gout.y = p[4]; a.gout.coef = (const float*)p[5];
-            a.y2 = p[6]; a.w1 = p[7]; a.w3t = p[8]; a.b1 = (const float*)p[9]; a.bn1 = (const float*)p[10];
-            a.bn2 = (const float*)p[11]; a.wdw = (const float*)p[12];
-            uint64_t q0, q1;
-            memcpy(&q0, &i[8], 8); memcpy(&q1, &i[10], 8);
-            if (i[7] == 0) { a.dy3 = p[13]; a.w3partial = (float*)p[14]; a.red2 = (float*)p[15]; return mnas_irb_bwd_proj(&a, stream); }
-            if (i[7] == 1) {
-                a.dy3 = p[13]; a.g1 = p[14]; a.dwpartial = (float*)p[15]; a.ppartial = (float*)(uintptr_t)q0; a.red1 = (float*)(uintptr_t)q1;
+            if (i[7] == 0) {            // p: G, y3, bnbuf3, y2, bn2, w3t, dy3, w3partial, red2
+                a.gout.g = p[0]; a.gout.y = p[1]; a.gout.coef = (const float*)p[2];
+                a.y2 = p[3]; a.bn2 = (const float*)p[4]; a.w3t = p[5];
+                a.dy3 = p[6]; a.w3partial = (float*)p[7]; a.red2 = (float*)p[8];
+                return mnas_irb_bwd_proj(&a, stream);
+            }
+            if (i[7] == 1) {            // p: x.data,x.scale,x.shift, dy3, y2, w1, w3t, b1, bn1, bn2, wdw, g1, dwpartial, ppartial, red1
+                a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
+                a.dy3 = p[3]; a.y2 = p[4]; a.w1 = p[5]; a.w3t = p[6]; a.b1 = (const float*)p[7]; a.bn1 = (const float*)p[8];
+                a.bn2 = (const float*)p[9]; a.wdw = (const float*)p[10];
+                a.g1 = p[11]; a.dwpartial = (float*)p[12]; a.ppartial = (float*)p[13]; a.red1 = (float*)p[14];
                 return mnas_irb_bwd_dw(&a, stream);
             }
-            if (i[7] == 2) { a.g1 = p[13]; a.dx = p[14]; return mnas_irb_bwd_exp(&a, stream); }
+            if (i[7] == 2) {            // p: x.data,x.scale,x.shift, g1, w1, b1, bn1, G (skip gradient or NULL), dx
+                a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
+                a.g1 = p[3]; a.w1 = p[4]; a.b1 = (const float*)p[5]; a.bn1 = (const float*)p[6]; a.gout.g = p[7]; a.dx = p[8];
+                return mnas_irb_bwd_exp(&a, stream);
+            }
             return MNAS_EINVAL;
         }
         case MNAS_OP_IRB_W1_FIN:

@@ -753,32 +753,30 @@ class Program:
         if pend["ops"] is not None and pend["ops"] is not ops:
             self._flush_post()
         self._emit_post(ops, (red_buf.data_ptr(), bn_p.data_ptr(), eng.gptr(p_ci, 2), eng.gptr(p_ci, 3), nred, C_, float(M)))
-        common = a_in.act_ptrs() + [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), y2.data_ptr(), e_ci.w_fwd.data_ptr(),
-                                    p_ci.w_dgrad.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                                    bn_e.data_ptr(), bn_d.data_ptr(), d_ci.w_fwd.data_ptr()]
+        b1p = econv.bias.data_ptr() if econv.bias is not None else None
         geo = [N, Hi, Wi, C_, E_, k, nparts]
         dy3 = new((N, Hi, Wi, C_))
         w3p = self._next_scratch()
-        ops.add(L.OP_IRB_BWD, geo + [0], [], common + [dy3.data_ptr(), w3p.data_ptr(), eng.scratch_red.data_ptr()], 0)
+        ops.add(L.OP_IRB_BWD, geo + [0], [],
+                [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), y2.data_ptr(), bn_d.data_ptr(), p_ci.w_dgrad.data_ptr(),
+                 dy3.data_ptr(), w3p.data_ptr(), eng.scratch_red.data_ptr()], 0)
         self._queue_wgrad(ops, w3p.data_ptr(), nparts, C_, E_, 1, False, eng.gptr(p_ci, 0))
         self._emit_post(ops, (eng.scratch_red.data_ptr(), bn_d.data_ptr(), eng.gptr(d_ci, 2), eng.gptr(d_ci, 3), nparts, E_, float(M)))
         g1 = new((N, Hi, Wi, E_))
         dwp, pp = self._next_scratch(), self._next_scratch()
-
-        def split64(v):
-            return [v & 0xffffffff if (v & 0xffffffff) < 2 ** 31 else (v & 0xffffffff) - 2 ** 32,
-                    (v >> 32) if (v >> 32) < 2 ** 31 else (v >> 32) - 2 ** 32]
-        ops.add(L.OP_IRB_BWD, geo + [1] + split64(pp.data_ptr()) + split64(eng.scratch_red.data_ptr()), [],
-                common + [dy3.data_ptr(), g1.data_ptr(), dwp.data_ptr()], 0)
+        ops.add(L.OP_IRB_BWD, geo + [1], [],
+                a_in.act_ptrs() + [dy3.data_ptr(), y2.data_ptr(), e_ci.w_fwd.data_ptr(), p_ci.w_dgrad.data_ptr(), b1p, bn_e.data_ptr(),
+                                   bn_d.data_ptr(), d_ci.w_fwd.data_ptr(), g1.data_ptr(), dwp.data_ptr(), pp.data_ptr(),
+                                   eng.scratch_red.data_ptr()], 0)
         self._queue_wgrad(ops, dwp.data_ptr(), nparts, E_, 1, k * k, True, eng.gptr(d_ci, 0))
         self._emit_post(ops, (eng.scratch_red.data_ptr(), bn_e.data_ptr(), eng.gptr(e_ci, 2), eng.gptr(e_ci, 3), nparts, E_, float(M)))
         ops.add(L.OP_IRB_W1_FIN, [nparts, E_, C_, 1], [],
-                [pp.data_ptr(), gd.data_ptr(), econv.weight.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                 bn_e.data_ptr(), eng.gptr(e_ci, 0)], 0)
+                [pp.data_ptr(), gd.data_ptr(), econv.weight.data_ptr(), b1p, bn_e.data_ptr(), eng.gptr(e_ci, 0)], 0)
         if not need_gin:
             return None
         gin = new((N, Hi, Wi, C_))
-        ops.add(L.OP_IRB_BWD, geo + [2], [], common + [g1.data_ptr(), gin.data_ptr(), None], 0)
+        ops.add(L.OP_IRB_BWD, geo + [2], [],
+                a_in.act_ptrs() + [g1.data_ptr(), e_ci.w_fwd.data_ptr(), b1p, bn_e.data_ptr(), G.data_ptr(), gin.data_ptr()], 0)
         return gin
 
     def _se_bwd(self, ops: _OpList, rec_index, gs):
