@@ -349,6 +349,8 @@ def main():
         eng.fuse_irb = {"full": "full", "fwd": "fwd", "off": False}[os.environ["MNAS_IRB"]]
     if os.environ.get("MNAS_IRB_WGS"):       # diagnosis only: workgroups per fused-block launch
         eng.irb_workgroups = int(os.environ["MNAS_IRB_WGS"])
+    if os.environ.get("MNAS_WGRAD_WGS"):     # diagnosis only: workgroups per k_wgrad launch
+        eng.wgrad_wgs = int(os.environ["MNAS_WGRAD_WGS"])
     if os.environ.get("MNAS_FUSE"):          # diagnosis only: fused expand + depthwise forward kernels (measured slower)
         eng.fuse_expand = True
     if os.environ.get("MNAS_DW5_SPLIT"):     # diagnosis only: two-launch backward for the 5x5 depthwise layers
