@@ -440,12 +440,16 @@ int mnas_head_cross_entropy(const void* logits, const void* target, int N, int C
  *   mnas_se_scale      : out = act(a) * sigmoid(u)[n][c]            (bf16 (N,HW,C): what the project conv then reads)
  *   mnas_se_bwd_reduce : du[n][c] = (sum_hw gs * act(a)) * s (1 - s), s = sigmoid(u)   (gs = dL/d out, bf16); scratch =
  *                        mnas_se_scratch_bytes(N, HW, C) bytes of partial sums (pixel splits, added in a fixed order)
- *   mnas_se_bwd_apply  : out = gs * sigmoid(u) + dz[n][c] / HW      (dz = dL/d(pooled a) from the MLP backward; out = dL/d act(a)) */
+ *   mnas_se_bwd_apply  : out = gs * sigmoid(u) + dz[n][c] / HW      (dz = dL/d(pooled a) from the MLP backward; out = dL/d act(a));
+ *                        optional fused BatchNorm-backward reduce of the ConvBlock whose activated output `out` is the gradient of:
+ *                        red_partial float[2][C][mnas_se_bwd_apply_cols(N,HW,C)] from (out, red_y, red_bn), as mnas_bn_bwd_reduce */
 int mnas_se_scale(const MnasActIn* a, const float* u, int N, int HW, int C, void* out_bf16, void* stream);
 int mnas_se_bwd_reduce(const void* gs, const MnasActIn* a, const float* u, int N, int HW, int C, float* du, float* scratch,
                        void* stream);
 int64_t mnas_se_scratch_bytes(int N, int HW, int C);
-int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16, void* stream);
+int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16,
+                      const void* red_y, const float* red_bn, float* red_partial, void* stream);
+int mnas_se_bwd_apply_cols(int N, int HW, int C);
 
 /* ---- weight packing (fp32 reference layout [Co][Ci/g][kh][kw] -> kernel layouts) -------------------- */
 #define MNAS_PACK_FWD   0   /* bf16 [Co_pad16][Kpad32], k = tap*Ci+ci            (mnas_conv_gemm mode 0) */

@@ -149,7 +149,8 @@ SYMBOLS = {
     "mnas_se_scale": (c_int, [C.POINTER(MnasActIn), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mnas_se_bwd_reduce": (c_int, [c_void_p, C.POINTER(MnasActIn), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mnas_se_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
-    "mnas_se_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_se_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnas_se_bwd_apply_cols": (c_int, [c_int, c_int, c_int]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),
     "mnas_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),

@@ -80,7 +80,7 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  HEAD_LINEAR      i: N,I,O,relu,accumulate,which   p: x,w,b,y,dz,dw,db,dx,relu_mask        (no dropout in launch lists)
 //  SE_SCALE         i: N,HW,C                      p: a.data,a.scale,a.shift, u, out
 //  SE_BWD_REDUCE    i: N,HW,C                      p: gs, a.data,a.scale,a.shift, u, du, scratch
-//  SE_BWD_APPLY     i: N,HW,C                      p: gs, u, dz, out
+//  SE_BWD_APPLY     i: N,HW,C                      p: gs, u, dz, out, red_y, red_bn, red_partial
 //  PW_BWD           i: M,Ci,Co,nparts   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,resid,gin,wpartial, red_partial,red_y,red_bn
 static int run_one(const MnasOp& o, void* stream) {
     const int32_t* i = o.i;
@@ -259,7 +259,8 @@ static int run_one(const MnasOp& o, void* stream) {
             return mnas_se_bwd_reduce(p[0], &a, (const float*)p[4], i[0], i[1], i[2], (float*)p[5], (float*)p[6], stream);
         }
         case MNAS_OP_SE_BWD_APPLY:
-            return mnas_se_bwd_apply(p[0], (const float*)p[1], (const float*)p[2], i[0], i[1], i[2], p[3], stream);
+            return mnas_se_bwd_apply(p[0], (const float*)p[1], (const float*)p[2], i[0], i[1], i[2], p[3], p[4], (const float*)p[5],
+                                     (float*)p[6], stream);
         case MNAS_OP_DY_MAT: {
             MnasGradIn d = {p[0], p[1], (const float*)p[2]};
             return mnas_dy_materialize(&d, (int64_t)o.d[0], i[0], p[3], stream);

@@ -87,25 +87,64 @@ __global__ __launch_bounds__(256) void k_se_bwd_finish(const float* __restrict__
     du[i] = v * sg * (1.f - sg);
 }
 
+// RED: also the BatchNorm-backward reduce of the depthwise conv whose activated output `out` is the gradient of (red_y = its raw
+// output, red_bn = its bnbuf): partial (sum dz, sum dz*xhat) per workgroup, dz = out * [s*y+t > 0] with out AS STORED (bf16) --
+// exactly what mnas_bn_bwd_reduce would compute from (out, red_y, red_bn) in a separate pass over both tensors.
+template <bool RED>
 __global__ __launch_bounds__(256) void k_se_bwd_apply(const uint4* __restrict__ gs, const float* __restrict__ u, const float* __restrict__ dz,
-                                                      SeGeom g, uint4* __restrict__ out) {
+                                                      SeGeom g, uint4* __restrict__ out, const uint4* __restrict__ red_y,
+                                                      const float* __restrict__ red_bn, float* __restrict__ red_partial) {
+    extern __shared__ float red[];                                  // RED: [R][2][C]
     const int n = blockIdx.x, cg = threadIdx.x % g.G, pr = threadIdx.x / g.G;
-    if (pr >= g.R) return;
-    float sg[8], zz[8];
-    const float inv = 1.f / (float)g.HW;
+    float r1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pr < g.R) {
+        float sg[8], zz[8], bs[8], bt[8], bi[8], bm[8];
+        const float inv = 1.f / (float)g.HW;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sg[j] = se_sigmoid(u[(size_t)n * g.C + cg * 8 + j]);
-        zz[j] = dz[(size_t)n * g.C + cg * 8 + j] * inv;
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            sg[j] = se_sigmoid(u[(size_t)n * g.C + c]);
+            zz[j] = dz[(size_t)n * g.C + c] * inv;
+            if (RED) {
+                bs[j] = red_bn[c]; bt[j] = red_bn[g.C + c]; bi[j] = red_bn[6 * g.C + c];
+                bm[j] = -red_bn[5 * g.C + c] * red_bn[6 * g.C + c];
+            }
+        }
+        const int p0 = blockIdx.y * g.chunk, p1 = min(g.HW, p0 + g.chunk);
+        const size_t base = (size_t)n * g.HW * g.G + cg;
+        for (int p = p0 + pr; p < p1; p += g.R) {
+            float gq[8];
+            unpack8(gs[base + (size_t)p * g.G], gq);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gq[j] = fmaf(gq[j], sg[j], zz[j]);
+            const uint4 o = pack8(gq);
+            out[base + (size_t)p * g.G] = o;
+            if (RED) {
+                float y[8], q[8];
+                unpack8(red_y[base + (size_t)p * g.G], y);
+                unpack8(o, q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = (fmaf(y[j], bs[j], bt[j]) > 0.f) ? q[j] : 0.f;
+                    r1[j] += d;
+                    r2[j] = fmaf(d, fmaf(y[j], bi[j], bm[j]), r2[j]);
+                }
+            }
+        }
     }
-    const int p0 = blockIdx.y * g.chunk, p1 = min(g.HW, p0 + g.chunk);
-    const size_t base = (size_t)n * g.HW * g.G + cg;
-    for (int p = p0 + pr; p < p1; p += g.R) {
-        float gq[8];
-        unpack8(gs[base + (size_t)p * g.G], gq);
+    if (RED) {
+        if (pr < g.R) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gq[j] = fmaf(gq[j], sg[j], zz[j]);
-        out[base + (size_t)p * g.G] = pack8(gq);
+            for (int j = 0; j < 8; ++j) { red[(pr * 2 + 0) * g.C + cg * 8 + j] = r1[j]; red[(pr * 2 + 1) * g.C + cg * 8 + j] = r2[j]; }
+        }
+        __syncthreads();
+        const int col = blockIdx.x * gridDim.y + blockIdx.y, ncols = gridDim.x * gridDim.y;
+        for (int i = threadIdx.x; i < 2 * g.C; i += 256) {
+            const int r = i / g.C, c = i - r * g.C;
+            float v = 0.f;
+            for (int k = 0; k < g.R; ++k) v += red[(k * 2 + r) * g.C + c];           // fixed order: deterministic
+            red_partial[((size_t)r * g.C + c) * ncols + col] = v;
+        }
     }
 }
 
@@ -114,7 +153,7 @@ static bool se_geom(int N, int HW, int C, SeGeom* g, int* splits) {
     if (N < 1 || HW < 1 || C < 8 || (C & 7) || C > 2048) return false;
     g->G = C >> 3; g->R = 256 / g->G; g->HW = HW; g->C = C;
     if (g->R < 1) return false;
-    int sp = (2048 + N - 1) / N;
+    int sp = 2048 / N;                                               // N * splits <= 2048: the fused reduce's table has one column per workgroup
     const int maxsp = (HW + g->R * 4 - 1) / (g->R * 4);              // at least 4 pixels per thread
     if (sp > maxsp) sp = maxsp;
     if (sp < 1) sp = 1;
@@ -148,10 +187,24 @@ extern "C" int mnas_se_bwd_reduce(const void* gs, const MnasActIn* a, const floa
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
-extern "C" int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16, void* stream) {
+extern "C" int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16,
+                                 const void* red_y, const float* red_bn, float* red_partial, void* stream) {
     SeGeom g; int sp;
     if (!gs || !u || !dz || !out_bf16 || !se_geom(N, HW, C, &g, &sp)) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_se_bwd_apply, dim3(N, sp), dim3(256), 0, (hipStream_t)stream, (const uint4*)gs, u, dz, g, (uint4*)out_bf16);
+    if (red_partial) {
+        if (!red_y || !red_bn) return MNAS_EINVAL;
+        hipLaunchKernelGGL(k_se_bwd_apply<true>, dim3(N, sp), dim3(256), (size_t)g.R * 2 * C * sizeof(float), (hipStream_t)stream,
+                           (const uint4*)gs, u, dz, g, (uint4*)out_bf16, (const uint4*)red_y, red_bn, red_partial);
+    } else {
+        hipLaunchKernelGGL(k_se_bwd_apply<false>, dim3(N, sp), dim3(256), 0, (hipStream_t)stream, (const uint4*)gs, u, dz, g,
+                           (uint4*)out_bf16, (const uint4*)nullptr, (const float*)nullptr, (float*)nullptr);
+    }
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
+}
+// columns of the fused reduce table mnas_se_bwd_apply writes (= N * pixel splits), or -1
+extern "C" int mnas_se_bwd_apply_cols(int N, int HW, int C) {
+    SeGeom g; int sp;
+    if (!se_geom(N, HW, C, &g, &sp)) return -1;
+    return N * sp;
 }

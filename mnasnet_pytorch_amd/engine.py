@@ -352,7 +352,7 @@ class Program:
                     continue
                 g2, c2 = self._conv_bwd(ops, rp, G, None, True, g_red, self._target_of(rp[2]))
                 if (start + 2) in self._se_records:
-                    g2, c2 = self._se_bwd(ops, start + 2, g2), 0          # g2 becomes dL/d(activated depthwise output)
+                    g2, c2 = self._se_bwd(ops, start + 2, g2)             # g2 becomes dL/d(activated depthwise output)
                 g1, c1 = self._conv_bwd(ops, rd, g2, None, True, c2, self._target_of(rd[2]))
                 need = (not first) or need_dx
                 if need:
@@ -807,8 +807,13 @@ class Program:
                                                             eng.gptr(se, 0), eng.gptr(se, 1)], 0)
         ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 2], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
                                                             None, None, dzp.data_ptr(), None], 0)
-        ops.add(L.OP_SE_BWD_APPLY, [N, HWl, E_], [], [gs.data_ptr(), u.data_ptr(), dzp.data_ptr(), ga.data_ptr()], 0)
-        return ga
+        # the BatchNorm2-backward reduce of the depthwise conv rides in the same pass (ga is its g; h2 = its raw output + bnbuf)
+        ncols = lib.mnas_se_bwd_apply_cols(N, HWl, E_)
+        fused = h2.bn is not None and 0 < ncols <= _STATS_PARTS
+        ops.add(L.OP_SE_BWD_APPLY, [N, HWl, E_], [],
+                [gs.data_ptr(), u.data_ptr(), dzp.data_ptr(), ga.data_ptr()] +
+                ([h2.data.data_ptr(), h2.bn.data_ptr(), eng.scratch_red.data_ptr()] if fused else [None, None, None]), 0)
+        return ga, (ncols if fused else 0)
 
     @staticmethod
     def _target_of(act: Optional[_Act]):

@@ -45,8 +45,26 @@ def test_se_kernels(shape, virt):
                                    L.cur_stream()), "se_bwd_reduce")
     assert relerr(du.cpu(), (gs * a).sum((2, 3)) * sg * (1 - sg)) < 2e-3
     ga = torch.full((N, H, W, Cc), float("nan"), dtype=torch.bfloat16, device="cuda")
-    L.check(lib.mnas_se_bwd_apply(gsd.data_ptr(), ud.data_ptr(), dzd.data_ptr(), N, HW, Cc, ga.data_ptr(), L.cur_stream()), "se_bwd_apply")
-    assert relerr(from_nhwc(ga), gs * sg[:, :, None, None] + dz[:, :, None, None] / HW) < 6e-3
+    L.check(lib.mnas_se_bwd_apply(gsd.data_ptr(), ud.data_ptr(), dzd.data_ptr(), N, HW, Cc, ga.data_ptr(), None, None, None,
+                                  L.cur_stream()), "se_bwd_apply")
+    ga_ref = gs * sg[:, :, None, None] + dz[:, :, None, None] / HW
+    assert relerr(from_nhwc(ga), ga_ref) < 6e-3
+    # ... with the fused BatchNorm-backward reduce of the conv that produced y (bnbuf rows 0,1,5,6)
+    ncols = lib.mnas_se_bwd_apply_cols(N, HW, Cc)
+    bn = torch.zeros(8, Cc)
+    bn[0], bn[1], bn[5], bn[6] = s, t, 0.1 * O.det_uniform((Cc,), 806), 1.0 + 0.2 * O.det_uniform((Cc,), 807).abs()
+    bnd = bn.cuda().contiguous()
+    part = torch.full((2, Cc, ncols), float("nan"), device="cuda")
+    ga2 = torch.empty_like(ga)
+    L.check(lib.mnas_se_bwd_apply(gsd.data_ptr(), ud.data_ptr(), dzd.data_ptr(), N, HW, Cc, ga2.data_ptr(), yd.data_ptr(), bnd.data_ptr(),
+                                  part.data_ptr(), L.cur_stream()), "se_bwd_apply+reduce")
+    assert torch.equal(ga2, ga)
+    gq = from_nhwc(ga2)
+    v = lambda r: bn[r].view(1, -1, 1, 1)
+    dzr = (gq * ((v(0) * y + v(1)) > 0)).double()
+    xh = ((y - v(5)) * v(6)).double()
+    st = part.cpu().double().sum(-1)
+    assert relerr(st[0], dzr.sum((0, 2, 3))) < 2e-3 and relerr(st[1], (dzr * xh).sum((0, 2, 3))) < 2e-3
 
 
 SE_STAGES = {
