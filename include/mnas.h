@@ -136,6 +136,9 @@ typedef struct MnasConvWgrad {
     float* partial;
 } MnasConvWgrad;
 int mnas_conv_wgrad(const MnasConvWgrad* a, void* stream);
+/* Number of (cout x k) slabs mnas_conv_wgrad splits dW[Co][taps*Ci] into (the slab shape is chosen per (Co, K)): a launch
+ * runs nsplit x slabs workgroups, so callers size nsplit as (workgroup budget) / slabs. */
+int mnas_conv_wgrad_slabs(int Co, int Ci, int taps);
 
 /* grad[co][ci][kh][kw] (reference layout, fp32) (+)= sum_s partial[s][co][tap*Ci+ci].  Deterministic (fixed summation
  * order, no atomics).  `partial` is scratch: with more than 256 splits the first row of every 128-row chunk is

@@ -158,6 +158,7 @@ SYMBOLS = {
     "mnas_conv_gemm_tile_pixels": (c_int, [c_int, c_int, c_int]),
     "mnas_conv_gemm_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mnas_conv_wgrad": (c_int, [C.POINTER(MnasConvWgrad), c_void_p]),
+    "mnas_conv_wgrad_slabs": (c_int, [c_int, c_int, c_int]),
     "mnas_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mnas_pw_bwd": (c_int, [C.POINTER(MnasPwBwd), c_void_p]),
     "mnas_pw_bwd_supported": (c_int, [c_int, c_int]),

@@ -240,6 +240,223 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_wgrad_t<CT,KT>: the same GEMM with a (32*CT cout) x (32*KT k) slab per workgroup.  The 4 waves tile the SLAB 2x2 (a wave
+// owns CT x KT MFMA tiles for ALL pixels of the workgroup's range) instead of splitting the pixels of a 64x64 slab four ways:
+// every staged 16 bytes feed (CT*KT)/4 times the MFMAs of k_wgrad<false>'s layout, each operand is re-read from L2
+// Co/(32 CT) resp. K/(32 KT) times instead of Co/64, K/64 times, and there is no cross-wave reduction at the end (the
+// accumulators go straight to partial[split]).  Pixel chunks of 64 (two MFMA k-steps), LDS tiles double-buffered: ONE barrier
+// per chunk; the global loads of chunk c+2 are in flight while chunk c is multiplied.  Row pitch = tile + 16 elements: the four
+// rows a 16-lane group of ds_read_b64_tr_b16 touches land in four disjoint 8-bank windows.
+// ------------------------------------------------------------------------------------------------
+#define WT_BP 64
+template <int CT, int KT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_t(WgradArgs a) {
+    constexpr int COT = 32 * CT, KTT = 32 * KT, LDD = COT + 16, LDA = KTT + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int co0 = blockIdx.y * COT, kc0 = blockIdx.z * KTT;
+    const int xcols = (a.taps == 1) ? KTT : a.Ci;
+    float* lds_cd = (float*)smem;                         // [5][COT]   dy coefficients for couts co0..
+    float* lds_cx = lds_cd + 5 * COT;                     // [2][xcols] scale/shift of x
+    uint16_t* tile_d = (uint16_t*)(lds_cx + 2 * xcols);   // [2][64][LDD]
+    uint16_t* tile_a = tile_d + 2 * WT_BP * LDD;          // [2][64][LDA]
+
+    const bool hasdy = a.dy.coef != nullptr;              // false: dy.g is a materialised dy
+    for (int i = tid; i < 5 * COT; i += 256) {
+        const int r = i / COT, c = co0 + i % COT;
+        lds_cd[i] = (hasdy && c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
+    }
+    const bool hasx = a.x.scale != nullptr;
+    if (hasx)
+        for (int i = tid; i < 2 * xcols; i += 256) {
+            const int r = i / xcols, c = (a.taps == 1 ? kc0 : 0) + i % xcols;
+            lds_cx[i] = (c < a.Ci) ? (r == 0 ? a.x.scale[c] : a.x.shift[c]) : 0.f;
+        }
+
+    // ---- per-thread staging plan (chunk-invariant): CT dy slots and KT x slots of 16 bytes; a slot outside the tensor's
+    // channels writes zeros, so the MFMA tiles past the slab's valid edge multiply zeros
+    int pd[CT], cd8[CT], pa[KT], ca8[KT], aci[KT], ath[KT], atw[KT];
+    bool vd[CT], va[KT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int q = tid + 256 * i;
+        pd[i] = q / (4 * CT); cd8[i] = q - pd[i] * (4 * CT);
+        vd[i] = co0 + cd8[i] * 8 < a.Co;
+    }
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+        const int q = tid + 256 * i;
+        pa[i] = q / (4 * KT); ca8[i] = q - pa[i] * (4 * KT);
+        const int k = kc0 + ca8[i] * 8;
+        va[i] = k < a.Ktot;
+        aci[i] = k; ath[i] = 0; atw[i] = 0;
+        if (!a.is_pw) {
+            const int tap = k / a.Ci;
+            aci[i] = k - tap * a.Ci;
+            ath[i] = tap / a.kw; atw[i] = tap - ath[i] * a.kw;
+        }
+    }
+
+    f32x4_t acc[CT][KT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // valid 16-wide tiles of this wave's part of the slab
+    const int ctn = max(0, min(CT, (min(COT, a.Co - co0) - wr * CT * 16 + 15) >> 4));
+    const int ktn = max(0, min(KT, (min(KTT, a.Ktot - kc0) - wc * KT * 16 + 15) >> 4));
+
+    const int p_begin = blockIdx.x * a.chunk;
+    const int p_end = min(a.M, p_begin + a.chunk);
+    const int nch = (p_end - p_begin + WT_BP - 1) / WT_BP;
+    uint4 vg[CT], vy[CT], vx[KT];
+    unsigned okd = 0, oka = 0;
+    const int hw = a.Ho * a.Wo;
+    auto issue = [&](int pc) {
+        okd = 0; oka = 0;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            vg[i] = make_uint4(0, 0, 0, 0); vy[i] = make_uint4(0, 0, 0, 0);
+            const int m = pc + pd[i];
+            if (vd[i] && m < p_end) {
+                okd |= 1u << i;
+                const size_t off = (size_t)m * a.Co + co0 + cd8[i] * 8;
+                vg[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
+                if (hasdy) vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            vx[i] = make_uint4(0, 0, 0, 0);
+            const int m = pc + pa[i];
+            if (!va[i] || m >= p_end) continue;
+            size_t src;
+            bool inb = true;
+            if (a.is_pw) {
+                src = (size_t)m * a.Ci + aci[i];
+            } else {
+                const int n = m / hw, rem = m - n * hw;
+                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                const int ih = oh * a.stride + ath[i] - a.pad, iw = ow * a.stride + atw[i] - a.pad;
+                inb = ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                src = (((size_t)n * a.Hi + ih) * a.Wi + iw) * a.Ci + aci[i];
+            }
+            if (inb) {
+                oka |= 1u << i;
+                vx[i] = *(const uint4*)((const uint16_t*)a.x.data + src);
+            }
+        }
+    };
+    auto stage = [&](int buf) {       // transform + LDS write of the chunk held in vg / vy / vx
+        uint16_t* td = tile_d + buf * WT_BP * LDD;
+        uint16_t* ta = tile_a + buf * WT_BP * LDA;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            uint4 v = vg[i];                                  // materialised dy (mnas_dy_materialize): no transform; zeros when masked
+            if (hasdy && ((okd >> i) & 1)) {
+                float cf[5][8];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    *(float4*)&cf[r][0] = *(const float4*)(lds_cd + r * COT + cd8[i] * 8);
+                    *(float4*)&cf[r][4] = *(const float4*)(lds_cd + r * COT + cd8[i] * 8 + 4);
+                }
+                float o[8];
+                dy8(vg[i], vy[i], cf[0], cf[1], cf[2], cf[3], cf[4], o);
+                v = pack8(o);
+            }
+            *(uint4*)(td + pd[i] * LDD + cd8[i] * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            uint4 v = vx[i];
+            if (hasx && ((oka >> i) & 1)) {
+                const int cc = (a.taps == 1) ? ca8[i] * 8 : aci[i];
+                float s[8], t[8];
+                *(float4*)&s[0] = *(const float4*)(lds_cx + cc);
+                *(float4*)&s[4] = *(const float4*)(lds_cx + cc + 4);
+                *(float4*)&t[0] = *(const float4*)(lds_cx + xcols + cc);
+                *(float4*)&t[4] = *(const float4*)(lds_cx + xcols + cc + 4);
+                v = act8(v, s, t);
+            }
+            *(uint4*)(ta + pa[i] * LDA + ca8[i] * 8) = v;
+        }
+    };
+    __syncthreads();                                          // coefficient tables
+    if (nch > 0) {
+        issue(p_begin);
+        stage(0);
+        if (nch > 1) issue(p_begin + WT_BP);
+    }
+    for (int c = 0; c < nch; ++c) {
+        __syncthreads();      // tile c complete; everyone is done multiplying tile c-1, whose buffer the next stage() overwrites
+        if (c + 1 < nch) {
+            stage((c + 1) & 1);
+            if (c + 2 < nch) issue(p_begin + (c + 2) * WT_BP);
+        }
+        const uint16_t* td = tile_d + (c & 1) * WT_BP * LDD;
+        const uint16_t* ta = tile_a + (c & 1) * WT_BP * LDA;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t bf[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                if (kt < ktn) bf[kt] = tr_frag(ta, LDA, ks * 32, (wc * KT + kt) * 16, lane);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (ct >= ctn) continue;
+                const bf16x8_t af = tr_frag(td, LDD, ks * 32, (wr * CT + ct) * 16, lane);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    if (kt < ktn) acc[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[kt], acc[ct][kt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial[split][co][k] straight from the accumulators (D: row = lg*4 + r -> cout, column = l15 -> k)
+    float* dst = a.partial + (size_t)blockIdx.x * a.Co * a.Ktot;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            if (ct >= ctn || kt >= ktn) continue;
+            const int col = kc0 + (wc * KT + kt) * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = co0 + (wr * CT + ct) * 16 + lg * 4 + r;
+                if (row < a.Co && col < a.Ktot) dst[(size_t)row * a.Ktot + col] = acc[ct][kt][r];
+            }
+        }
+}
+
+// Slab shape per launch: the (CT, KT) pair that minimises padded MFMA work plus staged bytes (both operands are re-read once
+// per slab of the OTHER dimension); CT <= 5, KT <= 4.
+static void wgrad_pick_tiles(int Co, int K, int* ct, int* kt) {
+    double best = 1e300;
+    for (int c = 5; c >= 1; --c)
+        for (int k = 4; k >= 1; --k) {
+            if (c == 5 && k == 4) continue;          // 80 accumulator registers + the staging registers do not fit 256 VGPRs
+            const double cop = (double)((Co + 32 * c - 1) / (32 * c)) * 32 * c, kp = (double)((K + 32 * k - 1) / (32 * k)) * 32 * k;
+            const double cost = cop * kp * (1.0 + 48.0 / (32 * c) + 48.0 / (32 * k));
+            if (cost < best) { best = cost; *ct = c; *kt = k; }
+        }
+}
+extern "C" int mnas_conv_wgrad_slabs(int Co, int Ci, int taps) {
+    if (Co < 1 || Ci < 1 || taps < 1) return 0;
+    int ct, kt;
+    wgrad_pick_tiles(Co, taps * Ci, &ct, &kt);
+    return ((Co + 32 * ct - 1) / (32 * ct)) * ((taps * Ci + 32 * kt - 1) / (32 * kt));
+}
+
+template <int CT, int KT>
+static void wgrad_t_launch(const WgradArgs& a, int nsplit, hipStream_t s) {
+    const int xcols = (a.taps == 1) ? 32 * KT : a.Ci;
+    const size_t lds = (size_t)(5 * 32 * CT + 2 * xcols) * sizeof(float) + (size_t)2 * WT_BP * (32 * CT + 16 + 32 * KT + 16) * 2;
+    dim3 grid(nsplit, (a.Co + 32 * CT - 1) / (32 * CT), (a.Ktot + 32 * KT - 1) / (32 * KT));
+    hipLaunchKernelGGL((k_wgrad_t<CT, KT>), grid, dim3(256), lds, s, a);
+}
+
 extern "C" int mnas_conv_wgrad(const MnasConvWgrad* c, void* stream) {
     if (!c || (c->Ci & 7) || (c->Co & 7) || c->nsplit < 1) return MNAS_EINVAL;
     WgradArgs a;
@@ -252,12 +469,16 @@ extern "C" int mnas_conv_wgrad(const MnasConvWgrad* c, void* stream) {
     if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;
     if (a.taps != 1 && c->Ci > 1024) return MNAS_EINVAL;
     const int per = (a.M + c->nsplit - 1) / c->nsplit;
-    a.chunk = (per + WG_BPIX - 1) / WG_BPIX * WG_BPIX;
+    a.chunk = (per + WT_BP - 1) / WT_BP * WT_BP;
     a.x = c->x; a.dy = c->dy; a.partial = c->partial;
-    const int xcols = (a.taps == 1) ? 64 : a.Ci;
-    const size_t lds = (size_t)(5 * 64 + 2 * xcols) * sizeof(float) + (size_t)2 * WG_BPIX * 72 * 2;
-    dim3 grid(c->nsplit, (c->Co + 63) / 64, (a.Ktot + 63) / 64);
-    hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    int ct, kt;
+    wgrad_pick_tiles(a.Co, a.Ktot, &ct, &kt);
+    hipStream_t s = (hipStream_t)stream;
+#define MNAS_WT(C_, K_) if (ct == C_ && kt == K_) wgrad_t_launch<C_, K_>(a, c->nsplit, s);
+#define MNAS_WTC(C_) MNAS_WT(C_, 1) MNAS_WT(C_, 2) MNAS_WT(C_, 3) MNAS_WT(C_, 4)
+    MNAS_WTC(1) MNAS_WTC(2) MNAS_WTC(3) MNAS_WTC(4) MNAS_WT(5, 1) MNAS_WT(5, 2) MNAS_WT(5, 3)
+#undef MNAS_WTC
+#undef MNAS_WT
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }

@@ -692,8 +692,7 @@ class Program:
             else:
                 ops.add(L.OP_WGRAD_FINALIZE, [nparts, Co, ci.cin, 1, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
         else:
-            K = ci.k * ci.k * ci.cin
-            slabs = _cdiv(Co, 64) * _cdiv(K, 64)
+            slabs = lib.mnas_conv_wgrad_slabs(Co, ci.cin, ci.k * ci.k)
             nsp = max(1, min(_cdiv(eng.wgrad_wgs, slabs), _cdiv(M, 256)))
             ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
                     a_in.act_ptrs() + gyd + [eng.scratch_wgrad.data_ptr()], WS)
@@ -1046,7 +1045,7 @@ class Engine:
                         self.lib.mnas_tconv_supported(8, 8, ci.cout, ci.cin):
                     ci.w_tconv = torch.empty(nbytes(L.PACK_TCONV, ci.cout, ci.cin, 3, 3), dtype=torch.uint8, device=device)
                 K = ci.k * ci.k * ci.cin
-                slabs = _cdiv(ci.cout, 64) * _cdiv(K, 64)
+                slabs = self.lib.mnas_conv_wgrad_slabs(ci.cout, ci.cin, ci.k * ci.k)
                 wmax = max(wmax, max(1, _cdiv(1024, slabs)) * ci.cout * K)
                 if ci.kind == "pw" and self.lib.mnas_pw_bwd_supported(ci.cin, ci.cout):
                     wmax = max(wmax, 1024 * ci.cout * ci.cin)      # one slab per workgroup of the fused 1x1 backward
