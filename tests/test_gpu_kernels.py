@@ -247,6 +247,28 @@ def test_dense_wgrad(shape):
     assert relerr(got, ref) < TOL_F32
 
 
+@pytest.mark.parametrize("shape,nsplit", [((1, 5, 5, 24, 40, 1), 7), ((2, 7, 7, 192, 320, 1), 3), ((1, 6, 6, 16, 24, 2), 5),
+                                          ((3, 7, 7, 8, 168, 1), 2)])
+def test_dense_wgrad_slabs_and_empty_splits(shape, nsplit):
+    """k_wgrad_t: more pixel splits than 64-pixel chunks (empty splits must contribute zeros), slab shapes with padded edge
+    tiles in both dimensions, and mnas_conv_wgrad_slabs consistent with a full cover of dW."""
+    N, H, W, Ci, Co, s = shape
+    lib = L.load()
+    slabs = lib.mnas_conv_wgrad_slabs(Co, Ci, 9)
+    assert 1 <= slabs <= ((Co + 31) // 32) * ((9 * Ci + 31) // 32)
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    x = _x((N, Ci, H, W), 31)
+    g, y = _x((N, Co, Ho, Wo), 36), _x((N, Co, Ho, Wo), 37)
+    b = rand_bn_coefs(Co, 39, O)
+    dy = dy_ref(g, y, b)
+    ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, 3, 3), dy, stride=s, padding=1)
+    xd, gd, yd, bd = nhwc(x), nhwc(g), nhwc(y), b.cuda()
+    got = _wgrad(N, H, W, Ci, Ho, Wo, Co, 3, s, 1, act_in(xd), grad_in(gd, yd, bd), nsplit)
+    assert relerr(got, ref) < TOL_F32
+    again = _wgrad(N, H, W, Ci, Ho, Wo, Co, 3, s, 1, act_in(xd), grad_in(gd, yd, bd), nsplit)
+    assert torch.equal(got, again)                 # fixed summation order: bit-reproducible
+
+
 # ---------------------------------------------------------------------------------------------------
 DW = [  # N,H,W,C,k
     (2, 12, 12, 48, 3), (2, 12, 12, 72, 5), (2, 7, 9, 240, 5), (3, 14, 14, 480, 3), (5, 7, 7, 1152, 3),

@@ -8,6 +8,7 @@ from mnasnet_pytorch_amd import _lib as L
 lib = L.load()
 N = int(os.environ.get("KB_N", "256"))
 WGS = int(os.environ.get("KB_WGS", "512"))
+FIN = int(os.environ.get("KB_FIN", "1"))       # time the split reduction (mnas_wgrad_finalize) with the launch
 SHAPES = [  # H, Ci, Co, k, stride, dy materialised
     (7, 192, 320, 3, 1, 1), (7, 1152, 192, 1, 1, 0), (7, 192, 1152, 1, 1, 0), (14, 96, 192, 3, 2, 1), (14, 96, 576, 1, 1, 0),
     (14, 80, 96, 3, 1, 1), (14, 80, 480, 1, 1, 0), (28, 40, 80, 3, 2, 1), (56, 24, 40, 3, 2, 1), (112, 16, 24, 3, 2, 1)]
@@ -40,6 +41,8 @@ def run(H, Ci, Co, k, s, mat):
         a.dy = L.MnasGradIn(gs[i].data_ptr(), None, None) if mat else L.MnasGradIn(gs[i].data_ptr(), ys[i].data_ptr(), coef.data_ptr())
         a.partial = partial.data_ptr()
         L.check(lib.mnas_conv_wgrad(C.byref(a), L.cur_stream()), "wgrad")
+        if FIN: L.check(lib.mnas_wgrad_finalize(partial.data_ptr(), nsp, Co, Ci, k * k, grad.data_ptr(), 1, L.cur_stream()), "fin")
+    grad = torch.zeros(Co * K, device="cuda")
     for i in range(nset): call(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
