@@ -25,7 +25,7 @@ def key(name):
     if name.startswith("k_dy_mat"): return "k_dy_mat"
     if name.startswith("k_pool"): return "k_pool"
     if name.startswith("void k_wgrad<true>"): return "k_wgrad<stem>"
-    if name.startswith("void k_wgrad<false>"): return "k_wgrad"
+    if name.startswith("void k_wgrad<false>") or name.startswith("void k_wgrad_t<"): return "k_wgrad"
     if name.startswith("void k_pw_bwd"): return "k_pw_bwd"
     if name.startswith("void k_dw_fwd"): return "k_dw_conv<fwd>"
     m = re.match(r"void k_dw_bwd<\d, (true|false), (true|false)", name)
