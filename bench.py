@@ -445,10 +445,18 @@ def main():
         gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dom_key)
         mfma_busy, mfma_src = pmc_mfma_busy(dom_key)
-        # every kernel class of this path sits left of the bf16 MFMA ridge (AI 4-165 flop/B < 312): HBM is the
-        # binding roofline; the matrix-pipe busy fraction from the SQ counters is reported next to it
-        res["roofline"] = {"kernel": dom_key, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        # the binding roofline follows from the class's arithmetic intensity against the bf16 ridge (2500 TFLOP/s / 8 TB/s = 312
+        # flop/B).  Every class of this path sits left of it (AI 4-165 flop/B) -> "hbm"; the matrix-pipe busy
+        # fraction from the SQ counters is reported next to it either way
+        ai = fl / nb if nb > 0 else 0.0
+        tfl = fl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
+        mfma_bound = ai > MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        res["roofline"] = {"kernel": dom_key, "bound": "mfma" if mfma_bound else "hbm",
+                           "achieved": round(tfl, 1) if mfma_bound else round(gbs, 1),
+                           "peak": MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                           "frac": round(tfl / MFMA_PEAK_TFLOPS, 4) if mfma_bound else round(gbs / HBM_PEAK_GBS, 4),
+                           "arithmetic_intensity_flop_per_byte": round(ai, 1),
+                           "traffic": traffic, "traffic_source": traffic_src,
                            "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
                            "mfma_achieved_TFLOPps": round(fl / (tms * 1e-3) / 1e12, 1) if tms > 0 else 0.0,
                            "mfma_peak_TFLOPps": MFMA_PEAK_TFLOPS,

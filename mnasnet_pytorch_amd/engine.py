@@ -692,8 +692,10 @@ class Program:
             else:
                 ops.add(L.OP_WGRAD_FINALIZE, [nparts, Co, ci.cin, 1, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
         else:
+            # pixel splits: as many as keep slabs x splits within the workgroup budget (rounding UP put 513-540 workgroups on the
+            # 512 resident slots of most launches: a second, nearly empty round)
             slabs = lib.mnas_conv_wgrad_slabs(Co, ci.cin, ci.k * ci.k)
-            nsp = max(1, min(_cdiv(eng.wgrad_wgs, slabs), _cdiv(M, 256)))
+            nsp = max(1, min(eng.wgrad_wgs // slabs, _cdiv(M, 256)))
             ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
                     a_in.act_ptrs() + gyd + [eng.scratch_wgrad.data_ptr()], WS)
             ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)

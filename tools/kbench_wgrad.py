@@ -30,7 +30,7 @@ def run(H, Ci, Co, k, s, mat):
     sc, sh = torch.rand(Ci, device="cuda") + 0.5, torch.randn(Ci, device="cuda") * 0.2
     coef = torch.randn(8, Co, device="cuda")
     slabs = lib.mnas_conv_wgrad_slabs(Co, Ci, k * k) if hasattr(lib, "mnas_conv_wgrad_slabs") else cdiv(Co, 64) * cdiv(K, 64)
-    nsp = max(1, min(cdiv(WGS, slabs), cdiv(M, 256)))
+    nsp = max(1, min(cdiv(WGS, slabs) if os.environ.get('KB_CEIL') else WGS // slabs, cdiv(M, 256)))
     partial = torch.empty(nsp * Co * K, device="cuda")
     def call(i):
         a = L.MnasConvWgrad()
