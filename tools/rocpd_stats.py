@@ -130,6 +130,50 @@ def seq_main(path):
 
 
 
+def grids_main(path):
+    """Wave quantisation: rocpd_stats.py --grids results.db -- per (kernel, grid) the workgroups launched against the resident
+    capacity of the chip (256 CUs x workgroups per CU from the VGPR / LDS / wave limits): a launch of 1.05 rounds pays for 2."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    dcols = [r[1] for r in cur.execute("pragma table_info(`%s`)" % kd)]
+    scols = [r[1] for r in cur.execute("pragma table_info(`%s`)" % ks)]
+    print("# dispatch columns:", dcols)
+    print("# symbol columns:", scols)
+    gx = [c for c in dcols if c.startswith("grid_size")]
+    wx = [c for c in dcols if c.startswith("workgroup_size")]
+    acc = "s.accum_vgpr_count" if "accum_vgpr_count" in scols else "0"
+    q = ("select s.display_name, %s, %s, max(d.group_segment_size), max(s.arch_vgpr_count), max(%s), count(*), sum(d.end-d.start) "
+         "from `%s` d join `%s` s on d.kernel_id=s.id group by s.display_name, %s, %s order by 11 desc"
+         % (", ".join("d." + c for c in gx), ", ".join("d." + c for c in wx), acc, kd, ks,
+            ", ".join("d." + c for c in gx), ", ".join("d." + c for c in wx)))
+    print("%-70s %9s %5s %7s %5s %6s %7s %7s %8s" % ("kernel", "wgs", "thr", "lds", "vgpr", "wg/CU", "rounds", "calls", "avg_us"))
+    for row in cur.execute(q):
+        name = row[0]
+        g = row[1:1 + len(gx)]
+        w = row[1 + len(gx):1 + len(gx) + len(wx)]
+        lds, vg, ac, n, tot = row[1 + len(gx) + len(wx):]
+        thr = 1
+        for v in w: thr *= max(1, v)
+        items = 1
+        for v in g: items *= max(1, v)
+        wgs = items // thr if items >= thr and items % thr == 0 else items          # grid in work-items (HSA) or in workgroups
+        waves = (thr + 63) // 64
+        regs = ((vg or 0) + (ac or 0) + 7) // 8 * 8
+        wps = min(8, 512 // regs) if regs else 8                                    # waves per SIMD
+        by_waves = max(1, 4 * wps // waves)
+        by_lds = (160 * 1024) // lds if lds else 32
+        res = max(1, min(by_waves, by_lds, 32))
+        nm = name if len(name) <= 70 else name[:67] + "..."
+        print("%-70s %9d %5d %7d %5d %6d %7.2f %7d %8.1f" % (nm, wgs, thr, lds or 0, regs, res, wgs / (256.0 * res), n, tot / n / 1e3))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--grids":
+    grids_main(sys.argv[2])
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--seq":
     seq_main(sys.argv[2])
     sys.exit(0)
