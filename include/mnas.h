@@ -55,7 +55,7 @@ typedef struct MnasGradIn {
     const float* coef;    /* float[5][C] */
 } MnasGradIn;
 
-int mnas_version(void);                 /* ABI version, currently 1 */
+int mnas_version(void);                 /* ABI version: 3 (= the round whose header this is: struct layouts changed in rounds 2 and 3) */
 const char* mnas_arch(void);            /* "gfx950" */
 
 /* ---- 1x1 / dense kxk convolution as an implicit GEMM on MFMA (bf16 in, fp32 accumulate) -------------

@@ -8,6 +8,7 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 3          # include/mnas.h: mnas_version()
 LIB_PATH = os.environ.get("MNAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmnas_hip.so")      # override: A/B builds (tools/)
 
 c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
@@ -222,8 +223,8 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.mnas_version() != 1:
-        raise RuntimeError("libmnas_hip.so ABI version %d != 1" % lib.mnas_version())
+    if lib.mnas_version() != ABI_VERSION:
+        raise RuntimeError("libmnas_hip.so ABI version %d != %d (stale build: run make -C mnasnet_pytorch_amd/csrc)" % (lib.mnas_version(), ABI_VERSION))
     _lib = lib
     return lib
 
