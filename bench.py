@@ -331,8 +331,10 @@ def main():
     model = FineTuneModelPool(base, "mnasnet", 1000, "512").to(dev).train()
     trainer = Trainer(model, lr=1e-3, distributed=distributed)
     eng = trainer.engine
-    if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream
+    if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream (the default)
         eng.use_side_stream = False
+    if os.environ.get("MNAS_SIDE"):          # diagnosis only: weight-gradient kernels on a second stream (the default until round 3)
+        eng.use_side_stream = True
     if os.environ.get("MNAS_PW_SPLIT_MAX"):  # diagnosis only: pixel count below which project convs use dgrad + wgrad kernels
         eng.pw_split_max_pixels = int(os.environ["MNAS_PW_SPLIT_MAX"])
     if os.environ.get("MNAS_PW_FUSED_MIN"):  # diagnosis only: pixel count from which 1x1 convs use the fused backward
@@ -465,9 +467,10 @@ def main():
                            "ms_per_step": round(tms, 3),
                            "share_of_all_conv_kernel_time": round(calib["agg"][dom_key][0] / tot, 3),
                            "note": "HIP events around every launch of this kernel class inside the timed region (last timed "
-                                   "step). Weight-gradient kernels run on a second stream concurrently with this chain, so a "
-                                   "launch's duration includes the bandwidth it shares with its neighbour; algorithmic bytes "
-                                   "per SURVEY 8(d) (inputs + outputs once, bf16)."}
+                                   "step)%s; algorithmic bytes per SURVEY 8(d) (inputs + outputs once, bf16)."
+                                   % (". Weight-gradient kernels run on a second stream concurrently with this chain, so a launch's "
+                                      "duration includes the bandwidth it shares with its neighbour" if eng.use_side_stream else
+                                      ", one stream")}
         res["kernel_classes"] = {k: {"ms_per_step": round(v[0], 3), "algorithmic_GB": round(v[1] / 1e9, 3),
                                      "GBps": round(v[1] / max(v[0], 1e-9) / 1e6, 1),
                                      "hbm_frac": round(v[1] / max(v[0], 1e-9) / 1e6 / HBM_PEAK_GBS, 3),

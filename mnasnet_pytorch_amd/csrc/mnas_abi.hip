@@ -29,7 +29,7 @@ int mnas_pwd_enabled() {
 int mnas_pws_enabled() {
     static int on = -1;
     if (on < 0) {
-        on = mnas_diag_env("MNAS_PWS", 1);
+        on = mnas_diag_env("MNAS_PWS", 2);      // 0: off, 1: forward only, 2: forward + input gradient
     }
     return on;
 }

@@ -109,7 +109,7 @@ int mnas_dimg_run(const MnasConvGemm* c, void* stream);          // csrc/mnas_di
 int mnas_pwd_enabled();      // MNAS_PWD (default 1): DMA-pipelined 1x1 input gradient for the few-dy-channel convs
 int mnas_pwd_parts(int M, int Ci, int Co);
 int mnas_pwd_dgrad(const MnasConvGemm* c, void* stream);
-// K-streaming 1x1 GEMM (mnas_pws.hip): long-K forward / input gradient on the small-M stages, unless MNAS_PWS=0
+// K-streaming 1x1 GEMM (mnas_pws.hip): long-K forward / input gradient on the small-M stages (diagnosis build: MNAS_PWS=0 off, 1 forward only)
 int mnas_pws_enabled();
 int mnas_pws_parts(int mode, int M, int K, int N);
 int mnas_pws_run(const MnasConvGemm* c, void* stream);

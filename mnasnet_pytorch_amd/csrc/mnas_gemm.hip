@@ -595,7 +595,10 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;   // strided / padded 1x1 does not occur in this network
     if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
     if (c->mode == 1 && (!c->grad.g || (!c->grad.y) != (!c->grad.coef))) return MNAS_EINVAL;    // (y, coef) both or neither
-    if (a.is_pw && (c->mode == 1 || !c->resid) && mnas_pws_parts(c->mode, a.M, c->Ci, c->Co) > 0) return mnas_pws_run(c, stream);
+    if (a.is_pw && (c->mode == 1 || !c->resid) && mnas_pws_parts(c->mode, a.M, c->Ci, c->Co) > 0) {
+        const int rc = mnas_pws_run(c, stream);          // MNAS_EINVAL: not that kernel's case (a materialised dy): fall through
+        if (rc != MNAS_EINVAL) return rc;
+    }
     if (c->mode == 0 && a.is_pw && !c->resid && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwf_forward(c, stream);
     if (c->mode == 1 && a.is_pw && !c->resid && !c->bias && mnas_pwd_enabled() && mnas_pwd_parts(a.M, c->Ci, c->Co) > 0)

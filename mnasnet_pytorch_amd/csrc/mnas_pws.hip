@@ -229,8 +229,11 @@ static bool pws_plan(int mode, int M, int K, int N, PwsPlan* p) {
     if ((K & 7) || (N & 7) || K < 192 || N < 8 || M < 1) return false;       // long reductions only
     // input-gradient mode: with 4 waves (KSW = 5) the dy-on-load transform (two tensors, five coefficient rows) pushed the kernel
     // to 256 VGPRs = one 4-wave workgroup per CU and the step lost 0.47 ms against k_igemm; 8 waves per workgroup (below) fix that
-    if (mode == 1 && mnas_pws_enabled() < 2) return false;        // measured neutral in the step (dgrad class 1.05 -> 0.99 ms, step
-                                                                  // time unchanged): k_igemm stays the default, MNAS_PWS=2 enables it
+    // round 2 measured this form neutral in the step although faster per launch (dgrad class 1.05 -> 0.99 ms): the side stream's
+    // weight-gradient kernels took what it freed.  With the weight gradients on the main stream (round 3 default) it shows:
+    // 14x14 expand convs 58 -> 49 us, 80->480 51 -> 41 us, 7x7 108 -> 65 us, step 11.20 -> 11.09 ms.  MNAS_PWS=1 (diagnosis
+    // build) restores k_igemm for the input gradients.
+    if (mode == 1 && mnas_pws_enabled() < 2) return false;
     if (M > 250000) return false;                                            // the 112x112 / 56x56 layers stay on k_igemm / k_pw_bwd
     const int ksteps = (K + 31) / 32;
     const int tiles = (N + 15) / 16;

@@ -970,7 +970,11 @@ class Engine:
         self.grad_numel = off
         self._sig = None
         self._ext_grad: Optional[torch.Tensor] = None
-        self.use_side_stream = True      # weight-gradient kernels on a second HIP stream, concurrent with dgrad
+        # weight-gradient kernels on a second HIP stream, concurrent with the input-gradient chain.  +14 % when introduced (round 1);
+        # by round 3 the main-stream kernels and k_wgrad_t fill the chip on their own and the overlap only trades time between the
+        # two streams (11.17-11.21 ms with it, 11.07-11.13 without, same call) -- and it hid per-kernel gains on the main stream
+        # (the K-streaming input gradient: neutral with the side stream, -0.1 ms without).  Off by default; the path stays tested.
+        self.use_side_stream = False
         # workgroups of a k_wgrad launch (pixel splits x 64x64 slabs): 512 rather than 1024 leaves the main stream's persistent
         # grids more of the chip while it runs beside them (11.57 vs 11.66 ms/step, three same-call A/B pairs; 256: 11.77)
         self.wgrad_wgs = 512

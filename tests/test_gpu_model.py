@@ -316,6 +316,31 @@ def test_fused_block_path_vs_per_layer_path(name):
                 assert rl2(ba[kk], b0[kk]) < 1e-3, kk
 
 
+@pytest.mark.parametrize("name", ["features3_24_40_k5_56", "features6_96_192_k5_14", "features7_192_320_k3_7"])
+def test_side_stream_path_is_bit_identical(name):
+    """Engine.use_side_stream (weight-gradient kernels on a second HIP stream; the default until round 3, now opt-in) must not
+    change a single bit: the same kernels run in the same per-stream order and every accumulation into a gradient slice stays on
+    one stream.  Outputs, input gradient, every parameter gradient and the BatchNorm buffers are compared with torch.equal."""
+    spec = FULL_STAGES[name][:7] + (32,) + FULL_STAGES[name][8:]
+    outs = []
+    for side in (False, True):
+        m, _, _, shp = _stage_setup(name, 0.1, spec)
+        m._engine().use_side_stream = side
+        x = C.det_input(shp).cuda().requires_grad_(True)
+        y = m(x)
+        cot = C.cotangent(tuple(y.shape)).cuda()
+        (y * cot).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((y.detach().cpu(), x.grad.cpu(), {kk: p.grad.cpu() for kk, p in m.named_parameters()},
+                     {kk: v.cpu() for kk, v in m.state_dict().items() if "running" in kk}))
+    (y0, dx0, g0, b0), (y1, dx1, g1, b1) = outs
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for kk in g0:
+        assert torch.equal(g0[kk], g1[kk]), kk
+    for kk in b0:
+        assert torch.equal(b0[kk], b1[kk]), kk
+
+
 @pytest.mark.parametrize("name", ["features5_80_96_k3_14", "features6_96_192_k5_14", "features7_192_320_k3_7"])
 def test_fused_block_stage_vs_mirror(name):
     """Engine.fuse_irb = "full" at the bench batch (256 images) against the bf16 mirror WITH the fused block's rounding points
