@@ -433,6 +433,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_t(WgradArgs a) {
 // Slab shape per launch: the (CT, KT) pair that minimises padded MFMA work plus staged bytes (both operands are re-read once
 // per slab of the OTHER dimension); CT <= 5, KT <= 4.
 static void wgrad_pick_tiles(int Co, int K, int* ct, int* kt) {
+#ifdef MNAS_DIAG
+    {   // diagnosis build only: MNAS_WT = 10*CT + KT forces the slab shape (tools/kbench_wgrad.py sweeps)
+        const int f = mnas_diag_env("MNAS_WT", 0);
+        if (f > 0) { *ct = f / 10; *kt = f % 10; return; }
+    }
+#endif
     double best = 1e300;
     for (int c = 5; c >= 1; --c)
         for (int k = 4; k >= 1; --k) {
