@@ -1,6 +1,7 @@
 """Execution engine: compiles a subtree of the drop-in modules (mnasnet.py) into a static PROGRAM of HIP
 kernel launches (include/mnas.h) per (batch, height, width, mode) and runs it with ONE host->library call
-per forward / per backward segment (mnas_run_ops_multi: main stream + a side stream for weight-gradient kernels).
+per forward / per backward segment (mnas_run_ops_multi: main stream + an OPTIONAL side stream for weight-gradient kernels,
+Engine.use_side_stream).
 
 Mirrors, for this path, what autograd + ATen do for the reference:
     forward   Mnasnet.features(x)                /root/reference/src/models/mnasnet.py:211-213
@@ -624,7 +625,7 @@ class Program:
             ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
                     [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
         # the weight-gradient kernels only share READ-ONLY inputs (g, y, the dy coefficients just finalised, the
-        # forward activations) with the input-gradient chain: they go to the side stream and run concurrently
+        # forward activations) with the input-gradient chain: with Engine.use_side_stream they go to the side stream
         gyd = gy
         if ci.kind == "dense" and eng.materialize_dy:
             # dense 3x3: every dy element is gathered 2.25-10 times by the input/weight-gradient kernels; form it once
