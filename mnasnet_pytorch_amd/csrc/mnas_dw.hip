@@ -321,7 +321,9 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
             dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
             if (s + 1 < nsteps) dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, r0 + G, x0, c0, wave, nwaves);
             if (!active) continue;
-#pragma unroll 1
+            // unrolled over the row group (3x3: all G rows, 5x5: two -- more spills past 168 VGPRs): the register-ring shift of
+            // consecutive rows becomes renaming instead of KS*DW_BW 64-bit moves per row (3x3 at 112x112: 146 -> 132 us)
+#pragma unroll (KS == 3 ? G : (G == 4 ? 2 : 1))
             for (int j = 0; j < G; ++j) {
                 const int iy = r0 + j;
                 const int oy = iy - PAD;             // A[0] is complete after this row
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             }
             if (s + 1 < nsteps) { dma_group(r0 + G); load_xn(r0 + G); }
             if (!active) continue;
-#pragma unroll 1
+#pragma unroll 1       // unrolling the group would drop the ring-shift moves (as in k_dw_fwd), but needs > 168 VGPRs: measured 266 -> 300 us at 2 waves/SIMD
             for (int j = 0; j < G; ++j) {
                 const int iy = r0 + j;
                 const int oy = iy - PAD;
