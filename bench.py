@@ -282,6 +282,54 @@ def h2d_mode(trainer, model, x_dev, target, steps, dev):
     return out
 
 
+# Diagnosis switches: MNAS_* environment variables that change how the engine compiles the step.  They exist for same-call A/B
+# measurements only; every one that is honoured is listed in the JSON line ("overrides") so that a number measured with one
+# can never pass for the default configuration.
+def _ov_int(name):
+    return int(os.environ[name])
+
+
+OVERRIDES = [
+    # (variable, what it does, setter(eng))
+    ("MNAS_NO_SIDE", "weight-gradient kernels on the main stream (the default)", lambda e: setattr(e, "use_side_stream", False)),
+    ("MNAS_SIDE", "weight-gradient kernels on a second stream (default until round 3)", lambda e: setattr(e, "use_side_stream", True)),
+    ("MNAS_PW_SPLIT_MAX", "pixel count below which project convs use dgrad + wgrad kernels",
+     lambda e: setattr(e, "pw_split_max_pixels", _ov_int("MNAS_PW_SPLIT_MAX"))),
+    ("MNAS_PW_FUSED_MIN", "pixel count from which 1x1 convs use the fused backward",
+     lambda e: setattr(e, "pw_fused_min_pixels", _ov_int("MNAS_PW_FUSED_MIN"))),
+    ("MNAS_NO_TCONV", "stride-2 3x3 input gradients through k_igemm's parity-class form", lambda e: setattr(e, "use_tconv", False)),
+    ("MNAS_NO_MERGE", "separate finalize launches", lambda e: setattr(e, "merge_post", False)),
+    ("MNAS_PWB", "large,mid,small persistent grids of the fused 1x1 backward",
+     lambda e: [setattr(e, n, int(v)) for n, v in zip(("pw_bwd_parts_large", "pw_bwd_parts_mid", "pw_bwd_parts_small"),
+                                                      os.environ["MNAS_PWB"].split(","))]),
+    ("MNAS_NO_DYMAT", "dense 3x3 backward forms dy on load", lambda e: setattr(e, "materialize_dy", False)),
+    ("MNAS_IRB", "fused-block mode on the 14x14 / 7x7 stages: full | fwd | off",
+     lambda e: setattr(e, "fuse_irb", {"full": "full", "fwd": "fwd", "off": False}[os.environ["MNAS_IRB"]])),
+    ("MNAS_IRB_WGS", "workgroups per fused-block launch", lambda e: setattr(e, "irb_workgroups", _ov_int("MNAS_IRB_WGS"))),
+    ("MNAS_WGRAD_WGS", "workgroups per k_wgrad launch", lambda e: setattr(e, "wgrad_wgs", _ov_int("MNAS_WGRAD_WGS"))),
+    ("MNAS_FUSE", "fused expand + depthwise forward kernels that also store y1 (measured slower)",
+     lambda e: setattr(e, "fuse_expand", True)),
+    ("MNAS_DW5_SPLIT", "two-launch backward for the 5x5 depthwise layers", lambda e: setattr(e, "dw_fused_k", (3,))),
+    ("MNAS_TILED", "spatially tiled fused block on the large maps: full | fwd | off",
+     lambda e: setattr(e, "fuse_tiled", {"full": "full", "fwd": "fwd", "off": False}[os.environ["MNAS_TILED"]])),
+    ("MNAS_LIB_PATH", "alternative build of libmnas_hip.so (tools/build_alt.sh)", lambda e: None),
+]
+
+
+def apply_overrides(eng):
+    used = []
+    for name, what, setter in OVERRIDES:
+        if os.environ.get(name):
+            setter(eng)
+            used.append("%s=%s (%s)" % (name, os.environ[name], what))
+    # switches the DIAGNOSIS build of the library reads itself (tools/build_alt.sh, -DMNAS_DIAG); the shipped library ignores them
+    if os.environ.get("MNAS_LIB_PATH"):
+        known = {n for n, _, _ in OVERRIDES}
+        used += ["%s=%s (library diagnosis switch)" % (k, v) for k, v in sorted(os.environ.items())
+                 if k.startswith("MNAS_") and k not in known and k != "MNAS_BENCH_DETAIL"]
+    return used
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -331,32 +379,7 @@ def main():
     model = FineTuneModelPool(base, "mnasnet", 1000, "512").to(dev).train()
     trainer = Trainer(model, lr=1e-3, distributed=distributed)
     eng = trainer.engine
-    if os.environ.get("MNAS_NO_SIDE"):       # diagnosis only: serialise weight-gradient kernels onto the main stream (the default)
-        eng.use_side_stream = False
-    if os.environ.get("MNAS_SIDE"):          # diagnosis only: weight-gradient kernels on a second stream (the default until round 3)
-        eng.use_side_stream = True
-    if os.environ.get("MNAS_PW_SPLIT_MAX"):  # diagnosis only: pixel count below which project convs use dgrad + wgrad kernels
-        eng.pw_split_max_pixels = int(os.environ["MNAS_PW_SPLIT_MAX"])
-    if os.environ.get("MNAS_PW_FUSED_MIN"):  # diagnosis only: pixel count from which 1x1 convs use the fused backward
-        eng.pw_fused_min_pixels = int(os.environ["MNAS_PW_FUSED_MIN"])
-    if os.environ.get("MNAS_NO_TCONV"):      # diagnosis only: stride-2 3x3 input gradients through k_igemm's parity-class form
-        eng.use_tconv = False
-    if os.environ.get("MNAS_NO_MERGE"):      # diagnosis only: separate finalize launches
-        eng.merge_post = False
-    if os.environ.get("MNAS_PWB"):           # diagnosis only: large,mid,small persistent grids of the fused 1x1 backward
-        eng.pw_bwd_parts_large, eng.pw_bwd_parts_mid, eng.pw_bwd_parts_small = (int(v) for v in os.environ["MNAS_PWB"].split(","))
-    if os.environ.get("MNAS_NO_DYMAT"):      # diagnosis only: dense 3x3 backward forms dy on load (two reads + transform per gather)
-        eng.materialize_dy = False
-    if os.environ.get("MNAS_IRB"):           # diagnosis only: fused-block mode on the 14x14 / 7x7 stages: full | fwd | off
-        eng.fuse_irb = {"full": "full", "fwd": "fwd", "off": False}[os.environ["MNAS_IRB"]]
-    if os.environ.get("MNAS_IRB_WGS"):       # diagnosis only: workgroups per fused-block launch
-        eng.irb_workgroups = int(os.environ["MNAS_IRB_WGS"])
-    if os.environ.get("MNAS_WGRAD_WGS"):     # diagnosis only: workgroups per k_wgrad launch
-        eng.wgrad_wgs = int(os.environ["MNAS_WGRAD_WGS"])
-    if os.environ.get("MNAS_FUSE"):          # diagnosis only: fused expand + depthwise forward kernels (measured slower)
-        eng.fuse_expand = True
-    if os.environ.get("MNAS_DW5_SPLIT"):     # diagnosis only: two-launch backward for the 5x5 depthwise layers
-        eng.dw_fused_k = (3,)
+    overrides = apply_overrides(eng)          # diagnosis switches (environment); every honoured one is echoed in the JSON line
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
                L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD,
@@ -434,7 +457,7 @@ def main():
         "windows": len(windows), "timed_seconds": round(sum(windows), 3),
         "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in windows[:16]],
         "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16", "data": "synthetic", "overrides": overrides,
         "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes%s) fwd+bwd+Adam, "
                                "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (", all depthwise convs 5x5 + squeeze-excite (build-defined)" if args.se else (", all depthwise convs 5x5" if args.k5 else ""), B, Hh, Ww),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss": round(lossv, 4)},
@@ -477,8 +500,9 @@ def main():
                                      "TFLOP": round(v[2] / 1e12, 4), "TFLOPps": round(v[2] / max(v[0], 1e-9) / 1e9, 1),
                                      "mfma_frac": round(v[2] / max(v[0], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS, 4), "launches": v[3]}
                                  for k, v in sorted(calib["agg"].items(), key=lambda kv: -kv[1][0])}
-        res["kernel_classes_note"] = ("untimed calibration step with every conv-kernel launch bracketed (two streams overlapping); "
-                                      "hbm_frac = algorithmic GB/s / 8 TB/s, mfma_frac = algorithmic TFLOP/s / 2500 (dense bf16): every "
+        res["kernel_classes_note"] = ("untimed calibration step with every conv-kernel launch bracketed (%s); "
+                                      % ("two streams overlapping" if eng.use_side_stream else "one stream")
+                                      + "hbm_frac = algorithmic GB/s / 8 TB/s, mfma_frac = algorithmic TFLOP/s / 2500 (dense bf16): every "
                                       "class is HBM-bound unfused (SURVEY 8(d)), mfma_frac is reported for completeness")
         res["bracketed_ms_per_step"] = round(tot, 3)
         if os.environ.get("MNAS_BENCH_DETAIL"):

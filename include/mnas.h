@@ -55,7 +55,7 @@ typedef struct MnasGradIn {
     const float* coef;    /* float[5][C] */
 } MnasGradIn;
 
-int mnas_version(void);                 /* ABI version: 3 (= the round whose header this is: struct layouts changed in rounds 2 and 3) */
+int mnas_version(void);                 /* ABI version: 4 (= the round whose header this is: struct layouts changed in rounds 2, 3 and 4) */
 const char* mnas_arch(void);            /* "gfx950" */
 
 /* ---- 1x1 / dense kxk convolution as an implicit GEMM on MFMA (bf16 in, fp32 accumulate) -------------
@@ -165,6 +165,17 @@ typedef struct MnasPwBwd {
     float* red_partial;
     const void*  red_y;
     const float* red_bn;
+    /* round 4: the forms the spatially tiled fused inverted-residual block uses (mnasnet.py:105-137 with the expanded tensors
+     * y1 / g2 kept off HBM).  All three default to NULL = the plain form above.
+     *   gin == NULL ("NOGIN", the PROJECT conv's backward): the input gradient g2 = dy . W is formed on the matrix cores only
+     *       to be reduced into red_partial (required then) -- it is never written.  dy_out (optional) receives the staged
+     *       dy tile, bf16 (M,Co): the project conv's dy, materialised for mnas_dw_bwd's SRC form.
+     *   dy.y == NULL && w_fwd != NULL ("RECOMP", the EXPAND conv's backward): the raw forward output y of dy-on-load is not
+     *       read but recomputed per tile as bf16(W act(x) + b_fwd) from the staged x tile -- bit-identical to what
+     *       mnas_conv_gemm(mode 0) stored (same MFMA, same k order).  w_fwd: MNAS_PACK_FWD [Co_pad16][Ci_pad32]; Ci <= 32. */
+    void*  dy_out;
+    const void*  w_fwd;
+    const float* b_fwd;
 } MnasPwBwd;
 int mnas_pw_bwd(const MnasPwBwd* a, void* stream);
 int mnas_pw_bwd_supported(int Ci, int Co);

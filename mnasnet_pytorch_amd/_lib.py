@@ -8,7 +8,7 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3          # include/mnas.h: mnas_version()
+ABI_VERSION = 4          # include/mnas.h: mnas_version()
 LIB_PATH = os.environ.get("MNAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmnas_hip.so")      # override: A/B builds (tools/)
 
 c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
@@ -59,7 +59,8 @@ class MnasDwExpFwd(C.Structure):
 class MnasPwBwd(C.Structure):
     _fields_ = [("M", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32), ("nparts", C.c_int32), ("x", MnasActIn),
                 ("dy", MnasGradIn), ("w", c_void_p), ("resid", c_void_p), ("gin", c_void_p), ("wpartial", c_void_p),
-                ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p)]
+                ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p), ("dy_out", c_void_p), ("w_fwd", c_void_p),
+                ("b_fwd", c_void_p)]
 
 
 class MnasPostWgrad(C.Structure):

@@ -34,7 +34,7 @@ int mnas_pws_enabled() {
     return on;
 }
 
-extern "C" int mnas_version(void) { return 3; }
+extern "C" int mnas_version(void) { return 4; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 
 extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
@@ -121,6 +121,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = p[6]; a.resid = p[7]; a.gin = p[8]; a.wpartial = (float*)p[9];
             a.red_partial = (float*)p[10]; a.red_y = p[11]; a.red_bn = (const float*)p[12];
+            a.dy_out = p[13]; a.w_fwd = p[14]; a.b_fwd = (const float*)p[15];
             return mnas_pw_bwd(&a, stream);
         }
         case MNAS_OP_GRAM: {

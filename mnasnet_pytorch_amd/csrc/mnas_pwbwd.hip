@@ -17,6 +17,14 @@
 //           whole kernel; written once per workgroup to wpartial[workgroup][co][ci] (mnas_wgrad_finalize sums them);
 //   reduce  per tile: 16-lane shuffle tree, then one LDS slot per (wave, channel) -- fixed order, no atomics.
 // Roofline: HBM.  MFMA work per tile is ~0.3 us against ~5 us of memory time.
+//
+// FORM (round 4, the spatially tiled fused inverted-residual block: the expanded tensors y1 / g2 never reach HBM):
+//   1 "NOGIN"  project conv: the input gradient g2 = dy3 . W3 is formed and bf16-rounded exactly as FORM 0 stores it, but only
+//              REDUCED (BatchNorm2-backward sums) -- the store is gone (a third of the launch's traffic); the staged dy tile
+//              can be written out (dy_out: dy3 materialised for k_dw_bwd's SRC form, which re-forms g2 row by row).
+//   2 "RECOMP" expand conv: dy-on-load's raw forward output y1 is not read: after the x tile is staged, y1 = bf16(W1 act(x) + b1)
+//              is recomputed on the matrix cores (same MFMA, same k order as the forward -> the same bits) and dy is formed
+//              in place over the raw g tile.  One more barrier per tile; a third of the launch's reads gone.
 #include "mnas_common.h"
 
 typedef __attribute__((ext_vector_type(4))) short pw_s4_t;
@@ -34,6 +42,10 @@ struct PwBwdArgs {
     const void* red_y;
     const float* red_bn;
     int nt;                  // nontemporal gin stores
+    void* dy_out;            // FORM 1: materialised dy (M,Co) or NULL
+    const uint16_t* w_fwd;   // FORM 2: MNAS_PACK_FWD [round16(Co)][Kf]
+    const float* b_fwd;      // FORM 2: [Co] or NULL
+    int Kf;                  // FORM 2: Ci rounded up to 32
 };
 
 __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
@@ -50,8 +62,9 @@ __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int
 // pixels are contiguous in memory, so these are full-line writes -- with the fused reduce done on that copy-out path (its
 // operand red_y loaded as 16-byte chunks before the MFMA phases).  The 8-byte-per-lane stores of the MFMA epilogue
 // (partial lines) sustained 2-2.4 TB/s of writes; the same change took the widening forward convs from 2.4 to 4.7 TB/s.
-template <int NTO, int NTI, int PT, bool OS>
+template <int NTO, int NTI, int PT, bool OS, int FORM>
 __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
+    static_assert(FORM == 0 || (FORM == 1 && OS) || (FORM == 2 && !OS), "NOGIN rides on the out-stage path, RECOMP on the plain epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
     constexpr int COP = NTO * 16, CIP = NTI * 16;
@@ -68,6 +81,10 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     uint16_t* lds_w = (uint16_t*)(lds_st + 8 * CIP);         // [CIP][ldw]
     uint16_t* tile_d = lds_w + CIP * ldw;                    // [BP][ldd]
     uint16_t* tile_a = tile_d + BP * ldd;                    // [BP][lda]
+    constexpr int KSF = (CIP + 31) / 32;                     // FORM 2: k-steps of the recompute GEMM
+    const int ldf = a.Kf + 8;
+    uint16_t* lds_wf = tile_a + BP * lda;                    // FORM 2: [COP][ldf] forward weights
+    float* lds_bf = (float*)(lds_wf + (FORM == 2 ? COP * ldf : 0));      // FORM 2: [COP] forward bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -108,6 +125,16 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         }
         const int nz = (BP * ldd + BP * lda) / 8;            // both tiles are contiguous; row strides are multiples of 8
         for (int i = tid; i < nz; i += 256) ((uint4*)tile_d)[i] = make_uint4(0, 0, 0, 0);
+        if constexpr (FORM == 2) {
+            const int kf8 = a.Kf >> 3, cop16 = (a.Co + 15) / 16 * 16;
+            for (int q = tid; q < COP * kf8; q += 256) {
+                const int r = q / kf8, k8 = q - r * kf8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r < cop16) v = *(const uint4*)(a.w_fwd + (size_t)r * a.Kf + k8 * 8);
+                *(uint4*)(lds_wf + r * ldf + k8 * 8) = v;
+            }
+            for (int i = tid; i < COP; i += 256) lds_bf[i] = (a.b_fwd && i < a.Co) ? a.b_fwd[i] : 0.f;
+        }
     }
 
     // ---- staging plan (tile-invariant): slot -> (pixel in tile, 16-byte channel chunk)
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             if (pd[i] >= 0 && tile0 + pd[i] < a.M) {
                 const size_t off = (size_t)(tile0 + pd[i]) * a.Co + cd8[i] * 8;
                 vg[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
-                vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
+                if constexpr (FORM != 2) vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
             }
         }
 #pragma unroll
@@ -183,7 +210,9 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         for (int i = 0; i < ND; ++i) {
             if (pd[i] < 0) continue;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (tile0 + pd[i] < a.M) {
+            if constexpr (FORM == 2) {
+                if (tile0 + pd[i] < a.M) v = vg[i];          // raw g: dy is formed after the recompute below
+            } else if (tile0 + pd[i] < a.M) {
                 float cf[5][8];
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
@@ -193,6 +222,10 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 float o[8];
                 dy8(vg[i], vy[i], cf[0], cf[1], cf[2], cf[3], cf[4], o);
                 v = pack8(o);
+                if constexpr (FORM == 1) {
+                    if (a.dy_out && blockIdx.y == 0)
+                        *(uint4*)((uint16_t*)a.dy_out + (size_t)(tile0 + pd[i]) * a.Co + cd8[i] * 8) = v;
+                }
             }
             *(uint4*)(tile_d + pd[i] * ldd + cd8[i] * 8) = v;
         }
@@ -212,6 +245,57 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             *(uint4*)(tile_a + pa[i] * lda + ca8[i] * 8) = v;
         }
         __syncthreads();
+        if constexpr (FORM == 2) {
+            // y1 = bf16(W act(x) + b) for this wave's pixels (D[co][pix]: a lane holds 4 consecutive co of one pixel), then
+            // dy = c1*(g*[s*y+t>0]) + c2*y + c3 in place over the raw g values of the same (pixel, 4 channels)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int p = (wave * PT + pt) * 16 + l15;
+                bf16x8_t xb[KSF];
+#pragma unroll
+                for (int ks = 0; ks < KSF; ++ks) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (ks * 32 + lg * 8 < CIP) v = *(const uint4*)(tile_a + p * lda + ks * 32 + lg * 8);
+                    xb[ks] = *(const bf16x8_t*)&v;
+                }
+                const bool pok = tile0 + p < a.M;              // rows past the end stay zero (they feed the weight gradient)
+#pragma unroll
+                for (int to = 0; to < NTO; ++to) {
+                    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSF; ++ks) {
+                        const bf16x8_t afrag = *(const bf16x8_t*)(lds_wf + (to * 16 + l15) * ldf + ks * 32 + lg * 8);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, xb[ks], acc, 0, 0, 0);
+                    }
+                    const int co = to * 16 + lg * 4;
+                    const float4 bb = *(const float4*)(lds_bf + co);
+                    uint2 yp;
+                    yp.x = pack_bf16(acc[0] + bb.x, acc[1] + bb.y);
+                    yp.y = pack_bf16(acc[2] + bb.z, acc[3] + bb.w);
+                    const uint2 gp = *(const uint2*)(tile_d + p * ldd + co);
+                    const float yq[4] = {bf_lo(yp.x), bf_hi(yp.x), bf_lo(yp.y), bf_hi(yp.y)};
+                    const float gq[4] = {bf_lo(gp.x), bf_hi(gp.x), bf_lo(gp.y), bf_hi(gp.y)};
+                    const float4 cs = *(const float4*)(lds_cd + co), ct = *(const float4*)(lds_cd + COP + co);
+                    const float4 c1 = *(const float4*)(lds_cd + 2 * COP + co), c2 = *(const float4*)(lds_cd + 3 * COP + co);
+                    const float4 c3 = *(const float4*)(lds_cd + 4 * COP + co);
+                    const float s_[4] = {cs.x, cs.y, cs.z, cs.w}, t_[4] = {ct.x, ct.y, ct.z, ct.w};
+                    const float c1_[4] = {c1.x, c1.y, c1.z, c1.w}, c2_[4] = {c2.x, c2.y, c2.z, c2.w}, c3_[4] = {c3.x, c3.y, c3.z, c3.w};
+                    float d[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dz = (fmaf(yq[r], s_[r], t_[r]) > 0.f) ? gq[r] : 0.f;
+                        d[r] = fmaf(c1_[r], dz, fmaf(c2_[r], yq[r], c3_[r]));
+                    }
+                    if (pok) {
+                        uint2 dp;
+                        dp.x = pack_bf16(d[0], d[1]);
+                        dp.y = pack_bf16(d[2], d[3]);
+                        *(uint2*)(tile_d + p * ldd + co) = dp;
+                    }
+                }
+            }
+            __syncthreads();
+        }
 
         // the epilogue's global operands (raw output of the reduce target, residual gradient) for this lane's fragments:
         // issued now, they land under the MFMA phases
@@ -308,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 if (ooff[k] < 0) continue;
                 const int p = orow0 + k * OROWS;
                 const uint4 pk = *(const uint4*)(tile_a + p * lda + oc8 * 8);
-                st_u4((uint16_t*)a.gin + ooff[k], pk, true);
+                if constexpr (FORM != 1) st_u4((uint16_t*)a.gin + ooff[k], pk, true);
                 if (do_red) {
                     float gq[8], yq[8];
                     unpack8(pk, gq);
@@ -444,19 +528,40 @@ static int pw_bwd_outstage() {
 template <int NTO, int NTI, int PT>
 static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int nslices = 1) {
     constexpr int BP = 64 * PT, COP = NTO * 16, CIP = NTI * 16;
-    const size_t lds = (size_t)(5 * COP + 14 * CIP) * sizeof(float) +
-                       ((size_t)CIP * (a.Kd + 8) + (size_t)BP * (a.Kd + 8) + (size_t)BP * (CIP + 8)) * 2;
+    const bool nogin = a.gin == nullptr, recomp = a.dy.y == nullptr;
+    size_t lds = (size_t)(5 * COP + 14 * CIP) * sizeof(float) +
+                 ((size_t)CIP * (a.Kd + 8) + (size_t)BP * (a.Kd + 8) + (size_t)BP * (CIP + 8)) * 2;
+    if (recomp) lds += (size_t)COP * (a.Kf + 8) * 2 + (size_t)COP * sizeof(float);
     if (lds > 160 * 1024) return MNAS_EINVAL;
     // narrowing conv with >= 48 result channels: gin is the wide tensor (32 -> 16 at 112x112 is 124 us without and 184 us with
     // the out-stage: two more barriers per tile and nothing to win on 64-byte rows)
     if constexpr ((NTI > NTO && NTI >= 3) || (NTI == NTO && NTI >= 5)) {       // (the 14x14 channel slices: 5/5, 6/6)
+        if (recomp) return MNAS_EINVAL;
+        if constexpr (NTI > NTO && NTO <= 3) {                // FORM 1 (project convs of the tiled fused block) rides on the out-stage path
+            if (nogin) {
+                if (a.resid || !a.red_partial) return MNAS_EINVAL;
+                hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 1>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+                MNAS_CHECK_LAUNCH();
+                return MNAS_OK;
+            }
+        }
+        if (nogin) return MNAS_EINVAL;
         if (pw_bwd_outstage() >= (NTI == NTO ? 2 : 1) && !a.resid) {
-            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 0>), dim3(nparts, nslices), dim3(256), lds, stream, a);
             MNAS_CHECK_LAUNCH();
             return MNAS_OK;
         }
     }
-    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+    if (nogin) return MNAS_EINVAL;
+    if constexpr (NTO > NTI && NTI <= 2) {                    // the expand convs of the 112x112 / 56x56 stages
+        if (recomp) {
+            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false, 2>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+            MNAS_CHECK_LAUNCH();
+            return MNAS_OK;
+        }
+    }
+    if (recomp) return MNAS_EINVAL;
+    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false, 0>), dim3(nparts, nslices), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -479,13 +584,16 @@ extern "C" int mnas_pw_bwd_supported(int Ci, int Co) { return pw_cfg(Ci, Co) ? 1
 
 extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     if (!c || c->M < 1 || c->nparts < 1 || c->nparts > 65535 || !mnas_pw_bwd_supported(c->Ci, c->Co)) return MNAS_EINVAL;
-    if (!c->x.data || !c->dy.g || !c->dy.y || !c->dy.coef || !c->w || !c->gin || !c->wpartial) return MNAS_EINVAL;
+    if (!c->x.data || !c->dy.g || !c->dy.coef || !c->w || !c->wpartial) return MNAS_EINVAL;
+    if (!c->dy.y && !c->w_fwd) return MNAS_EINVAL;           // RECOMP needs the forward weights
+    if (!c->gin && !c->red_partial) return MNAS_EINVAL;      // NOGIN: the input gradient is only reduced
     if (c->red_partial && (!c->red_bn || !c->red_y)) return MNAS_EINVAL;
     PwBwdArgs a;
     a.M = c->M; a.Ci = c->Ci; a.Co = c->Co; a.Kd = (c->Co + 31) / 32 * 32;
     a.x = c->x; a.dy = c->dy; a.w = (const uint16_t*)c->w; a.resid = c->resid; a.gin = c->gin;
     a.wpartial = c->wpartial; a.red_partial = c->red_partial; a.red_y = c->red_y; a.red_bn = c->red_bn;
     a.nt = (mnas_nt_mask() & MNAS_NT_PW_BWD) ? 1 : 0;
+    a.dy_out = c->dy_out; a.w_fwd = (const uint16_t*)c->w_fwd; a.b_fwd = c->b_fwd; a.Kf = (c->Ci + 31) / 32 * 32;
     const PwCfg* cfg = pw_cfg(c->Ci, c->Co);
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_PWB(O_, I_, P_) if (cfg->nto == O_ && cfg->nti_slice == I_ && cfg->pt == P_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s, cfg->nslices);

@@ -423,6 +423,12 @@ class Program:
         stats = eng.scratch_stats.data_ptr() if training else None
         if ci.kind == "stem":
             sp = lib.mnas_stem_parts(0, N, Hi, Wi, ci.cout)
+            if self._aff_ptr is not None and (sp < 1 or (training and lib.mnas_stem_parts(1, N, Hi, Wi, ci.cout) < 1)):
+                # the fused Normalize / uint8 load exists only in the band kernels (csrc/mnas_stem.hip)
+                raise NotImplementedError(
+                    "fused input normalisation needs the stem band kernels: 32 output channels and an image width that is a "
+                    "multiple of 4 (16 in training); got %dx%d, %d channels.  Normalise on the host or call "
+                    "set_input_normalization(None, None)" % (Hi, Wi, ci.cout))
             nparts = sp if sp > 0 else nparts
             j = fwd.add(L.OP_STEM_FWD, [N, Hi, Wi, Ho, Wo, ci.cout, nparts, 1 if self.in_u8 else 0], [],
                         [None, ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats, self._aff_ptr])
@@ -697,6 +703,8 @@ class Program:
             # 512 resident slots of most launches: a second, nearly empty round)
             slabs = lib.mnas_conv_wgrad_slabs(Co, ci.cin, ci.k * ci.k)
             nsp = max(1, min(eng.wgrad_wgs // slabs, _cdiv(M, 256)))
+            # partial[nsp][Co][K] must fit the scratch _setup sized for 1024 workgroups (Engine.wgrad_wgs is public)
+            nsp = max(1, min(nsp, eng.scratch_wgrad.numel() // (Co * ci.cin * ci.k * ci.k)))
             ops.add(L.OP_CONV_WGRAD, [N, Hi, Wi, ci.cin, Ho, Wo, Co, ci.k, ci.k, ci.stride, ci.pad, nsp], [],
                     a_in.act_ptrs() + gyd + [eng.scratch_wgrad.data_ptr()], WS)
             ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, ci.cin, ci.k * ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
@@ -828,7 +836,7 @@ class Program:
     # ------------------------------------------------------------------------------------------
     def _run(self, arr, n, what):
         failed = C.c_int(-1)
-        streams = (C.c_void_p * 2)(L.cur_stream(), self.eng.side_stream.cuda_stream)
+        streams = (C.c_void_p * 2)(L.cur_stream(), self.eng.side_stream_handle())
         rc = self.eng.lib.mnas_run_ops_multi(arr, n, streams, 2, C.byref(failed))
         if rc != 0:
             raise RuntimeError("%s: mnas_run_ops failed with code %d at op %d (opcode %d)" %
@@ -1039,8 +1047,8 @@ class Engine:
             self.reset_programs()
         self.device = device
         self._validate_modules()
-        if self.side_stream is None or self.side_stream.device != device:
-            self.side_stream = torch.cuda.Stream(device=device)
+        if self.side_stream is not None and self.side_stream.device != device:
+            self.side_stream = None          # re-created lazily on the new device (side_stream_handle)
         nbytes = self.lib.mnas_packed_bytes
         smax, wmax = 0, 0
         for ci in self.convs:
@@ -1141,6 +1149,15 @@ class Engine:
             for h in self._events:
                 self.lib.mnas_event_destroy(h)
             self._events = []
+
+    def side_stream_handle(self):
+        """hipStream_t for stream slot 1 of mnas_run_ops_multi.  The second stream exists only when use_side_stream asks for it
+        (created on first use); otherwise slot 1 is the current stream too and launch lists carry no stream-1 ops."""
+        if not self.use_side_stream:
+            return L.cur_stream()
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        return self.side_stream.cuda_stream
 
     def new_event(self):
         h = C.c_void_p()

@@ -3,21 +3,28 @@
 # in this build; the shipped libmnas_hip.so reads no environment), optionally one source with extra defines for an in-one-call A/B:
 #     bash tools/build_alt.sh                       # plain diagnosis build
 #     bash tools/build_alt.sh mnas_dw.hip -DMNAS_DW_XFILL=0
+#     OUT=libmnas_hip_b.so bash tools/build_alt.sh mnas_dw.hip -DFOO=1     # a second variant next to the first
 # -> mnasnet_pytorch_amd/csrc/libmnas_hip_alt.so (git-ignored); run with MNAS_LIB_PATH=$PWD/mnasnet_pytorch_amd/csrc/libmnas_hip_alt.so
+# The object built with extra defines goes to <name>.alt.o and is linked INSTEAD of the plain one: a later plain build never
+# picks up a stale variant object.  Plain objects are rebuilt when the source, mnas_common.h or include/mnas.h is newer.
 set -e
 cd "$(dirname "$0")/../mnasnet_pytorch_amd/csrc"
 OBJ=/tmp/mnas_diag_obj
+OUT=${OUT:-libmnas_hip_alt.so}
 mkdir -p $OBJ
 SRC=${1:-}; [ $# -gt 0 ] && shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -fno-slp-vectorize -DMNAS_DIAG"
+LINK=""
 for f in *.hip; do
     o=$OBJ/${f%.hip}.o
-    if [ "$f" = "$SRC" ]; then
+    if [ "$f" = "$SRC" ] && [ $# -gt 0 ]; then
+        o=$OBJ/${f%.hip}.alt.o
         /opt/rocm/bin/hipcc $FLAGS "$@" -c $f -o $o &
-    elif [ ! -f $o ] || [ $f -nt $o ] || [ mnas_common.h -nt $o ]; then
+    elif [ ! -f $o ] || [ $f -nt $o ] || [ mnas_common.h -nt $o ] || [ ../../include/mnas.h -nt $o ]; then
         /opt/rocm/bin/hipcc $FLAGS -c $f -o $o &
     fi
+    LINK="$LINK $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/*.o -o libmnas_hip_alt.so
-echo built libmnas_hip_alt.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $LINK -o $OUT
+echo built $OUT
