@@ -179,6 +179,7 @@ typedef struct MnasPwBwd {
 } MnasPwBwd;
 int mnas_pw_bwd(const MnasPwBwd* a, void* stream);
 int mnas_pw_bwd_supported(int Ci, int Co);
+int mnas_pw_bwd_forms(int Ci, int Co);      /* bit 0: NOGIN available for this channel pair, bit 1: RECOMP available */
 
 /* ---- depthwise kxk (k in {3,5}, stride 1, pad k/2), LDS-tiled direct conv on the vector ALU ----------
  * Replaces ATen conv2d fwd/bwd for ConvBlock's groups==C convs (mnasnet.py:122-125, 76-81). */

@@ -164,6 +164,7 @@ SYMBOLS = {
     "mnas_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mnas_pw_bwd": (c_int, [C.POINTER(MnasPwBwd), c_void_p]),
     "mnas_pw_bwd_supported": (c_int, [c_int, c_int]),
+    "mnas_pw_bwd_forms": (c_int, [c_int, c_int]),
     "mnas_dw_fwd": (c_int, [C.POINTER(MnasDwFwd), c_void_p]),
     "mnas_dw_bwd": (c_int, [C.POINTER(MnasDwBwd), c_void_p]),
     "mnas_dw_exp_fwd": (c_int, [C.POINTER(MnasDwExpFwd), c_void_p]),

@@ -72,7 +72,13 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     constexpr int NOWN = OWN_O ? (NTO + 3) / 4 : (NTI + 3) / 4;
     constexpr int NOTH = OWN_O ? NTI : NTO;
     constexpr int ND = (BP * (COP / 8) + 255) / 256;         // dy staging slots per thread (upper bound)
-    constexpr int NX = (BP * (CIP / 8) + 255) / 256;         // x staging slots per thread
+    // OS copy-out role: thread -> fixed 16-byte channel column oc8 of the tile rows orow0 + k*OROWS.  The out-stage forms STAGE x
+    // with the same mapping: the thread that stages chunk (row, oc8) of x is the one that later copies out -- and reduces --
+    // chunk (row, oc8) of the input gradient, whose reduce operand (the raw output of x's producer = x.data itself for a
+    // project conv) it therefore already holds in a register.  Round 3 re-read that operand from global memory (red_y): the
+    // project convs moved 2L + 2S + L bytes, a third of them the same tensor twice.
+    constexpr int NCH8 = CIP / 8, TCOLS = (256 / NCH8) * NCH8, OROWS = TCOLS / NCH8, MAXR = OS ? (BP + OROWS - 1) / OROWS : 1;
+    constexpr int NX = OS ? MAXR : (BP * (CIP / 8) + 255) / 256;         // x staging slots per thread
     const int ldd = a.Kd + 8, ldw = a.Kd + 8, lda = CIP + 8;
     float* lds_cd = (float*)smem;                            // [5][COP]
     float* lds_cx = lds_cd + 5 * COP;                        // [2][CIP]
@@ -148,9 +154,14 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const int q = tid + 256 * i;
-        pa[i] = q / cwa; ca8[i] = q - pa[i] * cwa;
-        if (pa[i] >= BP) pa[i] = -1;
+        if constexpr (OS) {                                  // copy-out mapping (see above)
+            pa[i] = (tid < TCOLS && (tid % NCH8) < cwa && tid / NCH8 + i * OROWS < BP) ? tid / NCH8 + i * OROWS : -1;
+            ca8[i] = tid % NCH8;
+        } else {
+            const int q = tid + 256 * i;
+            pa[i] = q / cwa; ca8[i] = q - pa[i] * cwa;
+            if (pa[i] >= BP) pa[i] = -1;
+        }
     }
 
     f32x4_t acc_w[NOWN][NOTH];
@@ -162,12 +173,11 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     // BatchNorm-backward partial sums: per lane in registers across all tiles when there are few cin tiles (one shuffle tree
     // at the very end), per tile through LDS otherwise (15 cin tiles would need 120 registers)
     // OS copy-out role: thread -> fixed 16-byte channel column c8 of the out-stage rows orow0 + k*OROWS
-    constexpr int NCH8 = CIP / 8, TCOLS = (256 / NCH8) * NCH8, OROWS = TCOLS / NCH8, MAXR = OS ? (BP + OROWS - 1) / OROWS : 1;
     const int oc8 = tid % NCH8, orow0 = tid / NCH8;
     const bool ocol_ok = tid < TCOLS && oc8 * 8 < cis;
-    float r1[8], r2[8], rcs[8], rct[8], rci[8], rcm[8];
+    float r1[8], r2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; rcs[j] = 0.f; rct[j] = 0.f; rci[j] = 0.f; rcm[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; }
     constexpr bool REGSTAT = NTI <= 6;
     float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
 #pragma unroll
@@ -175,16 +185,6 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { rs1[i][r] = 0.f; rs2[i][r] = 0.f; }
 
-    if (OS && do_red) {
-        __syncthreads();                                     // lds_rc written above
-        if (ocol_ok) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                rcs[j] = lds_rc[oc8 * 8 + j]; rct[j] = lds_rc[CIP + oc8 * 8 + j];
-                rci[j] = lds_rc[2 * CIP + oc8 * 8 + j]; rcm[j] = lds_rc[3 * CIP + oc8 * 8 + j];
-            }
-        }
-    }
     const int ntiles = (a.M + BP - 1) / BP;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tile0 = t * BP;
@@ -300,20 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         // the epilogue's global operands (raw output of the reduce target, residual gradient) for this lane's fragments:
         // issued now, they land under the MFMA phases
         uint2 ypre[PT][NTI], rpre[PT][NTI];
-        uint4 yreg[MAXR];
-        long long ooff[MAXR];
-        if constexpr (OS) {
-#pragma unroll
-            for (int k = 0; k < MAXR; ++k) {
-                const int p = orow0 + k * OROWS, m = tile0 + p;
-                ooff[k] = -1;
-                yreg[k] = make_uint4(0, 0, 0, 0);
-                if (ocol_ok && p < BP && m < a.M) {
-                    ooff[k] = (long long)m * a.Ci + ci0 + oc8 * 8;
-                    if (do_red) yreg[k] = *(const uint4*)((const uint16_t*)a.red_y + ooff[k]);
-                }
-            }
-        }
+        // (out-stage forms: the reduce operand of copy-out slot k is vx[k], the raw x chunk this thread staged)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int m = tile0 + (wave * PT + pt) * 16 + l15;
@@ -324,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 if (m < a.M && ci < cis) {
                     const size_t o = (size_t)m * a.Ci + ci0 + ci;
                     if (!OS && do_red) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + o);
-                    if (a.resid) rpre[pt][nt] = *(const uint2*)((const uint16_t*)a.resid + o);
+                    if (!OS && a.resid) rpre[pt][nt] = *(const uint2*)((const uint16_t*)a.resid + o);
                 }
             }
         }
@@ -375,11 +362,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 const int p = (wave * PT + pt) * 16 + l15;
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) {
-                    float v[4] = {acc_g[pt][nt][0], acc_g[pt][nt][1], acc_g[pt][nt][2], acc_g[pt][nt][3]};
-                    if (a.resid) {
-                        const uint2 rv = rpre[pt][nt];
-                        v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
-                    }
+                    const float v[4] = {acc_g[pt][nt][0], acc_g[pt][nt][1], acc_g[pt][nt][2], acc_g[pt][nt][3]};   // (no residual in the out-stage forms)
                     uint2 pk;
                     pk.x = pack_bf16(v[0], v[1]);
                     pk.y = pack_bf16(v[2], v[3]);
@@ -387,16 +370,28 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 }
             }
             __syncthreads();
+            // the reduce coefficients of this thread's channel column: fetched from LDS per tile, so that they are not live
+            // across the MFMA phases (32 registers: the out-stage forms sat at 175-250 VGPRs = two workgroups per CU)
+            float rcs[8], rct[8], rci[8], rcm[8];
+            if (do_red) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    *(float4*)&rcs[4 * h] = *(const float4*)(lds_rc + oc8 * 8 + 4 * h);
+                    *(float4*)&rct[4 * h] = *(const float4*)(lds_rc + CIP + oc8 * 8 + 4 * h);
+                    *(float4*)&rci[4 * h] = *(const float4*)(lds_rc + 2 * CIP + oc8 * 8 + 4 * h);
+                    *(float4*)&rcm[4 * h] = *(const float4*)(lds_rc + 3 * CIP + oc8 * 8 + 4 * h);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < MAXR; ++k) {
-                if (ooff[k] < 0) continue;
                 const int p = orow0 + k * OROWS;
+                if (!(ocol_ok && p < BP && tile0 + p < a.M)) continue;
                 const uint4 pk = *(const uint4*)(tile_a + p * lda + oc8 * 8);
-                if constexpr (FORM != 1) st_u4((uint16_t*)a.gin + ooff[k], pk, true);
+                if constexpr (FORM != 1) st_u4((uint16_t*)a.gin + ((size_t)(tile0 + p) * a.Ci + ci0 + oc8 * 8), pk, true);
                 if (do_red) {
                     float gq[8], yq[8];
                     unpack8(pk, gq);
-                    unpack8(yreg[k], yq);
+                    unpack8(vx[k], yq);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float dz = (fmaf(yq[j], rcs[j], rct[j]) > 0.f) ? gq[j] : 0.f;
@@ -537,16 +532,19 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
     // the out-stage: two more barriers per tile and nothing to win on 64-byte rows)
     if constexpr ((NTI > NTO && NTI >= 3) || (NTI == NTO && NTI >= 5)) {       // (the 14x14 channel slices: 5/5, 6/6)
         if (recomp) return MNAS_EINVAL;
+        // the out-stage forms reduce against the x chunks they staged: red_y must BE x.data (it is for a project conv: the
+        // reduce target is the depthwise conv that produced x); anything else takes the plain epilogue below
+        const bool redx = !a.red_partial || a.red_y == a.x.data;
         if constexpr (NTI > NTO && NTO <= 3) {                // FORM 1 (project convs of the tiled fused block) rides on the out-stage path
             if (nogin) {
-                if (a.resid || !a.red_partial) return MNAS_EINVAL;
+                if (a.resid || !a.red_partial || !redx) return MNAS_EINVAL;
                 hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 1>), dim3(nparts, nslices), dim3(256), lds, stream, a);
                 MNAS_CHECK_LAUNCH();
                 return MNAS_OK;
             }
         }
         if (nogin) return MNAS_EINVAL;
-        if (pw_bwd_outstage() >= (NTI == NTO ? 2 : 1) && !a.resid) {
+        if (pw_bwd_outstage() >= (NTI == NTO ? 2 : 1) && !a.resid && redx) {
             hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 0>), dim3(nparts, nslices), dim3(256), lds, stream, a);
             MNAS_CHECK_LAUNCH();
             return MNAS_OK;
@@ -581,6 +579,15 @@ static const PwCfg* pw_cfg(int Ci, int Co) {
     return nullptr;
 }
 extern "C" int mnas_pw_bwd_supported(int Ci, int Co) { return pw_cfg(Ci, Co) ? 1 : 0; }
+// bit 0: NOGIN (gin == NULL) available, bit 1: RECOMP (dy.y == NULL + w_fwd) available -- mirrors launch_pw_bwd's dispatch
+extern "C" int mnas_pw_bwd_forms(int Ci, int Co) {
+    const PwCfg* c = pw_cfg(Ci, Co);
+    if (!c) return 0;
+    int f = 0;
+    if (c->nti_slice > c->nto && c->nti_slice >= 3 && c->nto <= 3) f |= 1;
+    if (c->nto > c->nti_slice && c->nti_slice <= 2 && c->nslices == 1) f |= 2;
+    return f;
+}
 
 extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     if (!c || c->M < 1 || c->nparts < 1 || c->nparts > 65535 || !mnas_pw_bwd_supported(c->Ci, c->Co)) return MNAS_EINVAL;

@@ -691,9 +691,16 @@ class Program:
                 red = [eng.scratch_red.data_ptr(), rt[0].data_ptr(), rt[1].data_ptr()]
                 ncols = nparts
             wsc = self._next_scratch() if merge else eng.scratch_wgrad2
+            gyp, extra = gy, [None, None, None]
+            if eng.pw_recompute_y and (lib.mnas_pw_bwd_forms(ci.cin, Co) & 2):
+                # widening (expand) conv: dy-on-load's raw forward output is recomputed from the staged x tile on the matrix
+                # cores (bit-identical to the stored tensor) instead of being read: a third of the launch's reads
+                conv = ci.mod.conv
+                gyp = [gy[0], None, gy[2]]
+                extra = [None, ci.w_fwd.data_ptr(), conv.bias.data_ptr() if conv.bias is not None else None]
             ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts], [],
-                    a_in.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
-                                            gin.data_ptr(), wsc.data_ptr()] + red, 0)
+                    a_in.act_ptrs() + gyp + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                             gin.data_ptr(), wsc.data_ptr()] + red + extra, 0)
             if merge:
                 self._queue_wgrad(ops, wsc.data_ptr(), nparts, Co, ci.cin, 1, False, eng.gptr(ci, 0))
             else:
@@ -1020,6 +1027,10 @@ class Engine:
         # gradient takes 68 us against the fused kernel's 116 (576->96 at 14x14, bs 256), but next to the side stream's
         # k_wgrad it takes 130 us and the step is 0.1 ms slower (12.56 vs 12.44 ms)
         self.pw_split_max_pixels = 0
+        # expand convs of the 112x112 / 56x56 stages (16->48, 24->72): the fused 1x1 backward recomputes the conv's raw output
+        # from its (narrow) input instead of reading the t-times wider stored tensor (mnas_pw_bwd RECOMP; round 4:
+        # 209 -> 155 us per launch at 112x112, bit-identical results)
+        self.pw_recompute_y = True
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
         self.pw_bwd_parts_small = 85     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)
