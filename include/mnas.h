@@ -315,9 +315,24 @@ typedef struct MnasDwBwd {
     float* red_partial;
     int32_t phase;           /* 0: one fused sweep (input gradient + weight gradient + reduce); 1: input gradient (+reduce)
                                 only; 2: weight gradient only (lets the caller put the two on different streams) */
-    int32_t reserved;
+    int32_t src_cin;         /* SRC form: channels of the block (src_x / src_dy), 8..32; 0 otherwise */
+    /* round 4, "SRC" form (src_dy != NULL; the depthwise conv of an MBConv_block, mnasnet.py:116-129, whose neighbours' wide
+     * tensors were never written): dy.g (= g2, the project conv's input gradient) and x.data (= y1, the expand conv's raw
+     * output) are NULL; their rows are recomputed on the matrix cores from the block's narrow tensors:
+     *     g2 = src_dy . W3   (src_dy: the project conv's dy, bf16 (N,H,W,src_cin), from mnas_pw_bwd's dy_out;
+     *                         src_w3t: MNAS_PACK_DGRAD weights of the project conv)
+     *     y1 = W1 act(src_x) + src_b1   (src_x: the block input; src_w1: MNAS_PACK_FWD weights of the expand conv)
+     * rounded to bf16 exactly as the kernels that would have stored them do.  x.scale / x.shift (BatchNorm of the expand conv),
+     * dy.y / dy.coef (depthwise conv), red_bn / red_partial (required) and phase = 0 as in the plain form; the partial tables
+     * have mnas_dw_src_rows(N,H,W,C,k,src_cin,nparts) rows. */
+    MnasActIn src_x;
+    const void*  src_w1;
+    const float* src_b1;
+    const void*  src_dy;
+    const void*  src_w3t;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
+int mnas_dw_src_rows(int N, int H, int W, int C, int k, int cin, int nparts);
 /* grad[c][0][kh][kw] (+)= sum_{p<nparts} wpartial[p][tap][c]   (pass nparts = rows1); wpartial is scratch like above */
 int mnas_dw_wgrad_finalize(float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
                            void* stream);

@@ -46,7 +46,8 @@ class MnasDwBwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
                 ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p), ("phase", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("src_cin", C.c_int32), ("src_x", MnasActIn), ("src_w1", c_void_p), ("src_b1", c_void_p), ("src_dy", c_void_p),
+                ("src_w3t", c_void_p)]
 
 
 class MnasDwExpFwd(C.Structure):
@@ -173,6 +174,7 @@ SYMBOLS = {
     "mnas_gram_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "mnas_dw_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mnas_dw_src_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mnas_dw_geometry": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_int)]),
     "mnas_dw_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mnas_stem_fwd": (c_int, [C.POINTER(MnasStemFwd), c_void_p]),

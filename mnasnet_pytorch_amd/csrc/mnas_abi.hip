@@ -156,6 +156,12 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = (const float*)p[6]; a.gin = p[7]; a.wpartial = (float*)p[8];
             a.red_bn = (const float*)p[9]; a.red_partial = (float*)p[10]; a.phase = i[6];
+            a.src_cin = i[7];      // SRC form (i[7] > 0): x.data / dy.g do not exist -- their slots carry the weight blocks
+            if (a.src_cin > 0) {
+                a.src_w1 = p[0]; a.src_w3t = p[3]; a.x.data = nullptr; a.dy.g = nullptr;
+                a.src_x.data = p[11]; a.src_x.scale = (const float*)p[12]; a.src_x.shift = (const float*)p[13];
+                a.src_dy = p[14]; a.src_b1 = (const float*)p[15];
+            }
             return mnas_dw_bwd(&a, stream);
         }
         case MNAS_OP_DW_WGRAD_FINALIZE:

@@ -50,11 +50,19 @@ struct DwArgs {
 // [2*cpw rounded to 16][exp_kpad+8] bf16, bias and input coefficients in LDS; channel blocks of at most 128 channels = 8 MFMA
 // tiles; at most DW_EXP_MAXPG 16-pixel groups of the G x iw ring patch per wave)
 #define DW_EXP_MAXPG 4
+#ifndef DW_SRC_LDS_CAP
+#define DW_SRC_LDS_CAP (52 * 1024)      // SRC backward: three workgroups per CU
+#endif
 static size_t dw_exp_lds(int cpw, int exp_kpad) {
     const int rows = (2 * cpw + 15) / 16 * 16;
     return (size_t)rows * (exp_kpad + 8) * 2 + (size_t)rows * 4 + (size_t)2 * exp_kpad * 4;
 }
-static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a, int exp_kpad = 0) {
+// src_cin > 0: geometry for the SRC backward (k_dw_bwd<.., SRC>): two weight blocks (expand conv, project conv^T) + two staging
+// rings of the narrow tensors (block input x, project-conv dy: src_cin channels) next to the three row rings
+static size_t dw_src_lds(int cpw, int kpad, int rr, int iw, int src_cin) {
+    return 2 * dw_exp_lds(cpw, kpad) + (size_t)2 * rr * iw * src_cin * 2;
+}
+static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a, int exp_kpad = 0, int src_cin = 0) {
     const int cps = C / 2;
     // Search (channel pairs per workgroup, column strips).  Whole pixel when it fits (cps <= 72), otherwise channel
     // blocks of >= 32 pairs (>= 128-byte runs per pixel).  Score = lane utilisation x occupancy / halo.
@@ -70,14 +78,15 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArg
             size_t lds = (size_t)nrings * rr * iw * cpw * 4;
             if (exp_kpad > 0) {
                 if (cpw > 64) continue;
-                lds += dw_exp_lds(cpw, exp_kpad);
+                lds += src_cin > 0 ? dw_src_lds(cpw, exp_kpad, rr, iw, src_cin) : dw_exp_lds(cpw, exp_kpad);
                 const int nth_ = ((sx * cpw + 63) / 64) * 64;
                 const int npg = ((rr / 2) * iw + 15) / 16;
                 if ((npg + nth_ / 64 - 1) / (nth_ / 64) > DW_EXP_MAXPG) continue;
+                if (src_cin > 0 && (iw * (src_cin / 8) + 63) / 64 > 2 * (nth_ / 64)) continue;   // <= 2 staging DMA blocks per wave per row
             }
             // two workgroups per CU either way (160 KB LDS): wide strips (78 KB) measured 8-10 % faster than 60 KB for
             // every launch form except the 5x5 weight-gradient sweep (3 rings), which is 14 % slower with them
-            const size_t cap = (k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024;
+            const size_t cap = src_cin > 0 ? (size_t)DW_SRC_LDS_CAP : ((k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024);
             if (lds > cap) continue;
             const int nth = ((sx * cpw + 63) / 64) * 64;
             const int rc = iw * cgn;
@@ -593,10 +602,28 @@ __global__ __launch_bounds__(256, 2) void k_dw_fwd_exp(DwArgs a, DwExp e, MnasAc
 //                                   its centre 4 columns become D[0] of the dy ring (D[q] = dy row iy-q)
 //   xa = act(x) row r = iy-PAD   -> WG: wacc[ky][kx] += D[ky][ox] * xa[ox+kx]      (dy rows r-ky+PAD = iy-ky)
 //   RED: the raw x centre values of row iy-PAD are in the x ring too: sum dz, sum dz*xhat for the emitted gin row.
-template <int KS, bool DG, bool WG, bool RED, int G>
+// SRC (round 4, the spatially tiled fused inverted-residual block): the g ring and the x ring are not copied from HBM -- the
+// tensors they would be copied from (g2 = dy3 . W3, the project conv's input gradient, and y1 = W1 act(x) + b1, the expand
+// conv's raw output: both t times wider than the block) were never written.  Their rows are COMPUTED on the matrix cores, one
+// row group ahead of the sweep, from the two NARROW tensors of the block (dy3 and the block input x, Cin channels), whose row
+// segments are staged in LDS by DMA one further group ahead.  The epilogues round exactly as the kernels that used to store
+// the tensors did (same MFMA, same k order), so everything downstream is bit-identical to the per-layer path.
+struct DwSrc {
+    const uint16_t* x;       // block input (N,H,W,Cin) bf16
+    const float* xs;         // its act-on-load coefficients ([Cin]) or NULL
+    const float* xt;
+    const uint16_t* w1;      // MNAS_PACK_FWD weights of the expand conv [C rounded to 16][Kpad]
+    const float* b1;         // [C] or NULL
+    const uint16_t* dy;      // materialised dy of the project conv (N,H,W,Cin) bf16
+    const uint16_t* w3t;     // MNAS_PACK_DGRAD weights of the project conv [C rounded to 16][Kpad]
+    int Cin, Kpad;
+};
+
+template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false>
 __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
-    float* __restrict__ red_partial, const float* __restrict__ red_bn) {
+    float* __restrict__ red_partial, const float* __restrict__ red_bn, DwSrc e) {
+    static_assert(!SRC || (DG && WG), "the SRC form is the fused sweep");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
     constexpr bool NEEDX = WG;                 // x ring only when the weight gradient is computed here
@@ -611,6 +638,45 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     const bool active = sxi < a.sx;
     const bool has_coef = x.scale != nullptr;
     const uint32_t* xglob = (const uint32_t*)x.data;
+    // ---- SRC: weight blocks, coefficient tables and the staging rings of the two narrow tensors
+    const int ntb = (cblk + 15) >> 4;                     // MFMA cout tiles of the channel block
+    const int ldw = e.Kpad + 8;
+    const int cgs = e.Cin >> 3, rcs = a.iw * cgs;         // staging: 16-byte chunks per pixel / per ring row
+    uint16_t* lds_w1 = (uint16_t*)(ring_x + (size_t)(2 * G) * a.rc * 4);      // [ntb*16][ldw]
+    uint16_t* lds_w3 = lds_w1 + (size_t)ntb * 16 * ldw;                       // [ntb*16][ldw]
+    float* lds_b1 = (float*)(lds_w3 + (size_t)ntb * 16 * ldw);               // [ntb*16]
+    float* lds_xc = lds_b1 + ntb * 16;                                        // [2][Kpad]
+    uint16_t* stage_d = (uint16_t*)(lds_xc + 2 * e.Kpad);                     // [2G][rcs*8]
+    uint16_t* stage_x = stage_d + (size_t)(2 * G) * rcs * 8;                  // [2G][rcs*8]
+    const int l15 = lane & 15, lg = lane >> 4;
+    const bool has_xc = SRC && e.xs != nullptr;
+    const int npg = (G * a.iw + 15) >> 4;                 // 16-pixel groups of the G x iw patch
+    int pr_[SRC ? DW_EXP_MAXPG : 1], px_[SRC ? DW_EXP_MAXPG : 1];
+    if constexpr (SRC) {
+        const int c0w = ((int)blockIdx.x % a.cblocks) * cblk;          // a workgroup only ever sees one channel block
+        const int kc8n = e.Kpad >> 3, cpad16 = (a.C + 15) / 16 * 16;
+        for (int q = tid; q < ntb * 16 * kc8n; q += blockDim.x) {
+            const int r = q / kc8n, k8 = q - r * kc8n;
+            uint4 v1 = make_uint4(0, 0, 0, 0), v3 = make_uint4(0, 0, 0, 0);
+            if (r < cblk && c0w + r < cpad16) {
+                v1 = *(const uint4*)(e.w1 + (size_t)(c0w + r) * e.Kpad + k8 * 8);
+                v3 = *(const uint4*)(e.w3t + (size_t)(c0w + r) * e.Kpad + k8 * 8);
+            }
+            *(uint4*)(lds_w1 + r * ldw + k8 * 8) = v1;
+            *(uint4*)(lds_w3 + r * ldw + k8 * 8) = v3;
+        }
+        for (int i = tid; i < ntb * 16; i += blockDim.x) lds_b1[i] = (e.b1 && i < cblk && c0w + i < a.C) ? e.b1[c0w + i] : 0.f;
+        for (int i = tid; i < 2 * e.Kpad; i += blockDim.x) {
+            const int r = i / e.Kpad, c = i - r * e.Kpad;
+            lds_xc[i] = (has_xc && c < e.Cin) ? (r == 0 ? e.xs[c] : e.xt[c]) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < DW_EXP_MAXPG; ++i) {
+            const int pi = (wave + nwaves * i) * 16 + l15;
+            pr_[i] = pi / a.iw; px_[i] = pi - pr_[i] * a.iw;
+            if (wave + nwaves * i >= npg || pi >= G * a.iw) pr_[i] = -1;
+        }
+    }
     const f2 zero2 = {0.f, 0.f};
     int cur_c0 = -1;
     f2 wt[DG ? KS * KS : 1], wacc[WG ? KS * KS : 1];
@@ -668,9 +734,78 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
         // double-buffered groups of G rows (see k_dw_fwd); the x ring runs PAD rows behind g/y: row iy of dy meets row
         // oy = iy - PAD of x, and each row of either is read from LDS exactly once
         auto dma_group = [&](int r0) {
-            dw_dma_rows<KS, G>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
+            if constexpr (!SRC) dw_dma_rows<KS, G>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
             dw_dma_rows<KS, G>(a, plan, ring_y, (const uint4*)d.y, n, r0, x0, c0, wave, nwaves);
-            if (NEEDX) dw_dma_rows<KS, G>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves);
+            if constexpr (!SRC) { if (NEEDX) dw_dma_rows<KS, G>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves); }
+        };
+        // ---- SRC: staging DMA of the narrow tensors' row segments (chunk q of a staging row = chunk q of the HBM row segment)
+        int sq[2]; bool sok[2];
+        if constexpr (SRC) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int b = wave + j * nwaves;
+                sq[j] = b * 64 + lane;
+                const int gx = x0 - PAD + sq[j] / cgs;
+                sok[j] = b * 64 < rcs && sq[j] < rcs && gx >= 0 && gx < a.W;
+            }
+        }
+        auto stage_rows = [&](uint16_t* stage, const uint16_t* src, int row0) {
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                const int gy = row0 + r;
+                if (gy < 0 || gy >= a.H) continue;                                   // uniform
+                const uint4* rowsrc = (const uint4*)src + (((size_t)n * a.H + gy) * a.W + (ptrdiff_t)(x0 - PAD)) * cgs;
+                uint32_t* rowdst = (uint32_t*)stage + (size_t)dw_slot<2 * G>(gy) * rcs * 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int b = wave + j * nwaves;
+                    if (b * 64 >= rcs) continue;                                      // uniform
+                    if (sok[j])
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rowsrc + sq[j]), (lds_void_ptr)(rowdst + b * 256), 16, 0, 0);
+                }
+            }
+        };
+        auto stage_group = [&](int r0) {          // group r0: dy rows [r0, r0+G) (-> ring_g), x rows [r0-PAD, r0-PAD+G) (-> ring_x)
+            stage_rows(stage_d, e.dy, r0);
+            stage_rows(stage_x, e.x, r0 - PAD);
+        };
+        // rows [row0, row0+G) of a ring computed from the staged rows: D[c][pixel] = W[c][:] . in[pixel][:] (+ bias), bf16
+        auto produce = [&](uint32_t* ring, const uint16_t* stage, const uint16_t* lw, const float* lb, bool xform, int row0) {
+#pragma unroll
+            for (int i = 0; i < DW_EXP_MAXPG; ++i) {
+                if (wave + nwaves * i >= npg) break;                                  // uniform per wave
+                const int gy = row0 + pr_[i], gx = x0 - PAD + px_[i];
+                const bool ok = pr_[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const int slot = dw_slot<2 * G>(ok ? gy : 0);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok && lg * 8 < e.Cin) v = *(const uint4*)(stage + (size_t)slot * rcs * 8 + px_[i] * e.Cin + lg * 8);
+                if (xform && ok && lg * 8 < e.Cin) {
+                    float sc[8], sh[8];
+                    *(float4*)&sc[0] = *(const float4*)(lds_xc + lg * 8);
+                    *(float4*)&sc[4] = *(const float4*)(lds_xc + lg * 8 + 4);
+                    *(float4*)&sh[0] = *(const float4*)(lds_xc + e.Kpad + lg * 8);
+                    *(float4*)&sh[4] = *(const float4*)(lds_xc + e.Kpad + lg * 8 + 4);
+                    v = act8(v, sc, sh);
+                }
+                const bf16x8_t bfrag = *(const bf16x8_t*)&v;
+                uint32_t* ringp = ring + (size_t)slot * a.rc * 4 + (size_t)px_[i] * a.cgn * 4 + lg * 2;
+                for (int nt = 0; nt < ntb; ++nt) {
+                    const bf16x8_t afrag = *(const bf16x8_t*)(lw + (nt * 16 + l15) * ldw + lg * 8);
+                    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc, 0, 0, 0);
+                    const int cl = nt * 16 + lg * 4;                      // first of this lane's 4 channels inside the block
+                    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lb) bb = *(const float4*)(lb + cl);
+                    uint2 pk;
+                    pk.x = pack_bf16(acc[0] + bb.x, acc[1] + bb.y);
+                    pk.y = pack_bf16(acc[2] + bb.z, acc[3] + bb.w);
+                    if (ok && cl < cblk) *(uint2*)(ringp + nt * 8) = pk;
+                }
+            }
+        };
+        auto produce_group = [&](int r0) {
+            produce(ring_g, stage_d, lds_w3, nullptr, false, r0);
+            produce(ring_x, stage_x, lds_w1, lds_b1, has_xc, r0 - PAD);
         };
         // input-gradient-only launch with the fused reduce: the raw x values of the rows it emits come from global memory,
         // fetched one group AHEAD (with the DMA, before the barrier that drains vmcnt) so that no load issued inside the
@@ -692,18 +827,35 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 #if MNAS_DW_XFILL
         if (NEEDX) dw_fill_edges<2 * G>(a, plan, ring_x, wave, nwaves, lane, has_coef);   // out-of-image columns of x act to 0
 #endif
-        dma_group(-PAD);
+        if constexpr (SRC) {
+            // prologue: staging of groups 0 and 1, rings of group 0
+            stage_group(-PAD);
+            dma_group(-PAD);
+            dma_barrier();                           // staging of group 0 landed (and the weight blocks are visible)
+            if (nsteps > 1) stage_group(-PAD + G);
+            produce_group(-PAD);
+        } else {
+            dma_group(-PAD);
+        }
         load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
             dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
+            if constexpr (SRC) {
+                // rings of group s are complete (y by DMA, g / x produced during step s-1); staging of group s+1 has landed
+                if (s + 1 < nsteps) {
+                    dma_group(r0 + G);
+                    if (s + 2 < nsteps) stage_group(r0 + 2 * G);
+                    produce_group(r0 + G);
+                }
+            }
             if constexpr (REDG) {
 #pragma unroll
                 for (int j = 0; j < G; ++j)
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) xq[j][ox] = xn[j][ox];
             }
-            if (s + 1 < nsteps) { dma_group(r0 + G); load_xn(r0 + G); }
+            if constexpr (!SRC) { if (s + 1 < nsteps) { dma_group(r0 + G); load_xn(r0 + G); } }
             if (!active) continue;
 #pragma unroll 1       // unrolling the group would drop the ring-shift moves (as in k_dw_fwd), but needs > 168 VGPRs: measured 266 -> 300 us at 2 waves/SIMD
             for (int j = 0; j < G; ++j) {
@@ -826,10 +978,10 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 static int dw_rings(int form) { return form < 0 ? 1 : (form == 1 ? 2 : 3); }      // form: -1 forward, else phase
 // Pick rows-per-group G in {4, 2} and the strip geometry for a launch form: 2-row groups halve the ring footprint (wider
 // strips / more channels per workgroup) at the price of a barrier every 2 rows instead of 4 (priced at 7 %).
-static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g, int exp_kpad = 0) {
+static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g, int exp_kpad = 0, int src_cin = 0) {
     DwArgs a4, a2;
     const int nrings = dw_rings(form);
-    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4, exp_kpad), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2, exp_kpad);
+    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4, exp_kpad, src_cin), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2, exp_kpad, src_cin);
     if (!ok4 && !ok2) return false;
     if (ok2 && (!ok4 || 0.93f * a2.score > a4.score)) { *a = a2; *g = 2; }
     else { *a = a4; *g = 4; }
@@ -923,9 +1075,43 @@ extern "C" int mnas_dw_exp_fwd(const MnasDwExpFwd* c, void* stream) {
     return MNAS_OK;
 }
 
+// SRC form: geometry / partial-table rows (both tables of the launch, like which = 1 of mnas_dw_rows)
+static bool dw_src_ok(int C, int cin) { return cin >= 8 && !(cin & 7) && cin <= 32 && !(C & 7); }
+extern "C" int mnas_dw_src_rows(int N, int H, int W, int C, int k, int cin, int nparts) {
+    if (!dw_src_ok(C, cin) || (k != 3 && k != 5)) return -1;
+    DwArgs a;
+    int g;
+    if (!dw_choose(N, H, W, C, k, 0, &a, &g, 32, cin) || !dw_finish(&a, nparts)) return -1;
+    return a.geff / a.cblocks;
+}
+static int dw_bwd_src(const MnasDwBwd* c, hipStream_t s) {
+    if (c->phase != 0 || !c->red_bn || !c->red_partial || !dw_src_ok(c->C, c->src_cin)) return MNAS_EINVAL;
+    if (!c->src_x.data || !c->src_w1 || !c->src_w3t || !c->dy.y || !c->dy.coef || !c->w || !c->gin || !c->wpartial) return MNAS_EINVAL;
+    DwArgs a;
+    int g;
+    if (!dw_choose(c->N, c->H, c->W, c->C, c->k, 0, &a, &g, 32, c->src_cin) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
+    a.nt = (mnas_nt_mask() & MNAS_NT_DW_BWD) ? 1 : 0;
+    DwSrc e;
+    e.x = (const uint16_t*)c->src_x.data; e.xs = c->src_x.scale; e.xt = c->src_x.shift;
+    e.w1 = (const uint16_t*)c->src_w1; e.b1 = c->src_b1; e.dy = (const uint16_t*)c->src_dy; e.w3t = (const uint16_t*)c->src_w3t;
+    e.Cin = c->src_cin; e.Kpad = 32;
+    size_t lds = (size_t)3 * 2 * g * a.rc * 16 + dw_src_lds(a.cpw, 32, 2 * g, a.iw, c->src_cin);
+    const size_t red_need = (size_t)a.sx * c->k * c->k * 2 * a.cpw * sizeof(float);
+    if (lds < red_need) lds = red_need;
+#define MNAS_DWS(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
+                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, e)
+    if (c->k == 3) { if (g == 4) MNAS_DWS(3, 4); else MNAS_DWS(3, 2); }
+    else { if (g == 4) MNAS_DWS(5, 4); else MNAS_DWS(5, 2); }
+#undef MNAS_DWS
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1 || c->phase < 0 || c->phase > 2) return MNAS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (c->src_dy) return dw_bwd_src(c, s);
+    if (!c->x.data || !c->dy.g) return MNAS_EINVAL;
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
     // phase 0: everything in one fused sweep.  phase 1: input gradient (+reduce).  phase 2: weight gradient.
     const bool want_dg = c->phase != 2, want_wg = c->phase != 1;
@@ -938,7 +1124,7 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     const size_t red_need = (size_t)a.sx * (want_wg ? c->k * c->k : 2) * 2 * a.cpw * sizeof(float);   // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
 #define MNAS_DWB(K_, DG_, WG_, R_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
-                                                         c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
+                                                         c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{})
 #define MNAS_DWB_G(K_, DG_, WG_, R_) do { if (g == 4) MNAS_DWB(K_, DG_, WG_, R_, 4); else MNAS_DWB(K_, DG_, WG_, R_, 2); } while (0)
     if (c->k == 3) {
         if (want_dg && want_wg) { if (red) MNAS_DWB_G(3, true, true, true); else MNAS_DWB_G(3, true, true, false); }

@@ -110,3 +110,73 @@ def test_pw_bwd_recomp(shape, variant, nparts):
     # dy.y == NULL without forward weights: rejected
     rc, _, _ = _pw_bwd(M, Ci, Co, nparts, xin, grad_in(gd, None, bd), wdg, gin=gin1)
     assert rc == L.EINVAL
+
+
+# ---------------------------------------------------------------------------------------------------
+# depthwise backward, SRC form: g2 and y1 recomputed from the block's narrow tensors
+SRC = [  # N,H,W,C,E,k
+    (2, 12, 12, 16, 48, 3), (1, 37, 29, 16, 48, 3), (2, 20, 20, 24, 72, 5), (1, 9, 50, 24, 72, 5), (1, 112, 112, 16, 48, 3),
+    (2, 56, 56, 24, 72, 5), (3, 5, 7, 16, 48, 3),
+]
+
+
+@pytest.mark.parametrize("shape", SRC)
+@pytest.mark.parametrize("virt", [False, True])
+def test_dw_bwd_src(shape, virt):
+    """Build the tensors the per-layer kernels would have stored (y1 from mnas_conv_gemm mode 0, g2 from mnas_pw_bwd together
+    with the materialised dy3), run the plain fused depthwise backward on them, then the SRC form on (x, dy3) only."""
+    lib = L.load()
+    N, H, W, Cc, E, k = shape
+    M = N * H * W
+    x = _x((N, Cc, H, W), 1)
+    bx = rand_bn_coefs(Cc, 21, O)
+    w1 = bf16r(O.det_param("t.e.weight", (E, Cc, 1, 1), 2))
+    b1 = 0.1 * O.det_uniform((E,), 3)
+    w3 = bf16r(O.det_param("t.p.weight", (Cc, E, 1, 1), 4))
+    wd = O.det_param("t.dw.weight", (E, 1, k, k), 6)
+    bn1, bn2, bn3 = rand_bn_coefs(E, 31, O), rand_bn_coefs(E, 32, O), rand_bn_coefs(Cc, 33, O)
+    y2 = _x((N, E, H, W), 8)            # raw depthwise output (any values: the backward only reads it)
+    G, y3 = _x((N, Cc, H, W), 9), _x((N, Cc, H, W), 10)
+    xd, y2d, Gd, y3d = nhwc(x), nhwc(y2), nhwc(G), nhwc(y3)
+    bxd, bn1d, bn2d, bn3d, b1d = bx.cuda(), bn1.cuda(), bn2.cuda(), bn3.cuda(), b1.cuda()
+    xin = act_in(xd, bxd[0], bxd[1]) if virt else act_in(xd)
+    w1f, w3d, wdp = pack(w1, L.PACK_FWD), pack(w3, L.PACK_DGRAD), pack(wd, L.PACK_DW)
+    # per-layer tensors
+    y1d, _ = conv_gemm(0, N, H, W, Cc, H, W, E, 1, 1, 0, w1f, bias=b1d, act=xin, nparts=max(1, min(64, M // 64)))
+    g2d = torch.full((N, H, W, E), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dy3d = torch.full((N, H, W, Cc), float("nan"), dtype=torch.bfloat16, device="cuda")
+    a2in = act_in(y2d, bn2d[0], bn2d[1])
+    rc, _, _ = _pw_bwd(M, E, Cc, 3, a2in, grad_in(Gd, y3d, bn3d), w3d, gin=g2d, red=(y2d, bn2d))
+    assert rc == 0
+    rc, _, _ = _pw_bwd(M, E, Cc, 3, a2in, grad_in(Gd, y3d, bn3d), w3d, gin=None, red=(y2d, bn2d), dy_out=dy3d)
+    assert rc == 0
+    nparts = 37
+
+    def run(src):
+        rows = lib.mnas_dw_src_rows(N, H, W, E, k, Cc, nparts) if src else lib.mnas_dw_rows(N, H, W, E, k, nparts, 1)
+        assert rows >= 1
+        gin = torch.full((N, H, W, E), float("nan"), dtype=torch.bfloat16, device="cuda")
+        wpart = torch.full((rows, k * k, E), float("nan"), device="cuda")
+        redp = torch.full((2, E, rows), float("nan"), device="cuda")
+        a_ = L.MnasDwBwd()
+        a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts, a_.phase = N, H, W, E, k, nparts, 0
+        a_.w, a_.gin, a_.wpartial = wdp.data_ptr(), gin.data_ptr(), wpart.data_ptr()
+        a_.red_bn, a_.red_partial = bn1d.data_ptr(), redp.data_ptr()
+        if src:
+            a_.x, a_.dy = act_in(None, bn1d[0], bn1d[1]), grad_in(None, y2d, bn2d)
+            a_.src_cin, a_.src_x = Cc, xin
+            a_.src_w1, a_.src_b1, a_.src_dy, a_.src_w3t = w1f.data_ptr(), b1d.data_ptr(), dy3d.data_ptr(), w3d.data_ptr()
+        else:
+            a_.x, a_.dy = act_in(y1d, bn1d[0], bn1d[1]), grad_in(g2d, y2d, bn2d)
+        L.check(lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()), "dw_bwd")
+        torch.cuda.synchronize()
+        grad = torch.full((E, 1, k, k), float("nan"), device="cuda")
+        L.check(lib.mnas_dw_wgrad_finalize(wpart.data_ptr(), rows, E, k, grad.data_ptr(), 0, L.cur_stream()))
+        return gin, grad, redp.double().sum(-1)
+
+    g_ref, w_ref, r_ref = run(False)
+    g_src, w_src, r_src = run(True)
+    assert torch.equal(g_ref.view(torch.int16), g_src.view(torch.int16)), \
+        "input gradient differs: max |d| = %g" % float((g_ref.float() - g_src.float()).abs().max())
+    # different strip geometry = different summation order of the partial tables
+    assert relerr(w_src, w_ref) < 1e-4 and relerr(r_src, r_ref) < 1e-4
