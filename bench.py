@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE: 256; --clusters: 64)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--hw", type=str, default="", help="rectangular input HxW (BASELINE config 5 clusters: 384x512, 512x512, "
                                                        "512x384); overrides --size")
@@ -46,6 +46,11 @@ def parse():
                                                      "(the SE block of that config has no counterpart in the reference: not built)")
     ap.add_argument("--se", action="store_true", help="BASELINE config 4 in full: 5x5 depthwise convs AND a squeeze-excite block "
                                                      "(se_ratio 0.25, build-defined: the reference has none) in every MBConv_block")
+    ap.add_argument("--clusters", action="store_true",
+                    help="BASELINE config 5: rectangular-crop resolution clusters (384x512 / 512x512 / 512x384, datasets.py:331-335), "
+                         "ONE cluster per step drawn by DistributedClusterSampler (cluster_random_sampler.py:31-55 made rank-aware), "
+                         "the three compiled programs live at once.  Reports same-cluster-per-step img/s as `value` and, with "
+                         "--gpus N > 1, the mixed-across-ranks rate (every rank of a step on a different cluster) next to it")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-INCLUSIVE step rate (never `value`): pinned host batches, "
                                                       "double-buffered upload on a copy stream under the previous step, as fp32 "
                                                       "(what train.py:427 uploads) and as uint8 with the normalisation fused into the stem")
@@ -54,7 +59,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed window until this much timed work exists; "
                                                                    "the median window is reported")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 64 if args.clusters else 256
+    return args
 
 
 def conv_table(engine, N, H, W):
@@ -282,6 +290,83 @@ def h2d_mode(trainer, model, x_dev, target, steps, dev):
     return out
 
 
+CLUSTER_SHAPES = ((384, 512), (512, 512), (512, 384))        # (H, W) of clusters 0, 1, 2: datasets.py:331-335
+
+
+def clusters_mode(args, trainer, dev, rank, world, barrier, overrides):
+    """BASELINE configs[4] / SURVEY 8(d): "per step one shape from {384x512, 512x512, 512x384}; report both
+    same-cluster-per-step and mixed-across-ranks".  The step schedule comes from DistributedClusterSampler over a synthetic
+    dataset with three equally sized clusters (identical on every rank); a step's batch is the resident synthetic batch of its
+    cluster's shape.  same-cluster: every rank runs the schedule's cluster (what the sampler guarantees); mixed-across-ranks:
+    rank r runs the cluster of schedule position s + r, so the ranks of one step disagree (the straggler case the sampler
+    exists to avoid).  Timed as the main bench: exactly --steps steps between barrier + synchronize, MAX over ranks, repeated
+    until --min-seconds, median window."""
+    import types
+    import torch
+    from mnasnet_pytorch_amd.sampler import DistributedClusterSampler
+    B, K = args.batch, args.steps
+    per_cluster = ((K + 2) // 3 + 1) * B * world
+    ds = types.SimpleNamespace(cluster_indices=[list(range(c * per_cluster, (c + 1) * per_cluster)) for c in range(3)])
+    sampler = DistributedClusterSampler(ds, B, num_replicas=world, rank=rank, shuffle=True, seed=0)
+    sampler.set_epoch(0)
+    sched = sampler.cluster_of_step()[:K]
+    assert len(sched) == K and set(sched) <= {0, 1, 2}
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    xs = [torch.randn(B, 3, h, w, device=dev, generator=g) for h, w in CLUSTER_SHAPES]
+    target = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    for _ in range(max(1, args.warmup // 3)):                # builds the three programs; all stay alive
+        for c in range(3):
+            trainer.step(xs[c], target)
+    barrier()
+    eng = trainer.engine
+    live = sorted({k[1:3] for k, lst in eng.programs.items() if lst})
+
+    def run(order):
+        windows = []
+        while True:
+            barrier()
+            t0 = time.perf_counter()
+            for c in order:
+                trainer.step(xs[c], target)
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                import torch.distributed as dist
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt)
+            windows.append(dt)
+            if sum(windows) >= args.min_seconds or len(windows) >= 50:
+                break
+        windows.sort()
+        dt = windows[(len(windows) - 1) // 2]
+        return {"images_per_sec": round(B * world * K / dt, 1), "ms_per_step": round(dt / K * 1e3, 3), "windows": len(windows)}
+
+    same = run(sched)
+    mixed = run([sched[(s + rank) % K] for s in range(K)]) if world > 1 else None
+    per_shape = {}
+    for c, (h, w) in enumerate(CLUSTER_SHAPES):             # one shape per run, for reference (what --hw measures)
+        r = run([c] * K)
+        per_shape["%dx%d" % (h, w)] = {"images_per_sec": r["images_per_sec"], "ms_per_step": r["ms_per_step"]}
+    if rank != 0:
+        return None
+    return {
+        "metric": "images/sec MNASNet-1.0 rectangular-crop clusters bf16 train step", "value": same["images_per_sec"],
+        "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": same["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "overrides": overrides,
+        "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes) fwd+bwd+Adam, bs=%d/GPU, "
+                               "one resolution cluster per step from {384x512, 512x512, 512x384} (DistributedClusterSampler), "
+                               "per-rank BatchNorm" % B,
+                   "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "steps_per_cluster": {"%dx%d" % CLUSTER_SHAPES[c]: sched.count(c) for c in range(3)},
+                   "programs_live": ["%dx%d" % hw for hw in live]},
+        "clusters": {"same_cluster_per_step": same, "mixed_across_ranks": mixed,
+                     "mixed_note": None if world > 1 else "one rank: identical to same_cluster_per_step by construction",
+                     "single_shape_runs": per_shape},
+    }
+
+
 # Diagnosis switches: MNAS_* environment variables that change how the engine compiles the step.  They exist for same-call A/B
 # measurements only; every one that is honoured is listed in the JSON line ("overrides") so that a number measured with one
 # can never pass for the default configuration.
@@ -398,6 +483,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.clusters:
+        del x
+        res = clusters_mode(args, trainer, dev, rank, world, barrier, overrides)
+        if res is not None:
+            print(json.dumps(res))
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     for _ in range(args.warmup):
         trainer.step(x, target)
     barrier()

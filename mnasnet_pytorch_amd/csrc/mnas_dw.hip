@@ -81,8 +81,8 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArg
                 lds += src_cin > 0 ? dw_src_lds(cpw, exp_kpad, rr, iw, src_cin) : dw_exp_lds(cpw, exp_kpad);
                 const int nth_ = ((sx * cpw + 63) / 64) * 64;
                 const int npg = ((rr / 2) * iw + 15) / 16;
-                if ((npg + nth_ / 64 - 1) / (nth_ / 64) > DW_EXP_MAXPG) continue;
-                if (src_cin > 0 && (iw * (src_cin / 8) + 63) / 64 > 2 * (nth_ / 64)) continue;   // <= 2 staging DMA blocks per wave per row
+                if (src_cin == 0 && (npg + nth_ / 64 - 1) / (nth_ / 64) > DW_EXP_MAXPG) continue;
+                if (src_cin > 0 && nth_ > 192) continue;                       // + one producer wave = 256 threads
             }
             // two workgroups per CU either way (160 KB LDS): wide strips (78 KB) measured 8-10 % faster than 60 KB for
             // every launch form except the 5x5 weight-gradient sweep (3 rings), which is 14 % slower with them
@@ -608,6 +608,11 @@ __global__ __launch_bounds__(256, 2) void k_dw_fwd_exp(DwArgs a, DwExp e, MnasAc
 // row group ahead of the sweep, from the two NARROW tensors of the block (dy3 and the block input x, Cin channels), whose row
 // segments are staged in LDS by DMA one further group ahead.  The epilogues round exactly as the kernels that used to store
 // the tensors did (same MFMA, same k order), so everything downstream is bit-identical to the per-layer path.
+// WAVE SPECIALISATION: the workgroup carries ONE extra wave (the last one) that does nothing but this: it issues the staging
+// DMA and runs the MFMAs + epilogues of the next group while the sweep waves work the current group on the vector ALUs -- the
+// matrix pipe and the vector pipe of a CU are busy at the same time, from different waves, and the producer's dependent
+// LDS -> MFMA -> pack -> LDS chains sit on nobody's critical path (folded into the sweep waves, the same work made the launch
+// 2x slower: 614 vs 315 us at 112x112, 43 spilled VGPRs).  The sweep waves are exactly those of the plain kernel.
 struct DwSrc {
     const uint16_t* x;       // block input (N,H,W,Cin) bf16
     const float* xs;         // its act-on-load coefficients ([Cin]) or NULL
@@ -619,7 +624,7 @@ struct DwSrc {
     int Cin, Kpad;
 };
 
-template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false>
+template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false, int NTB = 1>
 __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
     float* __restrict__ red_partial, const float* __restrict__ red_bn, DwSrc e) {
@@ -633,9 +638,10 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     uint32_t* ring_y = ring_g + (size_t)(2 * G) * a.rc * 4;
     uint32_t* ring_x = ring_y + (size_t)(2 * G) * a.rc * 4;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (blockDim.x >> 6) - (SRC ? 1 : 0);   // sweep waves
+    const bool is_prod = SRC && wave == nwaves;           // SRC: the extra (last) wave produces the g / x ring rows
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
-    const bool active = sxi < a.sx;
+    const bool active = sxi < a.sx;                       // (false for the producer wave: tid >= sx * cpw)
     const bool has_coef = x.scale != nullptr;
     const uint32_t* xglob = (const uint32_t*)x.data;
     // ---- SRC: weight blocks, coefficient tables and the staging rings of the two narrow tensors
@@ -651,7 +657,6 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     const int l15 = lane & 15, lg = lane >> 4;
     const bool has_xc = SRC && e.xs != nullptr;
     const int npg = (G * a.iw + 15) >> 4;                 // 16-pixel groups of the G x iw patch
-    int pr_[SRC ? DW_EXP_MAXPG : 1], px_[SRC ? DW_EXP_MAXPG : 1];
     if constexpr (SRC) {
         const int c0w = ((int)blockIdx.x % a.cblocks) * cblk;          // a workgroup only ever sees one channel block
         const int kc8n = e.Kpad >> 3, cpad16 = (a.C + 15) / 16 * 16;
@@ -670,12 +675,6 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             const int r = i / e.Kpad, c = i - r * e.Kpad;
             lds_xc[i] = (has_xc && c < e.Cin) ? (r == 0 ? e.xs[c] : e.xt[c]) : 0.f;
         }
-#pragma unroll
-        for (int i = 0; i < DW_EXP_MAXPG; ++i) {
-            const int pi = (wave + nwaves * i) * 16 + l15;
-            pr_[i] = pi / a.iw; px_[i] = pi - pr_[i] * a.iw;
-            if (wave + nwaves * i >= npg || pi >= G * a.iw) pr_[i] = -1;
-        }
     }
     const f2 zero2 = {0.f, 0.f};
     int cur_c0 = -1;
@@ -688,6 +687,105 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
+    if (SRC && is_prod) {
+      if constexpr (SRC) {
+        // ================= producer wave: its own loop nest (disjoint live ranges: the kernel's register count is the larger of
+        // the two roles, not their sum), meeting the sweep waves at the same barriers =================
+        __syncthreads();                                  // weight blocks / tables are in LDS
+        bf16x8_t af1[NTB], af3[NTB];                      // expand / project^T weight fragments, bias: registers for the whole kernel
+        float4 bb1[NTB];
+        float xsc[8], xsh[8];
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) {
+            af1[nt] = *(const bf16x8_t*)(lds_w1 + (nt * 16 + l15) * ldw + lg * 8);
+            af3[nt] = *(const bf16x8_t*)(lds_w3 + (nt * 16 + l15) * ldw + lg * 8);
+            bb1[nt] = *(const float4*)(lds_b1 + nt * 16 + lg * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xsc[j] = lds_xc[(lg * 8 + j) & (e.Kpad - 1)]; xsh[j] = lds_xc[e.Kpad + ((lg * 8 + j) & (e.Kpad - 1))]; }
+        for (int item = blockIdx.x; item < a.items; item += a.geff) {
+            int n, x0, c0;
+            dw_item(a, item, n, x0, c0);
+            cur_c0 = c0;
+            // ---- staging: staging DMA of the narrow tensors' row segments (chunk q of a staging row = chunk q of the HBM
+            // row segment: all Cin channels of iw pixels, contiguous)
+            auto stage_rows = [&](uint16_t* stage, const uint16_t* src, int row0) {
+#pragma unroll
+                for (int r = 0; r < G; ++r) {
+                    const int gy = row0 + r;
+                    if (gy < 0 || gy >= a.H) continue;                                   // uniform
+                    const uint4* rowsrc = (const uint4*)src + (((size_t)n * a.H + gy) * a.W + (ptrdiff_t)(x0 - PAD)) * cgs;
+                    uint32_t* rowdst = (uint32_t*)stage + (size_t)dw_slot<2 * G>(gy) * rcs * 4;
+                    for (int b = 0; b * 64 < rcs; ++b) {
+                        const int q = b * 64 + lane, gx = x0 - PAD + q / cgs;
+                        if (q < rcs && gx >= 0 && gx < a.W)
+                            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rowsrc + q), (lds_void_ptr)(rowdst + b * 256), 16, 0, 0);
+                    }
+                }
+            };
+            auto stage_group = [&](int r0) {          // group r0: dy rows [r0, r0+G) (-> ring_g), x rows [r0-PAD, r0-PAD+G) (-> ring_x)
+                stage_rows(stage_d, e.dy, r0);
+                stage_rows(stage_x, e.x, r0 - PAD);
+            };
+            // Ring rows of group r0 computed from the staged rows: D[c][pixel] = W[c][:] . in[pixel][:] (+ bias), rounded to bf16.
+            // Lane l15 <-> pixel pg*16 + l15 of the G x iw patch; a lane's 4 accumulators are 4 consecutive channels of that pixel.
+            // Both producers of a pixel group run together: 2 LDS reads, 2*NTB independent MFMAs back to back (weight fragments and
+            // bias live in registers for the whole kernel), then the 2*NTB pack + store epilogues.
+            auto produce_group = [&](int r0) {
+                for (int pg = 0; pg < npg; ++pg) {
+                    const int pi = pg * 16 + l15;
+                    const int pr = pi / a.iw, px = pi - pr * a.iw;
+                    const int gx = x0 - PAD + px;
+                    const bool cok = pi < G * a.iw && gx >= 0 && gx < a.W;
+                    const int gyd = r0 + pr, gyx = r0 - PAD + pr;
+                    const bool okd = cok && gyd >= 0 && gyd < a.H, okx = cok && gyx >= 0 && gyx < a.H;
+                    const int sd = dw_slot<2 * G>(okd ? gyd : 0), sx_ = dw_slot<2 * G>(okx ? gyx : 0);
+                    uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
+                    if (lg * 8 < e.Cin) {
+                        if (okd) vd = *(const uint4*)(stage_d + (size_t)sd * rcs * 8 + px * e.Cin + lg * 8);
+                        if (okx) vx = *(const uint4*)(stage_x + (size_t)sx_ * rcs * 8 + px * e.Cin + lg * 8);
+                        if (has_xc && okx) vx = act8(vx, xsc, xsh);
+                    }
+                    const bf16x8_t bd = *(const bf16x8_t*)&vd, bx = *(const bf16x8_t*)&vx;
+                    f32x4_t accd[NTB], accx[NTB];
+#pragma unroll
+                    for (int nt = 0; nt < NTB; ++nt) {
+                        accd[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[nt], bd, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[nt], bx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    }
+                    uint32_t* rpd = ring_g + (size_t)sd * a.rc * 4 + (size_t)px * a.cgn * 4 + lg * 2;
+                    uint32_t* rpx = ring_x + (size_t)sx_ * a.rc * 4 + (size_t)px * a.cgn * 4 + lg * 2;
+#pragma unroll
+                    for (int nt = 0; nt < NTB; ++nt) {
+                        const bool cin_blk = nt * 16 + lg * 4 < cblk;
+                        uint2 pk;
+                        pk.x = pack_bf16(accd[nt][0], accd[nt][1]);
+                        pk.y = pack_bf16(accd[nt][2], accd[nt][3]);
+                        if (okd && cin_blk) *(uint2*)(rpd + nt * 8) = pk;
+                        pk.x = pack_bf16(accx[nt][0] + bb1[nt].x, accx[nt][1] + bb1[nt].y);
+                        pk.y = pack_bf16(accx[nt][2] + bb1[nt].z, accx[nt][3] + bb1[nt].w);
+                        if (okx && cin_blk) *(uint2*)(rpx + nt * 8) = pk;
+                    }
+                }
+            };
+
+            __syncthreads();                             // (sweep waves: previous item's last group consumed)
+            stage_group(-PAD);
+            dma_barrier();                               // staging of group 0 landed
+            if (nsteps > 1) stage_group(-PAD + G);
+            produce_group(-PAD);
+            for (int s = 0; s < nsteps; ++s) {
+                const int r0 = -PAD + s * G;
+                dma_barrier();                           // staging of group s+1 landed; readers of ring buffer (s+1)%2 retired
+                if (s + 1 < nsteps) {
+                    if (s + 2 < nsteps) stage_group(r0 + 2 * G);
+                    produce_group(r0 + G);
+                }
+            }
+        }
+      }
+    } else {
+    if constexpr (SRC) __syncthreads();                   // (producer wave: weight blocks visible)
     for (int item = blockIdx.x; item < a.items; item += a.geff) {
         int n, x0, c0;
         dw_item(a, item, n, x0, c0);
@@ -738,75 +836,6 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             dw_dma_rows<KS, G>(a, plan, ring_y, (const uint4*)d.y, n, r0, x0, c0, wave, nwaves);
             if constexpr (!SRC) { if (NEEDX) dw_dma_rows<KS, G>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves); }
         };
-        // ---- SRC: staging DMA of the narrow tensors' row segments (chunk q of a staging row = chunk q of the HBM row segment)
-        int sq[2]; bool sok[2];
-        if constexpr (SRC) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int b = wave + j * nwaves;
-                sq[j] = b * 64 + lane;
-                const int gx = x0 - PAD + sq[j] / cgs;
-                sok[j] = b * 64 < rcs && sq[j] < rcs && gx >= 0 && gx < a.W;
-            }
-        }
-        auto stage_rows = [&](uint16_t* stage, const uint16_t* src, int row0) {
-#pragma unroll
-            for (int r = 0; r < G; ++r) {
-                const int gy = row0 + r;
-                if (gy < 0 || gy >= a.H) continue;                                   // uniform
-                const uint4* rowsrc = (const uint4*)src + (((size_t)n * a.H + gy) * a.W + (ptrdiff_t)(x0 - PAD)) * cgs;
-                uint32_t* rowdst = (uint32_t*)stage + (size_t)dw_slot<2 * G>(gy) * rcs * 4;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int b = wave + j * nwaves;
-                    if (b * 64 >= rcs) continue;                                      // uniform
-                    if (sok[j])
-                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rowsrc + sq[j]), (lds_void_ptr)(rowdst + b * 256), 16, 0, 0);
-                }
-            }
-        };
-        auto stage_group = [&](int r0) {          // group r0: dy rows [r0, r0+G) (-> ring_g), x rows [r0-PAD, r0-PAD+G) (-> ring_x)
-            stage_rows(stage_d, e.dy, r0);
-            stage_rows(stage_x, e.x, r0 - PAD);
-        };
-        // rows [row0, row0+G) of a ring computed from the staged rows: D[c][pixel] = W[c][:] . in[pixel][:] (+ bias), bf16
-        auto produce = [&](uint32_t* ring, const uint16_t* stage, const uint16_t* lw, const float* lb, bool xform, int row0) {
-#pragma unroll
-            for (int i = 0; i < DW_EXP_MAXPG; ++i) {
-                if (wave + nwaves * i >= npg) break;                                  // uniform per wave
-                const int gy = row0 + pr_[i], gx = x0 - PAD + px_[i];
-                const bool ok = pr_[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                const int slot = dw_slot<2 * G>(ok ? gy : 0);
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok && lg * 8 < e.Cin) v = *(const uint4*)(stage + (size_t)slot * rcs * 8 + px_[i] * e.Cin + lg * 8);
-                if (xform && ok && lg * 8 < e.Cin) {
-                    float sc[8], sh[8];
-                    *(float4*)&sc[0] = *(const float4*)(lds_xc + lg * 8);
-                    *(float4*)&sc[4] = *(const float4*)(lds_xc + lg * 8 + 4);
-                    *(float4*)&sh[0] = *(const float4*)(lds_xc + e.Kpad + lg * 8);
-                    *(float4*)&sh[4] = *(const float4*)(lds_xc + e.Kpad + lg * 8 + 4);
-                    v = act8(v, sc, sh);
-                }
-                const bf16x8_t bfrag = *(const bf16x8_t*)&v;
-                uint32_t* ringp = ring + (size_t)slot * a.rc * 4 + (size_t)px_[i] * a.cgn * 4 + lg * 2;
-                for (int nt = 0; nt < ntb; ++nt) {
-                    const bf16x8_t afrag = *(const bf16x8_t*)(lw + (nt * 16 + l15) * ldw + lg * 8);
-                    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc, 0, 0, 0);
-                    const int cl = nt * 16 + lg * 4;                      // first of this lane's 4 channels inside the block
-                    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (lb) bb = *(const float4*)(lb + cl);
-                    uint2 pk;
-                    pk.x = pack_bf16(acc[0] + bb.x, acc[1] + bb.y);
-                    pk.y = pack_bf16(acc[2] + bb.z, acc[3] + bb.w);
-                    if (ok && cl < cblk) *(uint2*)(ringp + nt * 8) = pk;
-                }
-            }
-        };
-        auto produce_group = [&](int r0) {
-            produce(ring_g, stage_d, lds_w3, nullptr, false, r0);
-            produce(ring_x, stage_x, lds_w1, lds_b1, has_xc, r0 - PAD);
-        };
         // input-gradient-only launch with the fused reduce: the raw x values of the rows it emits come from global memory,
         // fetched one group AHEAD (with the DMA, before the barrier that drains vmcnt) so that no load issued inside the
         // compute phase has to wait behind the in-flight DMA of the next group (vmcnt retires in order)
@@ -827,35 +856,20 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 #if MNAS_DW_XFILL
         if (NEEDX) dw_fill_edges<2 * G>(a, plan, ring_x, wave, nwaves, lane, has_coef);   // out-of-image columns of x act to 0
 #endif
-        if constexpr (SRC) {
-            // prologue: staging of groups 0 and 1, rings of group 0
-            stage_group(-PAD);
-            dma_group(-PAD);
-            dma_barrier();                           // staging of group 0 landed (and the weight blocks are visible)
-            if (nsteps > 1) stage_group(-PAD + G);
-            produce_group(-PAD);
-        } else {
-            dma_group(-PAD);
-        }
+        dma_group(-PAD);
+        if constexpr (SRC) dma_barrier();            // (producer wave: staging of group 0 landed -> it produces the rings of group 0)
         load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
             dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
-            if constexpr (SRC) {
-                // rings of group s are complete (y by DMA, g / x produced during step s-1); staging of group s+1 has landed
-                if (s + 1 < nsteps) {
-                    dma_group(r0 + G);
-                    if (s + 2 < nsteps) stage_group(r0 + 2 * G);
-                    produce_group(r0 + G);
-                }
-            }
+            // (SRC: the rings of group s are complete -- y by DMA, g / x produced by the producer wave during step s-1)
             if constexpr (REDG) {
 #pragma unroll
                 for (int j = 0; j < G; ++j)
 #pragma unroll
                     for (int ox = 0; ox < DW_BW; ++ox) xq[j][ox] = xn[j][ox];
             }
-            if constexpr (!SRC) { if (s + 1 < nsteps) { dma_group(r0 + G); load_xn(r0 + G); } }
+            if (s + 1 < nsteps) { dma_group(r0 + G); load_xn(r0 + G); }
             if (!active) continue;
 #pragma unroll 1       // unrolling the group would drop the ring-shift moves (as in k_dw_fwd), but needs > 168 VGPRs: measured 266 -> 300 us at 2 waves/SIMD
             for (int j = 0; j < G; ++j) {
@@ -952,6 +966,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             }
         }
     }
+    }       // sweep waves
     const int row = blockIdx.x / a.cblocks, rows = a.geff / a.cblocks;
     const int cb0 = (blockIdx.x % a.cblocks) * cblk;
     const bool any = cur_c0 >= 0;
@@ -1082,6 +1097,8 @@ extern "C" int mnas_dw_src_rows(int N, int H, int W, int C, int k, int cin, int 
     DwArgs a;
     int g;
     if (!dw_choose(N, H, W, C, k, 0, &a, &g, 32, cin) || !dw_finish(&a, nparts)) return -1;
+    const int ntb = (2 * a.cpw + 15) / 16;
+    if (ntb != 3 && ntb != 5) return -1;
     return a.geff / a.cblocks;
 }
 static int dw_bwd_src(const MnasDwBwd* c, hipStream_t s) {
@@ -1098,10 +1115,14 @@ static int dw_bwd_src(const MnasDwBwd* c, hipStream_t s) {
     size_t lds = (size_t)3 * 2 * g * a.rc * 16 + dw_src_lds(a.cpw, 32, 2 * g, a.iw, c->src_cin);
     const size_t red_need = (size_t)a.sx * c->k * c->k * 2 * a.cpw * sizeof(float);
     if (lds < red_need) lds = red_need;
-#define MNAS_DWS(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
-                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, e)
-    if (c->k == 3) { if (g == 4) MNAS_DWS(3, 4); else MNAS_DWS(3, 2); }
-    else { if (g == 4) MNAS_DWS(5, 4); else MNAS_DWS(5, 2); }
+    const int ntb = (2 * a.cpw + 15) / 16;
+    if (ntb != 3 && ntb != 5) return MNAS_EINVAL;          // 48- and 72-channel blocks (the 112x112 / 56x56 stages)
+#define MNAS_DWS(K_, G_, T_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, true, T_>), dim3(a.geff), dim3(a.nthreads + 64), lds, s, a, \
+                                                c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, e)
+#define MNAS_DWS_T(K_, G_) do { if (ntb == 3) MNAS_DWS(K_, G_, 3); else MNAS_DWS(K_, G_, 5); } while (0)
+    if (c->k == 3) { if (g == 4) MNAS_DWS_T(3, 4); else MNAS_DWS_T(3, 2); }
+    else { if (g == 4) MNAS_DWS_T(5, 4); else MNAS_DWS_T(5, 2); }
+#undef MNAS_DWS_T
 #undef MNAS_DWS
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;

@@ -182,6 +182,83 @@ def test_bucket_schedule_order_world2_gloo():
         assert all(oks), (rank, oks)
 
 
+# ---- config 5's straggler case: every rank runs a DIFFERENT input shape (mixed-across-ranks clusters) ------------------------
+def _mixed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        import time
+        from mnasnet_pytorch_amd.train_step import BucketSchedule
+        ccf = False
+        shapes = [(2, 3, 32, 48), (2, 3, 48, 32)]          # rank 0 / rank 1: different "programs" (datasets.py:331-335 clusters)
+        st = O.init_state(ccf, C.STATE_SEED, proj_gamma=0.1)
+        # unique trainable tensors grouped by features.<stage>, flat layout = later stages first (engine.stage_ranges)
+        seen, by_stage = set(), {}
+        for k, v in st.items():
+            if v.dtype.is_floating_point and "running" not in k and id(v) not in seen:
+                seen.add(id(v)); v.requires_grad_(True)
+                by_stage.setdefault(int(k.split(".")[1]), []).append(v)
+        ranges, off = {}, 0
+        for stg in sorted(by_stage, reverse=True):
+            n_ = sum(p.numel() for p in by_stage[stg])
+            ranges[stg] = [off, off + n_]
+            off += n_
+        n_head = 7
+        flat = torch.zeros(n_head + off)
+        sched = BucketSchedule(flat, n_head, ranges, early_bucket_stage=5)
+        oks = []
+        for step in range(2):
+            x = C.det_input(shapes[(rank + step) % 2], seed=3 + step)      # the shapes swap between steps
+            for ps in by_stage.values():
+                for p in ps:
+                    p.grad = None
+            y = O.features_forward(x, st, ccf, True)
+            (y * C.cotangent(tuple(y.shape), seed=60 + rank)).sum().backward()
+            local = {stg: torch.cat([p.grad.reshape(-1) for p in ps]) for stg, ps in by_stage.items()}
+            flat.zero_()
+            sched.begin_step()
+            flat[:n_head] = 1.0 + rank
+            for stg in sorted(ranges, reverse=True):       # backward order; the "slow" rank of this step lags behind
+                if (rank + step) % 2 == 1:
+                    time.sleep(0.02)
+                a, b = ranges[stg]
+                flat[n_head + a:n_head + b] = local[stg]
+                sched.on_stage_done(stg)
+            sched.finish()
+            # expected: reduce-add over ranks of what every rank computed on ITS shape
+            mine = torch.cat([torch.full((n_head,), 1.0 + rank)] + [local[stg] for stg in sorted(ranges, reverse=True)])
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            oks.append(bool(torch.allclose(flat, sum(gathered), rtol=1e-5, atol=1e-6)))
+            oks.append([e for e in sched.log if e[0] == "launch"] == [("launch", 0), ("launch", 1)])
+            oks.append(sched.log.index(("launch", 0)) == sched.log.index(("stage", 5)) + 1)
+        q.put((rank, oks))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mixed_shape_ranks_world2_gloo():
+    """BASELINE configs[4] across ranks (SURVEY 8(e) caveat): the ranks of one step hold DIFFERENT resolution clusters, i.e. run
+    different launch lists and reach their stage-done callbacks at different times.  The gradient layout does not depend on the
+    input shape, so the two buckets must still be all-reduced in the same order with the same bounds on every rank and the
+    result must be the reduce-add of the per-rank gradients -- whichever rank is the straggler (they swap between the steps)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, oks in res:
+        assert all(oks), (rank, oks)
+
+
 def test_bench_multi_gpu_spawn_is_a_child_process():
     """bench.py --gpus N (plain python) must start torch.distributed.run as a CHILD before anything touches the GPU and never
     exec: checked on the source (the GPU box refuses an exec from a process that initialised HIP)."""

@@ -124,18 +124,19 @@ def test_baseline_config_step_bs256():
     assert bool(torch.isfinite(p4).all())
 
 
-def test_training_trajectory_matches_cpu_oracle():
-    """What "matches the reference" means for bf16 TRAINING (train.py:423-440): 30 Adam steps (lr 1e-3) at bs 32, 64x64,
-    10 classes, dropout off, cycling over 4 fixed batches, HIP Trainer vs the fp32 CPU oracle (oracle.train_step) from the same
-    state on identical data.  Stated band: at every step |loss_hip - loss_ref| <= max(6 % of loss_ref, 0.03) (bf16 activations,
-    fp32 master weights / statistics / optimizer; the absolute floor covers the end of the run, where the 128 images are
-    memorised and the loss is ~0.01), the mean gap over the steps with loss_ref > 0.1 is <= 3 %, and both runs learn (last-5
-    mean < 0.2 x first-5 mean).  Measured on MI355X: see the printed curve."""
+@pytest.mark.parametrize("nb,bs,size,steps", [(4, 32, 64, 30), (2, 64, 224, 8)], ids=["bs32_64px_30steps", "bs64_224px_8steps"])
+def test_training_trajectory_matches_cpu_oracle(nb, bs, size, steps):
+    """What "matches the reference" means for bf16 TRAINING (train.py:423-440): Adam steps (lr 1e-3), 10 classes, dropout off,
+    cycling over `nb` fixed batches, HIP Trainer vs the fp32 CPU oracle (oracle.train_step) from the same state on identical data
+    -- 30 steps at bs 32, 64x64, and (round 4) 8 steps at the bench resolution, bs 64 x 224 x 224.  Stated band: at every step
+    |loss_hip - loss_ref| <= max(6 % of loss_ref, 0.03) (bf16 activations, fp32 master weights / statistics / optimizer; the
+    absolute floor covers the end of the long run, where the 128 images are memorised and the loss is ~0.01), the mean gap over
+    the steps with loss_ref > 0.1 is <= 3 %, and both runs learn (long run: last-5 mean < 0.2 x first-5 mean; short run: the last
+    loss is below the first).  Measured on MI355X: see the printed curve."""
     from mnasnet_pytorch_amd.train_step import Trainer
     torch.manual_seed(0)
-    nb, bs, steps = 4, 32, 30
     gen = torch.Generator().manual_seed(123)
-    xs = [torch.randn(bs, 3, 64, 64, generator=gen) for _ in range(nb)]
+    xs = [torch.randn(bs, 3, size, size, generator=gen) for _ in range(nb)]
     ts = [torch.randint(0, 10, (bs,), generator=gen) for _ in range(nb)]
     # oracle (fp32, CPU): same initial state, same optimizer hyper-parameters
     net = O.OracleNet(ccf=False, head="512", num_classes=10, seed=C.STATE_SEED).train()
@@ -165,7 +166,10 @@ def test_training_trajectory_matches_cpu_oracle():
     assert np.isfinite(hip).all()
     assert (np.abs(hip - ref) <= np.maximum(6e-2 * np.abs(ref), 0.03)).all(), (hip, ref)
     assert gap[big].mean() <= 3e-2, gap[big].mean()
-    assert hip[-5:].mean() < 0.2 * hip[:5].mean() and ref[-5:].mean() < 0.2 * ref[:5].mean()
+    if steps >= 20:
+        assert hip[-5:].mean() < 0.2 * hip[:5].mean() and ref[-5:].mean() < 0.2 * ref[:5].mean()
+    else:
+        assert hip[-1] < hip[0] and ref[-1] < ref[0]
 
 
 def test_native_step_validates_inputs():
