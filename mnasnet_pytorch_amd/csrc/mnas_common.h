@@ -44,24 +44,57 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// Channel-pair math in explicit float2: v_pk_fma_f32 does two FMAs per issue slot.  The build runs with -fno-slp-vectorize (the
+// SLP pass packs arbitrary neighbours and pays for it in register shuffles), so packing has to be written out where it pays:
+// the staging transforms below run once per 16 bytes in every GEMM-class kernel (round 3 SQ counters: 20-25 % of their wave
+// cycles are vector-ALU instructions, most of them these transforms and the fused reduces).  Same IEEE operations as the scalar
+// form -> bit-identical results.
+typedef float mnas_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mnas_f2 mnas_f2fma(mnas_f2 a, mnas_f2 b, mnas_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ mnas_f2 mnas_bf2(uint32_t u) { mnas_f2 r; r.x = bf_lo(u); r.y = bf_hi(u); return r; }
+__device__ __forceinline__ mnas_f2 mnas_ld2(const float* p) { mnas_f2 r; r.x = p[0]; r.y = p[1]; return r; }
+
+// BatchNorm partial statistics of one channel pair: s1 += v, s2 += v*v
+__device__ __forceinline__ void mnas_stat2(mnas_f2 v, float* s1, float* s2) {
+    const mnas_f2 a = mnas_ld2(s1) + v, b = mnas_f2fma(v, v, mnas_ld2(s2));
+    s1[0] = a.x; s1[1] = a.y; s2[0] = b.x; s2[1] = b.y;
+}
+// fused BatchNorm-backward reduce of one channel pair: dz = g*[s*y+t>0] (g, y: packed bf16 pairs as stored), r1 += dz,
+// r2 += dz*(y*inv + m)   (inv = invstd, m = -mean*invstd)
+__device__ __forceinline__ void mnas_red2(uint32_t gu, uint32_t yu, mnas_f2 s, mnas_f2 t, mnas_f2 inv, mnas_f2 m, float* r1, float* r2) {
+    const mnas_f2 g = mnas_bf2(gu), y = mnas_bf2(yu);
+    const mnas_f2 z = mnas_f2fma(y, s, t);
+    mnas_f2 dz;
+    dz.x = (z.x > 0.f) ? g.x : 0.f;
+    dz.y = (z.y > 0.f) ? g.y : 0.f;
+    const mnas_f2 a = mnas_ld2(r1) + dz, b = mnas_f2fma(dz, mnas_f2fma(y, inv, m), mnas_ld2(r2));
+    r1[0] = a.x; r1[1] = a.y; r2[0] = b.x; r2[1] = b.y;
+}
+
 // act-on-load for one channel group: relu(s*x+t)
 __device__ __forceinline__ uint4 act8(const uint4& raw, const float* s, const float* t) {
-    float f[8];
-    unpack8(raw, f);
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t o[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], s[j], t[j]), 0.f);
-    return pack8(f);
+    for (int j = 0; j < 4; ++j) {
+        const mnas_f2 z = mnas_f2fma(mnas_bf2(u[j]), mnas_ld2(s + 2 * j), mnas_ld2(t + 2 * j));
+        o[j] = pack_bf16(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
 }
 // dy-on-load for one channel group: c1*(g*[s*y+t>0]) + c2*y + c3 ; coef rows are s,t,c1,c2,c3
 __device__ __forceinline__ void dy8(const uint4& graw, const uint4& yraw, const float* s, const float* t,
                                     const float* c1, const float* c2, const float* c3, float* out) {
-    float g[8], y[8];
-    unpack8(graw, g);
-    unpack8(yraw, y);
+    const uint32_t gu[4] = {graw.x, graw.y, graw.z, graw.w}, yu[4] = {yraw.x, yraw.y, yraw.z, yraw.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float dz = (fmaf(y[j], s[j], t[j]) > 0.f) ? g[j] : 0.f;
-        out[j] = fmaf(c1[j], dz, fmaf(c2[j], y[j], c3[j]));
+    for (int j = 0; j < 4; ++j) {
+        const mnas_f2 g = mnas_bf2(gu[j]), y = mnas_bf2(yu[j]);
+        const mnas_f2 z = mnas_f2fma(y, mnas_ld2(s + 2 * j), mnas_ld2(t + 2 * j));
+        mnas_f2 dz;
+        dz.x = (z.x > 0.f) ? g.x : 0.f;
+        dz.y = (z.y > 0.f) ? g.y : 0.f;
+        const mnas_f2 d = mnas_f2fma(mnas_ld2(c1 + 2 * j), dz, mnas_f2fma(mnas_ld2(c2 + 2 * j), y, mnas_ld2(c3 + 2 * j)));
+        out[2 * j] = d.x; out[2 * j + 1] = d.y;
     }
 }
 

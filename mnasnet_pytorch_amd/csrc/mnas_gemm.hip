@@ -413,9 +413,9 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                     const uint2 rv = *(const uint2*)((const uint16_t*)a.resid + o);
                     v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
                 }
-                if (MODE != 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { s1[nt][r] += v[r]; s2[nt][r] = fmaf(v[r], v[r], s2[nt][r]); }
+                if (MODE != 1) {                             // channel pairs in float2 (v_pk_fma_f32)
+                    mnas_stat2((mnas_f2){v[0], v[1]}, &s1[nt][0], &s2[nt][0]);
+                    mnas_stat2((mnas_f2){v[2], v[3]}, &s1[nt][2], &s2[nt][2]);
                 }
                 uint2 pk;
                 pk.x = pack_bf16(v[0], v[1]);
@@ -425,19 +425,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
                     // fused BN-backward reduce for the layer whose activated output this gradient belongs to:
                     // dz = g*[s*y+t>0] (g as stored, i.e. bf16-rounded), xhat = y*invstd - mean*invstd
                     const uint2 yv = ypre[pt][nt];
-                    const float gq[4] = {bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y)};
-                    const float yq[4] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y)};
                     const int cl = nt * 16 + lg * 4;
                     const float4 cs = *(const float4*)(lds_redc + cl), ct = *(const float4*)(lds_redc + NT * 16 + cl);
                     const float4 ci = *(const float4*)(lds_redc + 2 * NT * 16 + cl), cm = *(const float4*)(lds_redc + 3 * NT * 16 + cl);
-                    const float rs_[4] = {cs.x, cs.y, cs.z, cs.w}, rt_[4] = {ct.x, ct.y, ct.z, ct.w};
-                    const float ri_[4] = {ci.x, ci.y, ci.z, ci.w}, rm_[4] = {cm.x, cm.y, cm.z, cm.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dz = (fmaf(yq[r], rs_[r], rt_[r]) > 0.f) ? gq[r] : 0.f;
-                        s1[nt][r] += dz;
-                        s2[nt][r] = fmaf(dz, fmaf(yq[r], ri_[r], rm_[r]), s2[nt][r]);
-                    }
+                    mnas_red2(pk.x, yv.x, (mnas_f2){cs.x, cs.y}, (mnas_f2){ct.x, ct.y}, (mnas_f2){ci.x, ci.y}, (mnas_f2){cm.x, cm.y},
+                              &s1[nt][0], &s2[nt][0]);
+                    mnas_red2(pk.y, yv.y, (mnas_f2){cs.z, cs.w}, (mnas_f2){ct.z, ct.w}, (mnas_f2){ci.z, ci.w}, (mnas_f2){cm.z, cm.w},
+                              &s1[nt][2], &s2[nt][2]);
                 }
             }
         }

@@ -273,25 +273,24 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                     yp.x = pack_bf16(acc[0] + bb.x, acc[1] + bb.y);
                     yp.y = pack_bf16(acc[2] + bb.z, acc[3] + bb.w);
                     const uint2 gp = *(const uint2*)(tile_d + p * ldd + co);
-                    const float yq[4] = {bf_lo(yp.x), bf_hi(yp.x), bf_lo(yp.y), bf_hi(yp.y)};
-                    const float gq[4] = {bf_lo(gp.x), bf_hi(gp.x), bf_lo(gp.y), bf_hi(gp.y)};
                     const float4 cs = *(const float4*)(lds_cd + co), ct = *(const float4*)(lds_cd + COP + co);
                     const float4 c1 = *(const float4*)(lds_cd + 2 * COP + co), c2 = *(const float4*)(lds_cd + 3 * COP + co);
                     const float4 c3 = *(const float4*)(lds_cd + 4 * COP + co);
-                    const float s_[4] = {cs.x, cs.y, cs.z, cs.w}, t_[4] = {ct.x, ct.y, ct.z, ct.w};
-                    const float c1_[4] = {c1.x, c1.y, c1.z, c1.w}, c2_[4] = {c2.x, c2.y, c2.z, c2.w}, c3_[4] = {c3.x, c3.y, c3.z, c3.w};
-                    float d[4];
+                    const uint32_t yu[2] = {yp.x, yp.y}, gu[2] = {gp.x, gp.y};
+                    const mnas_f2 s2[2] = {{cs.x, cs.y}, {cs.z, cs.w}}, t2[2] = {{ct.x, ct.y}, {ct.z, ct.w}};
+                    const mnas_f2 a2[2] = {{c1.x, c1.y}, {c1.z, c1.w}}, b2[2] = {{c2.x, c2.y}, {c2.z, c2.w}}, e2[2] = {{c3.x, c3.y}, {c3.z, c3.w}};
+                    uint32_t dp[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dz = (fmaf(yq[r], s_[r], t_[r]) > 0.f) ? gq[r] : 0.f;
-                        d[r] = fmaf(c1_[r], dz, fmaf(c2_[r], yq[r], c3_[r]));
+                    for (int h = 0; h < 2; ++h) {            // channel pairs in float2 (v_pk_fma_f32)
+                        const mnas_f2 yq = mnas_bf2(yu[h]), gq = mnas_bf2(gu[h]);
+                        const mnas_f2 z = mnas_f2fma(yq, s2[h], t2[h]);
+                        mnas_f2 dz;
+                        dz.x = (z.x > 0.f) ? gq.x : 0.f;
+                        dz.y = (z.y > 0.f) ? gq.y : 0.f;
+                        const mnas_f2 d = mnas_f2fma(a2[h], dz, mnas_f2fma(b2[h], yq, e2[h]));
+                        dp[h] = pack_bf16(d.x, d.y);
                     }
-                    if (pok) {
-                        uint2 dp;
-                        dp.x = pack_bf16(d[0], d[1]);
-                        dp.y = pack_bf16(d[2], d[3]);
-                        *(uint2*)(tile_d + p * ldd + co) = dp;
-                    }
+                    if (pok) *(uint2*)(tile_d + p * ldd + co) = make_uint2(dp[0], dp[1]);
                 }
             }
             __syncthreads();
@@ -388,15 +387,19 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 if (!(ocol_ok && p < BP && tile0 + p < a.M)) continue;
                 const uint4 pk = *(const uint4*)(tile_a + p * lda + oc8 * 8);
                 if constexpr (FORM != 1) st_u4((uint16_t*)a.gin + ((size_t)(tile0 + p) * a.Ci + ci0 + oc8 * 8), pk, true);
-                if (do_red) {
-                    float gq[8], yq[8];
-                    unpack8(pk, gq);
-                    unpack8(vx[k], yq);
+                if (do_red) {                                // channel pairs in float2 (v_pk_fma_f32); same operations as the scalar form
+                    const uint32_t gu[4] = {pk.x, pk.y, pk.z, pk.w}, yu[4] = {vx[k].x, vx[k].y, vx[k].z, vx[k].w};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float dz = (fmaf(yq[j], rcs[j], rct[j]) > 0.f) ? gq[j] : 0.f;
-                        r1[j] += dz;
-                        r2[j] = fmaf(dz, fmaf(yq[j], rci[j], rcm[j]), r2[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const mnas_f2 gq = mnas_bf2(gu[j]), yq = mnas_bf2(yu[j]);
+                        const mnas_f2 z = mnas_f2fma(yq, mnas_ld2(rcs + 2 * j), mnas_ld2(rct + 2 * j));
+                        mnas_f2 dz;
+                        dz.x = (z.x > 0.f) ? gq.x : 0.f;
+                        dz.y = (z.y > 0.f) ? gq.y : 0.f;
+                        const mnas_f2 xh = mnas_f2fma(yq, mnas_ld2(rci + 2 * j), mnas_ld2(rcm + 2 * j));
+                        const mnas_f2 a1 = mnas_ld2(r1 + 2 * j) + dz, a2 = mnas_f2fma(dz, xh, mnas_ld2(r2 + 2 * j));
+                        r1[2 * j] = a1.x; r1[2 * j + 1] = a1.y;
+                        r2[2 * j] = a2.x; r2[2 * j + 1] = a2.y;
                     }
                 }
             }
@@ -426,17 +429,21 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                     if (do_red) {
                         // dz = g*[s*y+t>0] with g as stored (bf16), y = raw output of the reduce target; xhat = y*invstd - mean*invstd
                         const uint2 yv = ypre[pt][nt];
-                        const float gq[4] = {bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y)};
-                        const float yq[4] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y)};
                         const float4 cs = *(const float4*)(lds_rc + ci), ct = *(const float4*)(lds_rc + CIP + ci);
                         const float4 cI = *(const float4*)(lds_rc + 2 * CIP + ci), cm = *(const float4*)(lds_rc + 3 * CIP + ci);
-                        const float rs_[4] = {cs.x, cs.y, cs.z, cs.w}, rt_[4] = {ct.x, ct.y, ct.z, ct.w};
-                        const float ri_[4] = {cI.x, cI.y, cI.z, cI.w}, rm_[4] = {cm.x, cm.y, cm.z, cm.w};
+                        const uint32_t gu[2] = {pk.x, pk.y}, yu[2] = {yv.x, yv.y};
+                        const mnas_f2 s2[2] = {{cs.x, cs.y}, {cs.z, cs.w}}, t2[2] = {{ct.x, ct.y}, {ct.z, ct.w}};
+                        const mnas_f2 i2[2] = {{cI.x, cI.y}, {cI.z, cI.w}}, m2[2] = {{cm.x, cm.y}, {cm.z, cm.w}};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float dz = (fmaf(yq[r], rs_[r], rt_[r]) > 0.f) ? gq[r] : 0.f;
-                            d1[r] = dz;
-                            d2[r] = dz * fmaf(yq[r], ri_[r], rm_[r]);
+                        for (int h = 0; h < 2; ++h) {        // channel pairs in float2 (v_pk_fma_f32)
+                            const mnas_f2 gq = mnas_bf2(gu[h]), yq = mnas_bf2(yu[h]);
+                            const mnas_f2 z = mnas_f2fma(yq, s2[h], t2[h]);
+                            mnas_f2 dz;
+                            dz.x = (z.x > 0.f) ? gq.x : 0.f;
+                            dz.y = (z.y > 0.f) ? gq.y : 0.f;
+                            const mnas_f2 pr = dz * mnas_f2fma(yq, i2[h], m2[h]);
+                            d1[2 * h] = dz.x; d1[2 * h + 1] = dz.y;
+                            d2[2 * h] = pr.x; d2[2 * h + 1] = pr.y;
                         }
                     }
                 }

@@ -225,15 +225,12 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
             const uint4 pk = o[p * OPITCH + oc8];
             if (!PWF_ABL(a, 1)) st_u4((uint16_t*)a.out + ooff[k], pk, a.nt_store);
             if (do_red) {
-                float gq[8], yq[8];
-                unpack8(pk, gq);
-                unpack8(yreg[k], yq);
+                const uint32_t gu[4] = {pk.x, pk.y, pk.z, pk.w}, yu[4] = {yreg[k].x, yreg[k].y, yreg[k].z, yreg[k].w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = oc8 * 8 + j;
-                    const float dz = (fmaf(yq[j], lds_redc[c], lds_redc[NB + c]) > 0.f) ? gq[j] : 0.f;
-                    r1[j] += dz;
-                    r2[j] = fmaf(dz, fmaf(yq[j], lds_redc[2 * NB + c], lds_redc[3 * NB + c]), r2[j]);
+                for (int j = 0; j < 4; ++j) {                // channel pairs in float2 (v_pk_fma_f32)
+                    const int c = oc8 * 8 + 2 * j;
+                    mnas_red2(gu[j], yu[j], mnas_ld2(lds_redc + c), mnas_ld2(lds_redc + NB + c), mnas_ld2(lds_redc + 2 * NB + c),
+                              mnas_ld2(lds_redc + 3 * NB + c), r1 + 2 * j, r2 + 2 * j);
                 }
             }
         }
@@ -315,9 +312,9 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = MODE == 1 ? acc[pt][nt][r] : acc[pt][nt][r] + bias_r[nt][r];
-                if (MODE == 0 && mok) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { s1[nt][r] += v[r]; s2[nt][r] = fmaf(v[r], v[r], s2[nt][r]); }
+                if (MODE == 0 && mok) {                      // channel pairs in float2 (v_pk_fma_f32)
+                    mnas_stat2((mnas_f2){v[0], v[1]}, &s1[nt][0], &s2[nt][0]);
+                    mnas_stat2((mnas_f2){v[2], v[3]}, &s1[nt][2], &s2[nt][2]);
                 }
                 uint2 pk;
                 pk.x = pack_bf16(v[0], v[1]);

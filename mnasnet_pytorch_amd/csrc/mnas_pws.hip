@@ -176,7 +176,11 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
             const size_t o = (size_t)(m0 + ep) * a.N + n0 + ec8 * 8;
             if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { v[j] += bias8[j]; s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                for (int j = 0; j < 4; ++j) {                // channel pairs in float2 (v_pk_fma_f32)
+                    const mnas_f2 w2 = mnas_ld2(v + 2 * j) + mnas_ld2(bias8 + 2 * j);
+                    v[2 * j] = w2.x; v[2 * j + 1] = w2.y;
+                    mnas_stat2(w2, s1 + 2 * j, s2 + 2 * j);
+                }
                 *(uint4*)((uint16_t*)a.out + o) = pack8(v);
             } else {
                 if (a.resid) {
@@ -189,16 +193,12 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
                 *(uint4*)((uint16_t*)a.out + o) = pk;
                 if (do_red) {
                     // dz = g*[s*y+t>0] with g as stored (bf16), xhat = y*invstd - mean*invstd   (as k_igemm's fused reduce)
-                    float gq[8], yq[8];
-                    unpack8(pk, gq);
-                    unpack8(ypre, yq);
+                    const uint32_t gu[4] = {pk.x, pk.y, pk.z, pk.w}, yu[4] = {ypre.x, ypre.y, ypre.z, ypre.w};
                     const int cl = ec8 * 8;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float dz = (fmaf(yq[j], lds_redc[cl + j], lds_redc[NB + cl + j]) > 0.f) ? gq[j] : 0.f;
-                        s1[j] += dz;
-                        s2[j] = fmaf(dz, fmaf(yq[j], lds_redc[2 * NB + cl + j], lds_redc[3 * NB + cl + j]), s2[j]);
-                    }
+                    for (int j = 0; j < 4; ++j)              // channel pairs in float2 (v_pk_fma_f32)
+                        mnas_red2(gu[j], yu[j], mnas_ld2(lds_redc + cl + 2 * j), mnas_ld2(lds_redc + NB + cl + 2 * j),
+                                  mnas_ld2(lds_redc + 2 * NB + cl + 2 * j), mnas_ld2(lds_redc + 3 * NB + cl + 2 * j), s1 + 2 * j, s2 + 2 * j);
                 }
             }
         }
