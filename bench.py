@@ -393,6 +393,8 @@ OVERRIDES = [
     ("MNAS_IRB_WGS", "workgroups per fused-block launch", lambda e: setattr(e, "irb_workgroups", _ov_int("MNAS_IRB_WGS"))),
     ("MNAS_WGRAD_WGS", "workgroups per k_wgrad launch", lambda e: setattr(e, "wgrad_wgs", _ov_int("MNAS_WGRAD_WGS"))),
     ("MNAS_NO_RECOMP", "expand convs' fused backward reads the stored y1 instead of recomputing it", lambda e: setattr(e, "pw_recompute_y", False)),
+    ("MNAS_NO_MASKED_G", "project convs store the unmasked input gradient, the depthwise backward derives the ReLU mask per window column",
+     lambda e: setattr(e, "dw_masked_g", False)),
     ("MNAS_FUSE", "fused expand + depthwise forward kernels that also store y1 (measured slower)",
      lambda e: setattr(e, "fuse_expand", True)),
     ("MNAS_DW5_SPLIT", "two-launch backward for the 5x5 depthwise layers", lambda e: setattr(e, "dw_fused_k", (3,))),

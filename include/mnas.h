@@ -176,10 +176,14 @@ typedef struct MnasPwBwd {
     void*  dy_out;
     const void*  w_fwd;
     const float* b_fwd;
+    /* round 4: store gin MASKED, dz = gin*[s*x+t>0] under red_bn (the mask its fused reduce computes anyway), for a consumer
+     * that would otherwise re-derive it per element and window column (mnas_dw_bwd g_masked).  Out-stage forms with the fused
+     * reduce only (mnas_pw_bwd_forms bit 2); MNAS_EINVAL otherwise. */
+    int32_t gin_masked, reserved;
 } MnasPwBwd;
 int mnas_pw_bwd(const MnasPwBwd* a, void* stream);
 int mnas_pw_bwd_supported(int Ci, int Co);
-int mnas_pw_bwd_forms(int Ci, int Co);      /* bit 0: NOGIN available for this channel pair, bit 1: RECOMP available */
+int mnas_pw_bwd_forms(int Ci, int Co);      /* bit 0: NOGIN available for this channel pair, bit 1: RECOMP, bit 2: gin_masked */
 
 /* ---- depthwise kxk (k in {3,5}, stride 1, pad k/2), LDS-tiled direct conv on the vector ALU ----------
  * Replaces ATen conv2d fwd/bwd for ConvBlock's groups==C convs (mnasnet.py:122-125, 76-81). */
@@ -330,6 +334,9 @@ typedef struct MnasDwBwd {
     const float* src_b1;
     const void*  src_dy;
     const void*  src_w3t;
+    /* round 4: dy.g already holds dz = g*[s*y+t>0] (written by mnas_pw_bwd with gin_masked): dy-on-read skips the mask.
+     * Phase 0 with the fused reduce only; results are bit-identical to the plain form on the unmasked g. */
+    int32_t g_masked, reserved;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
 int mnas_dw_src_rows(int N, int H, int W, int C, int k, int cin, int nparts);

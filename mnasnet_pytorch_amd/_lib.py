@@ -47,7 +47,7 @@ class MnasDwBwd(C.Structure):
                 ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
                 ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p), ("phase", C.c_int32),
                 ("src_cin", C.c_int32), ("src_x", MnasActIn), ("src_w1", c_void_p), ("src_b1", c_void_p), ("src_dy", c_void_p),
-                ("src_w3t", c_void_p)]
+                ("src_w3t", c_void_p), ("g_masked", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasDwExpFwd(C.Structure):
@@ -61,7 +61,7 @@ class MnasPwBwd(C.Structure):
     _fields_ = [("M", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32), ("nparts", C.c_int32), ("x", MnasActIn),
                 ("dy", MnasGradIn), ("w", c_void_p), ("resid", c_void_p), ("gin", c_void_p), ("wpartial", c_void_p),
                 ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p), ("dy_out", c_void_p), ("w_fwd", c_void_p),
-                ("b_fwd", c_void_p)]
+                ("b_fwd", c_void_p), ("gin_masked", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasPostWgrad(C.Structure):

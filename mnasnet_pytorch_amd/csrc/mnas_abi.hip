@@ -122,6 +122,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.w = p[6]; a.resid = p[7]; a.gin = p[8]; a.wpartial = (float*)p[9];
             a.red_partial = (float*)p[10]; a.red_y = p[11]; a.red_bn = (const float*)p[12];
             a.dy_out = p[13]; a.w_fwd = p[14]; a.b_fwd = (const float*)p[15];
+            a.gin_masked = i[4];
             return mnas_pw_bwd(&a, stream);
         }
         case MNAS_OP_GRAM: {
@@ -156,6 +157,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = (const float*)p[6]; a.gin = p[7]; a.wpartial = (float*)p[8];
             a.red_bn = (const float*)p[9]; a.red_partial = (float*)p[10]; a.phase = i[6];
+            a.g_masked = i[8];
             a.src_cin = i[7];      // SRC form (i[7] > 0): x.data / dy.g do not exist -- their slots carry the weight blocks
             if (a.src_cin > 0) {
                 a.src_w1 = p[0]; a.src_w3t = p[3]; a.x.data = nullptr; a.dy.g = nullptr;

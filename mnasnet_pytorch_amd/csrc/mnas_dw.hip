@@ -229,16 +229,21 @@ __device__ __forceinline__ void dw_fill_edges(const DwArgs& a, const DwDma& p, u
 }
 
 // window row of dy = c1*(g*[s*y+t>0]) + c2*y + c3, zero outside the image columns.  cf = {s,t,c1,c2,c3}
-template <int WIN_W>
+// GM ("g is masked", round 4): the producer of g -- mnas_pw_bwd's out-stage forms with gin_masked, which compute the mask for
+// their fused reduce anyway -- stored dz = g*[s*y+t>0] instead of g: the window read drops the mask (one packed FMA, two
+// compares, two selects per channel pair and column: 40 of the 5x5 row body's ~530 vector instructions)
+template <int WIN_W, bool GM = false>
 __device__ __forceinline__ void dw_read_dy(const uint32_t* growp, const uint32_t* yrowp, int ps, const f2 (&cf)[5],
                                            unsigned colmask, f2 (&xr)[WIN_W]) {
 #pragma unroll
     for (int xx = 0; xx < WIN_W; ++xx) {
         const f2 g = f2bf(growp[xx * ps]), y = f2bf(yrowp[xx * ps]);
-        const f2 z = f2fma(y, cf[0], cf[1]);
-        f2 dz;
-        dz.x = (z.x > 0.f) ? g.x : 0.f;
-        dz.y = (z.y > 0.f) ? g.y : 0.f;
+        f2 dz = g;
+        if constexpr (!GM) {
+            const f2 z = f2fma(y, cf[0], cf[1]);
+            dz.x = (z.x > 0.f) ? g.x : 0.f;
+            dz.y = (z.y > 0.f) ? g.y : 0.f;
+        }
         const f2 d = f2fma(cf[2], dz, f2fma(cf[3], y, cf[4]));
         const bool in = (colmask >> xx) & 1u;
         xr[xx].x = in ? d.x : 0.f;
@@ -624,7 +629,7 @@ struct DwSrc {
     int Cin, Kpad;
 };
 
-template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false, int NTB = 1>
+template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false, int NTB = 1, bool GM = false>
 __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
     float* __restrict__ red_partial, const float* __restrict__ red_bn, DwSrc e) {
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 f2 xr[WIN_W];
                 if (row_in) {
                     const size_t ro = (size_t)dw_slot<2 * G>(iy) * a.rc * 4 + coloff;
-                    dw_read_dy<WIN_W>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
+                    dw_read_dy<WIN_W, GM>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
                 } else {
 #pragma unroll
                     for (int xx = 0; xx < WIN_W; ++xx) xr[xx] = zero2;
@@ -1147,6 +1152,16 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
 #define MNAS_DWB(K_, DG_, WG_, R_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
                                                          c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{})
 #define MNAS_DWB_G(K_, DG_, WG_, R_) do { if (g == 4) MNAS_DWB(K_, DG_, WG_, R_, 4); else MNAS_DWB(K_, DG_, WG_, R_, 2); } while (0)
+    if (c->g_masked) {                       // fused sweep only (what the engine runs behind a project conv's masked gradient)
+        if (!(want_dg && want_wg && red)) return MNAS_EINVAL;
+#define MNAS_DWM(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, false, 1, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
+                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{})
+        if (c->k == 3) { if (g == 4) MNAS_DWM(3, 4); else MNAS_DWM(3, 2); }
+        else { if (g == 4) MNAS_DWM(5, 4); else MNAS_DWM(5, 2); }
+#undef MNAS_DWM
+        MNAS_CHECK_LAUNCH();
+        return MNAS_OK;
+    }
     if (c->k == 3) {
         if (want_dg && want_wg) { if (red) MNAS_DWB_G(3, true, true, true); else MNAS_DWB_G(3, true, true, false); }
         else if (want_dg) { if (red) MNAS_DWB_G(3, true, false, true); else MNAS_DWB_G(3, true, false, false); }

@@ -46,6 +46,7 @@ struct PwBwdArgs {
     const uint16_t* w_fwd;   // FORM 2: MNAS_PACK_FWD [round16(Co)][Kf]
     const float* b_fwd;      // FORM 2: [Co] or NULL
     int Kf;                  // FORM 2: Ci rounded up to 32
+    int gin_masked;          // out-stage forms: store dz = gin*[s*x+t>0] (the fused reduce's mask) instead of gin
 };
 
 __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
@@ -386,9 +387,11 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 const int p = orow0 + k * OROWS;
                 if (!(ocol_ok && p < BP && tile0 + p < a.M)) continue;
                 const uint4 pk = *(const uint4*)(tile_a + p * lda + oc8 * 8);
-                if constexpr (FORM != 1) st_u4((uint16_t*)a.gin + ((size_t)(tile0 + p) * a.Ci + ci0 + oc8 * 8), pk, true);
+                uint16_t* gdst = (uint16_t*)a.gin + ((size_t)(tile0 + p) * a.Ci + ci0 + oc8 * 8);
+                if (FORM != 1 && !a.gin_masked) st_u4(gdst, pk, true);
                 if (do_red) {                                // channel pairs in float2 (v_pk_fma_f32); same operations as the scalar form
                     const uint32_t gu[4] = {pk.x, pk.y, pk.z, pk.w}, yu[4] = {vx[k].x, vx[k].y, vx[k].z, vx[k].w};
+                    uint32_t mz[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const mnas_f2 gq = mnas_bf2(gu[j]), yq = mnas_bf2(yu[j]);
@@ -396,11 +399,13 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                         mnas_f2 dz;
                         dz.x = (z.x > 0.f) ? gq.x : 0.f;
                         dz.y = (z.y > 0.f) ? gq.y : 0.f;
+                        mz[j] = (__float_as_uint(dz.x) >> 16) | (__float_as_uint(dz.y) & 0xffff0000u);   // dz is g or 0: exact in bf16
                         const mnas_f2 xh = mnas_f2fma(yq, mnas_ld2(rci + 2 * j), mnas_ld2(rcm + 2 * j));
                         const mnas_f2 a1 = mnas_ld2(r1 + 2 * j) + dz, a2 = mnas_f2fma(dz, xh, mnas_ld2(r2 + 2 * j));
                         r1[2 * j] = a1.x; r1[2 * j + 1] = a1.y;
                         r2[2 * j] = a2.x; r2[2 * j + 1] = a2.y;
                     }
+                    if (FORM != 1 && a.gin_masked) st_u4(gdst, make_uint4(mz[0], mz[1], mz[2], mz[3]), true);
                 }
             }
             continue;
@@ -596,6 +601,7 @@ extern "C" int mnas_pw_bwd_forms(int Ci, int Co) {
     int f = 0;
     if (c->nti_slice > c->nto && c->nti_slice >= 3 && c->nto <= 3) f |= 1;
     if (c->nto > c->nti_slice && c->nti_slice <= 2 && c->nslices == 1) f |= 2;
+    if ((c->nti_slice > c->nto && c->nti_slice >= 3) || (c->nti_slice == c->nto && c->nti_slice >= 5)) f |= 4;     // out-stage form
     return f;
 }
 
@@ -611,6 +617,8 @@ extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     a.wpartial = c->wpartial; a.red_partial = c->red_partial; a.red_y = c->red_y; a.red_bn = c->red_bn;
     a.nt = (mnas_nt_mask() & MNAS_NT_PW_BWD) ? 1 : 0;
     a.dy_out = c->dy_out; a.w_fwd = (const uint16_t*)c->w_fwd; a.b_fwd = c->b_fwd; a.Kf = (c->Ci + 31) / 32 * 32;
+    a.gin_masked = c->gin_masked;
+    if (a.gin_masked && (!c->red_partial || c->resid || c->red_y != c->x.data || !(mnas_pw_bwd_forms(c->Ci, c->Co) & 4))) return MNAS_EINVAL;
     const PwCfg* cfg = pw_cfg(c->Ci, c->Co);
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_PWB(O_, I_, P_) if (cfg->nto == O_ && cfg->nti_slice == I_ && cfg->pt == P_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s, cfg->nslices);

@@ -324,6 +324,7 @@ class Program:
 
 
 
+        self._masked_g = set()       # data_ptr of gradient tensors stored masked (dz) by their producer
         g = g_final
         g_red = 0            # number of fused-reduce partial columns already written for the layer g belongs to
         self.patch_x_bwd = None
@@ -669,12 +670,18 @@ class Program:
                 # one sweep: dgrad + wgrad (+ fused reduce); both partial tables have `wrows` rows
                 if rt is not None:
                     ncols = wrows
-                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0], [], dwp, 0)
+                # g written by a project conv's out-stage backward as dz = g*[s*y+t>0] (see below): dy-on-read skips the mask
+                gm = 1 if g.data_ptr() in self._masked_g else 0
+                if gm and rt is None:
+                    raise AssertionError("masked gradient handed to a depthwise backward without the fused reduce")
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0, 0, gm], [], dwp, 0)
                 if merge:
                     self._queue_wgrad(ops, wsc.data_ptr(), wrows, Co, 1, ci.k * ci.k, True, eng.gptr(ci, 0))
                 else:
                     ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
             else:
+                if g.data_ptr() in self._masked_g:
+                    raise AssertionError("masked gradient handed to the two-launch depthwise backward")
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
                 ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
@@ -698,7 +705,14 @@ class Program:
                 conv = ci.mod.conv
                 gyp = [gy[0], None, gy[2]]
                 extra = [None, ci.w_fwd.data_ptr(), conv.bias.data_ptr() if conv.bias is not None else None]
-            ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts], [],
+            # project conv in front of a depthwise conv: the out-stage form stores the input gradient already masked with the
+            # depthwise conv's ReLU (the mask its fused reduce computes anyway); mnas_dw_bwd then skips re-deriving it per window column
+            masked = 0
+            if (eng.dw_masked_g and rt is not None and resid is None and a_in.bn is not None and rt[0] is a_in.data
+                    and (lib.mnas_pw_bwd_forms(ci.cin, Co) & 4) and self._feeds_fused_dw(a_in)):
+                masked = 1
+                self._masked_g.add(gin.data_ptr())
+            ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts, masked], [],
                     a_in.act_ptrs() + gyp + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
                                              gin.data_ptr(), wsc.data_ptr()] + red + extra, 0)
             if merge:
@@ -795,6 +809,16 @@ class Program:
         ops.add(L.OP_IRB_BWD, geo + [2], [],
                 a_in.act_ptrs() + [g1.data_ptr(), e_ci.w_fwd.data_ptr(), b1p, bn_e.data_ptr(), G.data_ptr(), gin.data_ptr()], 0)
         return gin
+
+    def _feeds_fused_dw(self, act: _Act):
+        """True if the ConvBlock that produced the virtual activation `act` is a depthwise conv whose backward runs as the fused
+        sweep (the only mnas_dw_bwd form that takes a masked gradient)."""
+        for rec in self._records:
+            if rec[3] is act or (rec[3].data is act.data and rec[3].bn is act.bn):
+                ci = rec[1]
+                # ... and carries the fused reduce (its own input is a virtual activation), the form g_masked exists for
+                return ci.kind == "dw" and ci.k in self.eng.dw_fused_k and rec[2] is not None and rec[2].bn is not None
+        return False
 
     def _se_bwd(self, ops: _OpList, rec_index, gs):
         """Backward of the squeeze-excite stage: gs = dL/d(a2 * s) from the project conv's input gradient -> dL/d a2, and the
@@ -1031,6 +1055,10 @@ class Engine:
         # from its (narrow) input instead of reading the t-times wider stored tensor (mnas_pw_bwd RECOMP; round 4:
         # 209 -> 155 us per launch at 112x112, bit-identical results)
         self.pw_recompute_y = True
+        # project convs' fused backward (out-stage forms) store the depthwise conv's incoming gradient already masked with its ReLU
+        # (dz = g*[s*y+t>0], the mask the fused reduce computes anyway); the depthwise sweep's dy-on-read then skips the mask:
+        # 40 of the 5x5 row body's ~530 vector instructions (round 4; results bit-identical)
+        self.dw_masked_g = True
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
         self.pw_bwd_parts_small = 85     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)

@@ -180,3 +180,75 @@ def test_dw_bwd_src(shape, virt):
         "input gradient differs: max |d| = %g" % float((g_ref.float() - g_src.float()).abs().max())
     # different strip geometry = different summation order of the partial tables
     assert relerr(w_src, w_ref) < 1e-4 and relerr(r_src, r_ref) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# masked gradient hand-over: mnas_pw_bwd(gin_masked) -> mnas_dw_bwd(g_masked)
+MASKED = [(2, 12, 12, 16, 48, 3), (2, 20, 20, 24, 72, 5), (1, 28, 28, 40, 240, 5), (2, 14, 14, 96, 576, 5), (1, 14, 14, 80, 480, 3)]
+
+
+@pytest.mark.parametrize("shape", MASKED)
+def test_masked_gradient_handover(shape):
+    """A project conv's fused backward with gin_masked stores dz = g*[s*y2+t>0] (exactly g or 0 in bf16); the depthwise
+    backward with g_masked on that tensor must reproduce the plain pair (unmasked g, mask derived on read) bit for bit."""
+    lib = L.load()
+    N, H, W, Cc, E, k = shape
+    M = N * H * W
+    assert lib.mnas_pw_bwd_forms(E, Cc) & 4
+    y1, y2 = _x((N, E, H, W), 7), _x((N, E, H, W), 8)
+    G, y3 = _x((N, Cc, H, W), 9), _x((N, Cc, H, W), 10)
+    w3 = bf16r(O.det_param("t.p.weight", (Cc, E, 1, 1), 4))
+    wd = O.det_param("t.dw.weight", (E, 1, k, k), 6)
+    bn1, bn2, bn3 = rand_bn_coefs(E, 31, O), rand_bn_coefs(E, 32, O), rand_bn_coefs(Cc, 33, O)
+    y1d, y2d, Gd, y3d = nhwc(y1), nhwc(y2), nhwc(G), nhwc(y3)
+    bn1d, bn2d, bn3d = bn1.cuda(), bn2.cuda(), bn3.cuda()
+    w3d, wdp = pack(w3, L.PACK_DGRAD), pack(wd, L.PACK_DW)
+    a2in = act_in(y2d, bn2d[0], bn2d[1])
+
+    def proj(masked):
+        gin = torch.full((N, H, W, E), float("nan"), dtype=torch.bfloat16, device="cuda")
+        wpart = torch.full((3, Cc, E), float("nan"), device="cuda")
+        redp = torch.full((2, E, 3), float("nan"), device="cuda")
+        c = L.MnasPwBwd()
+        c.M, c.Ci, c.Co, c.nparts = M, E, Cc, 3
+        c.x, c.dy = a2in, grad_in(Gd, y3d, bn3d)
+        c.w, c.gin, c.wpartial = L.ptr(w3d), L.ptr(gin), L.ptr(wpart)
+        c.red_partial, c.red_y, c.red_bn = L.ptr(redp), L.ptr(y2d), L.ptr(bn2d)
+        c.gin_masked = 1 if masked else 0
+        L.check(lib.mnas_pw_bwd(C.byref(c), L.cur_stream()), "pw_bwd")
+        torch.cuda.synchronize()
+        return gin, wpart, redp
+
+    g_plain, wp0, rp0 = proj(False)
+    g_mask, wp1, rp1 = proj(True)
+    assert torch.equal(wp0, wp1) and torch.equal(rp0, rp1)
+    s2, t2 = bn2[0].view(1, -1, 1, 1), bn2[1].view(1, -1, 1, 1)
+    want = from_nhwc(g_plain) * ((s2 * y2 + t2) > 0)
+    assert torch.equal(from_nhwc(g_mask), want), "masked gradient is not g * [s*y+t > 0]"
+
+    def dw(g, masked):
+        nparts = 37
+        rows = lib.mnas_dw_rows(N, H, W, E, k, nparts, 1)
+        gin = torch.full((N, H, W, E), float("nan"), dtype=torch.bfloat16, device="cuda")
+        wpart = torch.full((rows, k * k, E), float("nan"), device="cuda")
+        redp = torch.full((2, E, rows), float("nan"), device="cuda")
+        a_ = L.MnasDwBwd()
+        a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts, a_.phase = N, H, W, E, k, nparts, 0
+        a_.x, a_.dy = act_in(y1d, bn1d[0], bn1d[1]), grad_in(g, y2d, bn2d)
+        a_.w, a_.gin, a_.wpartial = wdp.data_ptr(), gin.data_ptr(), wpart.data_ptr()
+        a_.red_bn, a_.red_partial = bn1d.data_ptr(), redp.data_ptr()
+        a_.g_masked = 1 if masked else 0
+        L.check(lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()), "dw_bwd")
+        torch.cuda.synchronize()
+        return gin, wpart, redp
+
+    r0, r1 = dw(g_plain, False), dw(g_mask, True)
+    for a, b in zip(r0, r1):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
+    # the masked flag without the fused reduce is rejected
+    a_ = L.MnasDwBwd()
+    a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts, a_.phase = N, H, W, E, k, 37, 1
+    a_.x, a_.dy = act_in(y1d, bn1d[0], bn1d[1]), grad_in(g_mask, y2d, bn2d)
+    a_.w, a_.gin = wdp.data_ptr(), g_plain.data_ptr()
+    a_.g_masked = 1
+    assert lib.mnas_dw_bwd(C.byref(a_), L.cur_stream()) == L.EINVAL
