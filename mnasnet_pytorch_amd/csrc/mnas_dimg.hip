@@ -37,8 +37,9 @@ struct DimgArgs {
     const float* red_bn;
 };
 
+// (PXW 4, CG 3: the 14x14 stride-1 layers with their couts cut into 48-channel groups -- 244-255 VGPRs, two workgroups per CU)
 template <int MODE, int PXW, int CG>
-__global__ __launch_bounds__(256) void k_dimg(DimgArgs a) {
+__global__ __launch_bounds__(256, (PXW == 4 && CG == 3 ? 2 : 1)) void k_dimg(DimgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -306,8 +307,11 @@ static bool dimg_plan(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, i
         p->pxw = p->ni * npix > 128 ? 4 : (p->ni * npix > 64 ? 2 : 1);
         const int cgmax = p->pxw == 4 ? 6 : 12;
         p->groups = (tiles + cgmax - 1) / cgmax;
-        // enough workgroups to cover the CUs: cout groups over grid.y (each re-stages the image)
-        while ((long long)(N / p->ni) * p->groups < wgs && p->groups < tiles) ++p->groups;
+        // enough workgroups to cover the CUs: cout groups over grid.y (each re-stages the image).  14x14 planes, stride 1: twice
+        // as many, smaller groups (<= 3 cout tiles: the 2-workgroups-per-CU instantiation): 80 -> 96 forward 33 -> 26 us, its input
+        // gradient 45 -> 33 us (round 4); the same split loses on the 7x7 planes (72 -> 82 us) and on the stride-2 layers
+        const int want = (npix > 64 && stride == 1) ? 2 * wgs : wgs;
+        while ((long long)(N / p->ni) * p->groups < want && p->groups < tiles) ++p->groups;
         p->cg = (tiles + p->groups - 1) / p->groups;
         p->groups = (tiles + p->cg - 1) / p->cg;
         const size_t img = (((size_t)(Hi + 2) * (Wi + 2) * (Ci + 8) * 2 + 15) & ~(size_t)15) * p->ni;
@@ -361,6 +365,7 @@ int mnas_dimg_run(const MnasConvGemm* c, void* stream) {
         MNAS_CHECK_LAUNCH(); \
         return MNAS_OK; \
     }
+    MNAS_DIMG(0, 4, 3) MNAS_DIMG(1, 4, 3)            // (smallest fitting cout-tile bound first: the register arrays are sized by it)
     MNAS_DIMG(0, 4, 6) MNAS_DIMG(0, 2, 12) MNAS_DIMG(0, 1, 12) MNAS_DIMG(1, 4, 6) MNAS_DIMG(1, 2, 12) MNAS_DIMG(1, 1, 12)
 #undef MNAS_DIMG
     return MNAS_EINVAL;
