@@ -2,7 +2,7 @@
 # Everything the round's profiles/ directory is built from, in ONE gpurun call:  bash tools/collect_round.sh <tag>
 # (kernel trace + timeline, FETCH / WRITE PMC passes, SQ + MFMA counter passes, the default bench line with its CPU baseline,
 # the variant configurations).  Summaries land in gpurun_out/; copy the ones to be judged into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.json 2> $R/gpurun_out/${TAG}_bench_default.err
 bash $R/tools/profile_round.sh $TAG
@@ -18,6 +18,7 @@ python3 bench.py --se --no-cpu-baseline > gpurun_out/${TAG}_bench_se.json 2>/dev
 for hw in 384x512 512x512 512x384; do
   python3 bench.py --hw $hw --batch 64 --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_bench_${hw}.json 2>/dev/null
 done
-for m in full fwd; do
-  MNAS_IRB=$m MNAS_BENCH_DETAIL=1 python3 bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_irb_${m}.json 2> gpurun_out/${TAG}_detail_irb_${m}.txt
-done
+python3 bench.py --clusters --no-cpu-baseline > gpurun_out/${TAG}_bench_clusters.json 2>/dev/null
+# round 4: the stand-alone chain benchmark of one inverted-residual block application (per-layer launches vs the tiled fused forms)
+python3 tools/kbench_irb112.py > gpurun_out/${TAG}_chain112.txt 2>&1
+python3 tools/kbench_irb112.py 56 24 72 5 > gpurun_out/${TAG}_chain56.txt 2>&1

@@ -3,7 +3,7 @@
 per-launch list of the fused-block run)."""
 import json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 COPY = {"prof_%s_kernel_trace.txt": "%s_kernel_trace.txt", "prof_%s_timeline.txt": "%s_timeline.txt",
@@ -34,12 +34,15 @@ for name in ("k5", "se"):
     runs[name] = entry(line(name))
 for hw in ("384x512", "512x512", "512x384"):
     runs[hw] = entry(line(hw), False)
-for m in ("full", "fwd"):
-    runs["irb_" + m] = entry(line("irb_" + m))
-note = ("one gpurun call (tools/collect_round.sh): variants of python bench.py on 1 x MI355X; irb_* = Engine.fuse_irb modes (MNAS_IRB), "
-        "rect shapes at --batch 64.  Box-to-box spread on this pool: the same commit has measured between 19.6k and 22.8k img/s on "
+c = line("clusters")
+runs["clusters"] = {"value": c["value"], "ms_per_step": c["ms_per_step"], "workload": c["config"]["workload"],
+                    "steps_per_cluster": c["config"]["steps_per_cluster"], "programs_live": c["config"]["programs_live"],
+                    "clusters": c["clusters"]}
+note = ("one gpurun call (tools/collect_round.sh): variants of python bench.py on 1 x MI355X; clusters = bench.py --clusters (one "
+        "resolution cluster per step, DistributedClusterSampler); rect shapes at --batch 64.  Box-to-box spread on this pool: the same commit has measured between 19.6k and 22.8k img/s on "
         "different boxes (default command), so only numbers from the same call are comparable.")
 with open(os.path.join(dst, "%s_bench_variants.json" % tag), "w") as f:
     json.dump({"note": "round %s, " % tag[1:] + note, "runs": runs}, f, indent=1)
-shutil.copyfile(os.path.join(src, "%s_detail_irb_full.txt" % tag), os.path.join(dst, "%s_irb_full_per_launch.txt" % tag))
+for hw in ("112", "56"):
+    shutil.copyfile(os.path.join(src, "%s_chain%s.txt" % (tag, hw)), os.path.join(dst, "%s_chain%s.txt" % (tag, hw)))
 print("installed profiles/%s_*" % tag)
