@@ -398,8 +398,6 @@ OVERRIDES = [
     ("MNAS_FUSE", "fused expand + depthwise forward kernels that also store y1 (measured slower)",
      lambda e: setattr(e, "fuse_expand", True)),
     ("MNAS_DW5_SPLIT", "two-launch backward for the 5x5 depthwise layers", lambda e: setattr(e, "dw_fused_k", (3,))),
-    ("MNAS_TILED", "spatially tiled fused block on the large maps: full | fwd | off",
-     lambda e: setattr(e, "fuse_tiled", {"full": "full", "fwd": "fwd", "off": False}[os.environ["MNAS_TILED"]])),
     ("MNAS_LIB_PATH", "alternative build of libmnas_hip.so (tools/build_alt.sh)", lambda e: None),
 ]
 
