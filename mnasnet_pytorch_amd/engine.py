@@ -655,7 +655,7 @@ class Program:
             self.patch_x_bwd = (ops, jx, 0)
             ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
         elif ci.kind == "dw":
-            nparts = max(64, min(1024, _cdiv(M * Co, 256 * 16 * 2)))
+            nparts = max(64, min(eng.dw_bwd_parts, _cdiv(M * Co, 256 * 16 * 2)))
             gin = new((N, Hi, Wi, ci.cin))
             red = [None, None]
             if rt is not None:
@@ -1059,6 +1059,7 @@ class Engine:
         # (dz = g*[s*y+t>0], the mask the fused reduce computes anyway); the depthwise sweep's dy-on-read then skips the mask:
         # 40 of the 5x5 row body's ~530 vector instructions (round 4; results bit-identical)
         self.dw_masked_g = True
+        self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
         self.pw_bwd_parts_small = 85     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)
