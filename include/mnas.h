@@ -90,7 +90,12 @@ typedef struct MnasConvGemm {
      * mnas_bn_bwd_reduce would produce from (out, red_y, red_bn). */
     const void*  red_y;
     const float* red_bn;
+    /* ABI 5, mode 0, 1x1 only, optional: per-(image, input channel) multiplier float[N][Ci] applied AFTER the activation on
+     * load, value = relu(scale*x+shift) * gate[n][c] -- the squeeze-excite excitation folded into the project conv's load
+     * (mnas_se_gate writes the table).  Requires act.scale; supported shapes: mnas_conv_gemm_gate_ok. */
+    const float* gate;
 } MnasConvGemm;
+int mnas_conv_gemm_gate_ok(int N, int HW, int Ci, int Co);
 int mnas_conv_gemm(const MnasConvGemm* a, void* stream);
 /* Pixels per tile (64 or 128) mnas_conv_gemm uses for a problem with M output pixels, Co output channels and reduction
  * length K (= kh*kw*Ci of that mode): callers size nparts in whole tiles with it (host-side, no launch). */
@@ -179,10 +184,18 @@ typedef struct MnasPwBwd {
     /* round 4: store gin MASKED, dz = gin*[s*x+t>0] under red_bn (the mask its fused reduce computes anyway), for a consumer
      * that would otherwise re-derive it per element and window column (mnas_dw_bwd g_masked).  Out-stage forms with the fused
      * reduce only (mnas_pw_bwd_forms bit 2); MNAS_EINVAL otherwise. */
-    int32_t gin_masked, reserved;
+    int32_t gin_masked;
+    /* ABI 5: > 0 = "segment mode": workgroup b owns the contiguous pixels [b*seg_px, (b+1)*seg_px) (nparts*seg_px >= M >
+     * (nparts-1)*seg_px) instead of striding over the tiles of the whole tensor, so that wpartial[b] is the weight-gradient sum
+     * over a KNOWN pixel range -- with seg_px dividing H*W, a fraction of one image: what mnas_se_proj_finalize needs. */
+    int32_t seg_px;
 } MnasPwBwd;
 int mnas_pw_bwd(const MnasPwBwd* a, void* stream);
 int mnas_pw_bwd_supported(int Ci, int Co);
+/* ABI 5: pixels per tile (64 / 128) and channel slices of the launch for a supported channel pair (-1 otherwise): segment mode
+ * wastes ceil(seg_px / tile) * tile - seg_px pixel slots per workgroup, a caller picks seg_px with that in view. */
+int mnas_pw_bwd_tile_pixels(int Ci, int Co);
+int mnas_pw_bwd_slices(int Ci, int Co);
 int mnas_pw_bwd_forms(int Ci, int Co);      /* bit 0: NOGIN available for this channel pair, bit 1: RECOMP, bit 2: gin_masked */
 
 /* ---- depthwise kxk (k in {3,5}, stride 1, pad k/2), LDS-tiled direct conv on the vector ALU ----------
@@ -487,6 +500,17 @@ int64_t mnas_se_scratch_bytes(int N, int HW, int C);
 int mnas_se_bwd_apply(const void* gs, const float* u, const float* dz, int N, int HW, int C, void* out_bf16,
                       const void* red_y, const float* red_bn, float* red_partial, void* stream);
 int mnas_se_bwd_apply_cols(int N, int HW, int C);
+/* ABI 5 -- the excitation applied ON LOAD instead of through a materialised a*s (csrc/mnas_se.hip):
+ *   mnas_se_gate          : gate[n][c] = sigmoid(u[n][c]), fp32 -- the table MnasConvGemm.gate takes.
+ *   mnas_se_proj_finalize : after mnas_pw_bwd of the PROJECT conv run in segment mode (MnasPwBwd.seg_px = HW / kseg, nparts =
+ *                           N * kseg) on the UNGATED activation act(a): wpartial float[N*kseg][Co][Ci] holds per-image(-fraction)
+ *                           sums of dy[pix][o] * act(a)[pix][c].  Writes du[n][c] = (sum_o W[o][c] * P_n[o][c]) * s (1 - s)
+ *                           (= what mnas_se_bwd_reduce computes from gs = dy . W, without the pass over gs and a) and the conv's
+ *                           weight gradient dW[o][c] (+)= sum_n s[n][c] * P_n[o][c].  W: the conv's fp32 weight [Co][Ci].
+ *                           wpartial is overwritten (scratch).  Deterministic (fixed summation order). */
+int mnas_se_gate(const float* u, int N, int C, float* gate, void* stream);
+int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, int Ci, const float* u, const float* W, float* dW,
+                          int accumulate, float* du, void* stream);
 
 /* ---- weight packing (fp32 reference layout [Co][Ci/g][kh][kw] -> kernel layouts) -------------------- */
 #define MNAS_PACK_FWD   0   /* bf16 [Co_pad16][Kpad32], k = tap*Ci+ci            (mnas_conv_gemm mode 0) */
@@ -552,6 +576,8 @@ int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 #define MNAS_OP_SE_SCALE 31
 #define MNAS_OP_SE_BWD_REDUCE 32
 #define MNAS_OP_SE_BWD_APPLY 33
+#define MNAS_OP_SE_GATE 34          /* ABI 5 */
+#define MNAS_OP_SE_PROJ_FIN 35      /* ABI 5 */
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

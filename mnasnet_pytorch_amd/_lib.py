@@ -8,7 +8,7 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 4          # include/mnas.h: mnas_version()
+ABI_VERSION = 5          # include/mnas.h: mnas_version()
 LIB_PATH = os.environ.get("MNAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmnas_hip.so")      # override: A/B builds (tools/)
 
 c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
@@ -27,7 +27,7 @@ class MnasConvGemm(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("stride", C.c_int32), ("pad", C.c_int32), ("nparts", C.c_int32), ("reserved", C.c_int32),
                 ("act", MnasActIn), ("grad", MnasGradIn), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p),
-                ("out", c_void_p), ("stats", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p)]
+                ("out", c_void_p), ("stats", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p), ("gate", c_void_p)]
 
 
 class MnasConvWgrad(C.Structure):
@@ -61,7 +61,7 @@ class MnasPwBwd(C.Structure):
     _fields_ = [("M", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32), ("nparts", C.c_int32), ("x", MnasActIn),
                 ("dy", MnasGradIn), ("w", c_void_p), ("resid", c_void_p), ("gin", c_void_p), ("wpartial", c_void_p),
                 ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p), ("dy_out", c_void_p), ("w_fwd", c_void_p),
-                ("b_fwd", c_void_p), ("gin_masked", C.c_int32), ("reserved", C.c_int32)]
+                ("b_fwd", c_void_p), ("gin_masked", C.c_int32), ("seg_px", C.c_int32)]
 
 
 class MnasPostWgrad(C.Structure):
@@ -122,6 +122,7 @@ OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP
 OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
 OP_BWD_POST, OP_TCONV_DGRAD, OP_IRB_FWD, OP_IRB_BWD, OP_IRB_W1_FIN = 25, 26, 27, 28, 29
 OP_HEAD_LINEAR, OP_SE_SCALE, OP_SE_BWD_REDUCE, OP_SE_BWD_APPLY = 30, 31, 32, 33
+OP_SE_GATE, OP_SE_PROJ_FIN = 34, 35
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 EINVAL = 10001      # MNAS_EINVAL
 
@@ -154,6 +155,9 @@ SYMBOLS = {
     "mnas_se_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
     "mnas_se_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnas_se_bwd_apply_cols": (c_int, [c_int, c_int, c_int]),
+    "mnas_se_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mnas_se_proj_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "mnas_conv_gemm_gate_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),
     "mnas_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
@@ -166,6 +170,8 @@ SYMBOLS = {
     "mnas_pw_bwd": (c_int, [C.POINTER(MnasPwBwd), c_void_p]),
     "mnas_pw_bwd_supported": (c_int, [c_int, c_int]),
     "mnas_pw_bwd_forms": (c_int, [c_int, c_int]),
+    "mnas_pw_bwd_tile_pixels": (c_int, [c_int, c_int]),
+    "mnas_pw_bwd_slices": (c_int, [c_int, c_int]),
     "mnas_dw_fwd": (c_int, [C.POINTER(MnasDwFwd), c_void_p]),
     "mnas_dw_bwd": (c_int, [C.POINTER(MnasDwBwd), c_void_p]),
     "mnas_dw_exp_fwd": (c_int, [C.POINTER(MnasDwExpFwd), c_void_p]),

@@ -34,7 +34,7 @@ int mnas_pws_enabled() {
     return on;
 }
 
-extern "C" int mnas_version(void) { return 4; }
+extern "C" int mnas_version(void) { return 5; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 
 extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
@@ -94,6 +94,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.grad.g = p[3]; a.grad.y = p[4]; a.grad.coef = (const float*)p[5];
             a.w = p[6]; a.bias = (const float*)p[7]; a.resid = p[8]; a.out = p[9]; a.stats = (float*)p[10];
             a.red_y = p[11]; a.red_bn = (const float*)p[12];
+            a.gate = (const float*)p[13];
             return mnas_conv_gemm(&a, stream);
         }
         case MNAS_OP_CONV_WGRAD: {
@@ -122,7 +123,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.w = p[6]; a.resid = p[7]; a.gin = p[8]; a.wpartial = (float*)p[9];
             a.red_partial = (float*)p[10]; a.red_y = p[11]; a.red_bn = (const float*)p[12];
             a.dy_out = p[13]; a.w_fwd = p[14]; a.b_fwd = (const float*)p[15];
-            a.gin_masked = i[4];
+            a.gin_masked = i[4]; a.seg_px = i[5];
             return mnas_pw_bwd(&a, stream);
         }
         case MNAS_OP_GRAM: {
@@ -267,6 +268,11 @@ static int run_one(const MnasOp& o, void* stream) {
             MnasActIn a = {p[1], (const float*)p[2], (const float*)p[3]};
             return mnas_se_bwd_reduce(p[0], &a, (const float*)p[4], i[0], i[1], i[2], (float*)p[5], (float*)p[6], stream);
         }
+        case MNAS_OP_SE_GATE:
+            return mnas_se_gate((const float*)p[0], i[0], i[1], (float*)p[1], stream);
+        case MNAS_OP_SE_PROJ_FIN:
+            return mnas_se_proj_finalize((float*)p[0], i[0], i[1], i[2], i[3], (const float*)p[1], (const float*)p[2], (float*)p[3],
+                                         i[4], (float*)p[4], stream);
         case MNAS_OP_SE_BWD_APPLY:
             return mnas_se_bwd_apply(p[0], (const float*)p[1], (const float*)p[2], i[0], i[1], i[2], p[3], p[4], (const float*)p[5],
                                      (float*)p[6], stream);

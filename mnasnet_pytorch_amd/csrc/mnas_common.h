@@ -82,6 +82,19 @@ __device__ __forceinline__ uint4 act8(const uint4& raw, const float* s, const fl
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
+// gated act-on-load (squeeze-excite applied on load, csrc/mnas_se.hip): relu(s*x+t) * g, g = the per-(image, channel) excitation
+__device__ __forceinline__ uint4 act8g(const uint4& raw, const float* s, const float* t, const float* g) {
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const mnas_f2 z = mnas_f2fma(mnas_bf2(u[j]), mnas_ld2(s + 2 * j), mnas_ld2(t + 2 * j));
+        const mnas_f2 r = {fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)};
+        const mnas_f2 q = r * mnas_ld2(g + 2 * j);
+        o[j] = pack_bf16(q.x, q.y);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 // dy-on-load for one channel group: c1*(g*[s*y+t>0]) + c2*y + c3 ; coef rows are s,t,c1,c2,c3
 __device__ __forceinline__ void dy8(const uint4& graw, const uint4& yraw, const float* s, const float* t,
                                     const float* c1, const float* c2, const float* c3, float* out) {
@@ -146,6 +159,7 @@ int mnas_pwd_dgrad(const MnasConvGemm* c, void* stream);
 int mnas_pws_enabled();
 int mnas_pws_parts(int mode, int M, int K, int N);
 int mnas_pws_run(const MnasConvGemm* c, void* stream);
+int mnas_pws_gate_ok(int M, int K, int N);
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

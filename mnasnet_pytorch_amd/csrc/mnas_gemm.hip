@@ -35,6 +35,7 @@ struct IgemmArgs {
     const float* red_bn;
     int nt;                  // nontemporal output stores
     float rcp_hw, rcp_wo, rcp_ci;   // reciprocals for igemm_fdiv (0 = use the exact integer division)
+    const float* gate;       // MODE 0, 1x1 (GATE instantiations): per-(image, input channel) multiplier [N][Ci] applied after the activation
 };
 
 // floor(n / d) for 0 <= n < 2^24, d > 0 with a float reciprocal and one correction step (7 instructions instead of the ~25
@@ -49,8 +50,9 @@ __device__ __forceinline__ int igemm_fdiv(int n, int d, float rcp) {
     return q;
 }
 
-template <int MODE, int NT, int PT, int KCH, bool PIPE, bool PAR2>
+template <int MODE, int NT, int PT, int KCH, bool PIPE, bool PAR2, bool GATE = false>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
+    static_assert(!GATE || (MODE == 0 && !PAR2), "the gate is an act-on-load extension of the 1x1 forward");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
     constexpr int CROWS = (MODE == 1) ? 5 : 2;
@@ -135,7 +137,11 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
     // prologue transform and writes LDS one phase later, when they have landed.
     constexpr int NA = BP * kc8n / 256;
     uint4 v0[NA], v1[MODE == 1 ? NA : 1];
-    unsigned okm = 0;
+    // GATE: a thread's slots share the channel chunk and a tile spans at most two images (host: H*W >= tile pixels), so two gate
+    // vectors per load phase serve all of them (per-slot vectors cost 32 VGPRs and 2x the activation bytes in L1 traffic: the
+    // 72 -> 24 project conv at 56x56 went 39 -> 78 us)
+    float gq0[8], gq1[8];                          // (plain floats: pointer arithmetic across float4 members lands in scratch)
+    unsigned okm = 0, gsel = 0;
     auto load_a = [&](int t, int k0) {
         const int tile0 = decode_tile(t);
         const int kc8 = tid & (kc8n - 1);
@@ -153,10 +159,26 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
             th = tap / a.kw; tw = tap - th * a.kw;
         }
         okm = 0;
+        int m_next = 0;                            // GATE: first pixel of the image after the tile's first one
+        if constexpr (GATE) {
+            const int hw = a.Ho * a.Wo;
+            const int nA = igemm_fdiv(tile0 < a.M ? tile0 : a.M - 1, hw, a.rcp_hw);
+            m_next = (nA + 1) * hw;
+            gsel = 0;
+            if (kok) {
+                const float* gp = a.gate + (size_t)nA * a.Ci + k;
+                const float* gn = gp + (m_next < a.M ? a.Ci : 0);
+                const float4 a0 = *(const float4*)gp, a1 = *(const float4*)(gp + 4);
+                const float4 b0 = *(const float4*)gn, b1 = *(const float4*)(gn + 4);
+                gq0[0] = a0.x; gq0[1] = a0.y; gq0[2] = a0.z; gq0[3] = a0.w; gq0[4] = a1.x; gq0[5] = a1.y; gq0[6] = a1.z; gq0[7] = a1.w;
+                gq1[0] = b0.x; gq1[1] = b0.y; gq1[2] = b0.z; gq1[3] = b0.w; gq1[4] = b1.x; gq1[5] = b1.y; gq1[6] = b1.z; gq1[7] = b1.w;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int p = (tid >> KSH) + (256 >> KSH) * i;
             const int m = tile0 + p;
+            if constexpr (GATE) gsel |= (m >= m_next ? 1u : 0u) << i;
             v0[i] = make_uint4(0, 0, 0, 0);
             if (MODE == 1) v1[i] = make_uint4(0, 0, 0, 0);
             if (MODE == 2) {
@@ -245,7 +267,14 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a) {
             for (int i = 0; i < NA; ++i) {
                 if (!((okm >> i) & 1u)) continue;
                 if (MODE == 0) {
-                    v0[i] = act8(v0[i], cf[0], cf[1]);
+                    if constexpr (GATE) {
+                        const bool hi = (gsel >> i) & 1u;
+                        float gg[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) gg[j] = hi ? gq1[j] : gq0[j];
+                        v0[i] = act8g(v0[i], cf[0], cf[1], gg);
+                    }
+                    else v0[i] = act8(v0[i], cf[0], cf[1]);
                 } else if (MODE == 1) {
                     float o[8];
                     dy8(v0[i], v1[i], cf[0], cf[1], cf[2 % CROWS], cf[3 % CROWS], cf[4 % CROWS], o);
@@ -478,6 +507,16 @@ static int launch_igemm_k(const IgemmArgs& a, int nparts, int nblocks, bool pipe
             return MNAS_OK;
         }
     }
+    if (a.gate) {       // gated act-on-load: the narrow 1x1 forward shapes only (the squeeze-excite project convs, K < 192)
+        if constexpr (MODE == 0 && NT <= 3 && KCH <= 64) {
+            if (a.Ho * a.Wo < 64 * PT) return MNAS_EINVAL;       // a tile may span two images, not three
+            if (pipe) hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, true, false, true>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+            else hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, false, false, true>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
+            MNAS_CHECK_LAUNCH();
+            return MNAS_OK;
+        }
+        return MNAS_EINVAL;
+    }
     if (pipe) hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, true, false>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((k_igemm<MODE, NT, PT, KCH, false, false>), dim3(nparts, nblocks), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
@@ -555,6 +594,17 @@ extern "C" int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps) {
     return -1;
 }
 
+// Shapes whose 1x1 forward takes MnasConvGemm.gate: the streaming kernel with short per-wave K slices (K >= 192), or k_igemm
+// with at most three output tiles.
+extern "C" int mnas_conv_gemm_gate_ok(int N, int HW, int Ci, int Co) {
+    if (N < 1 || HW < 1 || (Ci & 7) || (Co & 7) || Ci < 8 || Co < 8) return 0;
+    const int M = N * HW;
+    if (mnas_pws_parts(0, M, Ci, Co) > 0) return mnas_pws_gate_ok(M, Ci, Co);
+    int nt, nblocks, pt;
+    igemm_tiling(Co, (Ci + 31) / 32 * 32, M, &nt, &nblocks, &pt);
+    return (nt <= 3 && nblocks == 1 && !(pt == 1 && Ci >= 256) && HW >= 64 * pt) ? 1 : 0;
+}
+
 extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (!c || (c->mode != 0 && c->mode != 1)) return MNAS_EINVAL;
     if ((c->Ci & 7) || (c->Co & 7) || c->nparts < 1 || c->nparts > 65535) return MNAS_EINVAL;
@@ -572,6 +622,8 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = c->resid; a.out = c->out; a.stats = c->stats;
     a.red_y = (c->mode == 1) ? c->red_y : nullptr; a.red_bn = c->red_bn;
     a.nt = (mnas_nt_mask() & (c->mode == 1 ? MNAS_NT_IGEMM_DGRAD : MNAS_NT_IGEMM_FWD)) ? 1 : 0;
+    a.gate = c->gate;
+    if (a.gate && (c->mode != 0 || !a.is_pw || !c->act.scale || c->resid)) return MNAS_EINVAL;
     {   // the decode divides by the OUTPUT plane (half plane for the parity-class form); exact division beyond 2^24 pixels
         const int s2f = (c->mode == 1 && c->kh == 3 && c->kw == 3 && c->stride == 2 && c->pad == 1 && !(c->Ho & 1) && !(c->Wo & 1));
         const int wd = s2f ? c->Wo / 2 : c->Wo, hwd = s2f ? (c->Ho / 2) * wd : c->Ho * c->Wo;
@@ -593,7 +645,7 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
         const int rc = mnas_pws_run(c, stream);          // MNAS_EINVAL: not that kernel's case (a materialised dy): fall through
         if (rc != MNAS_EINVAL) return rc;
     }
-    if (c->mode == 0 && a.is_pw && !c->resid && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
+    if (c->mode == 0 && a.is_pw && !c->resid && !c->gate && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwf_forward(c, stream);
     if (c->mode == 1 && a.is_pw && !c->resid && !c->bias && mnas_pwd_enabled() && mnas_pwd_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwd_dgrad(c, stream);
@@ -634,7 +686,7 @@ extern "C" int mnas_stem_fwd(const MnasStemFwd* c, void* stream) {
     a.act.data = c->x; a.act.scale = nullptr; a.act.shift = nullptr;
     a.grad.g = nullptr; a.grad.y = nullptr; a.grad.coef = nullptr;
     a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = nullptr; a.out = c->out; a.stats = c->stats;
-    a.red_y = nullptr; a.red_bn = nullptr;
+    a.red_y = nullptr; a.red_bn = nullptr; a.gate = nullptr;
     a.nt = (mnas_nt_mask() & MNAS_NT_STEM) ? 1 : 0;
     a.rcp_hw = (int64_t)a.M < (1 << 24) ? 1.0f / (float)(c->Ho * c->Wo) : 0.f;
     a.rcp_wo = (int64_t)a.M < (1 << 24) ? 1.0f / (float)c->Wo : 0.f;

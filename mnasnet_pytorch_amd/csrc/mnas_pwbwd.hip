@@ -47,6 +47,7 @@ struct PwBwdArgs {
     const float* b_fwd;      // FORM 2: [Co] or NULL
     int Kf;                  // FORM 2: Ci rounded up to 32
     int gin_masked;          // out-stage forms: store dz = gin*[s*x+t>0] (the fused reduce's mask) instead of gin
+    int seg_px;              // > 0: segment mode (see the tile walk)
 };
 
 __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
@@ -186,16 +187,19 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { rs1[i][r] = 0.f; rs2[i][r] = 0.f; }
 
-    const int ntiles = (a.M + BP - 1) / BP;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tile0 = t * BP;
+    // Tile walk: workgroups stride over the 64*PT-pixel tiles of the whole tensor, or (seg_px > 0, "segment mode") workgroup b
+    // owns the contiguous pixels [b*seg_px, (b+1)*seg_px) -- its weight-gradient partial is then the sum over a known pixel
+    // range (a fraction of ONE image for the squeeze-excite project conv: csrc/mnas_se.hip k_se_proj_du)
+    const int mend = a.seg_px ? min(a.M, ((int)blockIdx.x + 1) * a.seg_px) : a.M;
+    const int tstep = a.seg_px ? BP : (int)gridDim.x * BP;
+    for (int tile0 = a.seg_px ? (int)blockIdx.x * a.seg_px : (int)blockIdx.x * BP; tile0 < mend; tile0 += tstep) {
         __syncthreads();                                     // previous tile's fragments consumed (first pass: setup visible)
         // ---- issue every load of the tile, then transform + write
         uint4 vg[ND], vy[ND], vx[NX];
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             vg[i] = make_uint4(0, 0, 0, 0); vy[i] = make_uint4(0, 0, 0, 0);
-            if (pd[i] >= 0 && tile0 + pd[i] < a.M) {
+            if (pd[i] >= 0 && tile0 + pd[i] < mend) {
                 const size_t off = (size_t)(tile0 + pd[i]) * a.Co + cd8[i] * 8;
                 vg[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
                 if constexpr (FORM != 2) vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             vx[i] = make_uint4(0, 0, 0, 0);
-            if (pa[i] >= 0 && tile0 + pa[i] < a.M)
+            if (pa[i] >= 0 && tile0 + pa[i] < mend)
                 vx[i] = *(const uint4*)((const uint16_t*)a.x.data + (size_t)(tile0 + pa[i]) * a.Ci + ci0 + ca8[i] * 8);
         }
 #pragma unroll
@@ -212,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             if (pd[i] < 0) continue;
             uint4 v = make_uint4(0, 0, 0, 0);
             if constexpr (FORM == 2) {
-                if (tile0 + pd[i] < a.M) v = vg[i];          // raw g: dy is formed after the recompute below
-            } else if (tile0 + pd[i] < a.M) {
+                if (tile0 + pd[i] < mend) v = vg[i];          // raw g: dy is formed after the recompute below
+            } else if (tile0 + pd[i] < mend) {
                 float cf[5][8];
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         for (int i = 0; i < NX; ++i) {
             if (pa[i] < 0) continue;
             uint4 v = vx[i];
-            if (tile0 + pa[i] >= a.M) v = make_uint4(0, 0, 0, 0);
+            if (tile0 + pa[i] >= mend) v = make_uint4(0, 0, 0, 0);
             else if (hasx) {
                 float s[8], sh[8];
                 *(float4*)&s[0] = *(const float4*)(lds_cx + ca8[i] * 8);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                     if (ks * 32 + lg * 8 < CIP) v = *(const uint4*)(tile_a + p * lda + ks * 32 + lg * 8);
                     xb[ks] = *(const bf16x8_t*)&v;
                 }
-                const bool pok = tile0 + p < a.M;              // rows past the end stay zero (they feed the weight gradient)
+                const bool pok = tile0 + p < mend;              // rows past the end stay zero (they feed the weight gradient)
 #pragma unroll
                 for (int to = 0; to < NTO; ++to) {
                     f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             for (int nt = 0; nt < NTI; ++nt) {
                 const int ci = nt * 16 + lg * 4;
                 ypre[pt][nt] = make_uint2(0, 0); rpre[pt][nt] = make_uint2(0, 0);
-                if (m < a.M && ci < cis) {
+                if (m < mend && ci < cis) {
                     const size_t o = (size_t)m * a.Ci + ci0 + ci;
                     if (!OS && do_red) ypre[pt][nt] = *(const uint2*)((const uint16_t*)a.red_y + o);
                     if (!OS && a.resid) rpre[pt][nt] = *(const uint2*)((const uint16_t*)a.resid + o);
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
             for (int k = 0; k < MAXR; ++k) {
                 const int p = orow0 + k * OROWS;
-                if (!(ocol_ok && p < BP && tile0 + p < a.M)) continue;
+                if (!(ocol_ok && p < BP && tile0 + p < mend)) continue;
                 const uint4 pk = *(const uint4*)(tile_a + p * lda + oc8 * 8);
                 uint16_t* gdst = (uint16_t*)a.gin + ((size_t)(tile0 + p) * a.Ci + ci0 + oc8 * 8);
                 if (FORM != 1 && !a.gin_masked) st_u4(gdst, pk, true);
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int m = tile0 + (wave * PT + pt) * 16 + l15;
-            const bool mok = m < a.M;
+            const bool mok = m < mend;
 #pragma unroll
             for (int nt = 0; nt < NTI; ++nt) {
                 const int ci = nt * 16 + lg * 4;
@@ -594,6 +598,9 @@ static const PwCfg* pw_cfg(int Ci, int Co) {
     return nullptr;
 }
 extern "C" int mnas_pw_bwd_supported(int Ci, int Co) { return pw_cfg(Ci, Co) ? 1 : 0; }
+// pixels per tile / channel slices (grid.y) of the launch for this channel pair: what a caller sizing MnasPwBwd.seg_px needs
+extern "C" int mnas_pw_bwd_tile_pixels(int Ci, int Co) { const PwCfg* c = pw_cfg(Ci, Co); return c ? 64 * c->pt : -1; }
+extern "C" int mnas_pw_bwd_slices(int Ci, int Co) { const PwCfg* c = pw_cfg(Ci, Co); return c ? c->nslices : -1; }
 // bit 0: NOGIN (gin == NULL) available, bit 1: RECOMP (dy.y == NULL + w_fwd) available -- mirrors launch_pw_bwd's dispatch
 extern "C" int mnas_pw_bwd_forms(int Ci, int Co) {
     const PwCfg* c = pw_cfg(Ci, Co);
@@ -618,6 +625,8 @@ extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     a.nt = (mnas_nt_mask() & MNAS_NT_PW_BWD) ? 1 : 0;
     a.dy_out = c->dy_out; a.w_fwd = (const uint16_t*)c->w_fwd; a.b_fwd = c->b_fwd; a.Kf = (c->Ci + 31) / 32 * 32;
     a.gin_masked = c->gin_masked;
+    a.seg_px = c->seg_px;
+    if (a.seg_px < 0 || (a.seg_px > 0 && ((int64_t)a.seg_px * c->nparts < c->M || (int64_t)a.seg_px * (c->nparts - 1) >= c->M))) return MNAS_EINVAL;
     if (a.gin_masked && (!c->red_partial || c->resid || c->red_y != c->x.data || !(mnas_pw_bwd_forms(c->Ci, c->Co) & 4))) return MNAS_EINVAL;
     const PwCfg* cfg = pw_cfg(c->Ci, c->Co);
     hipStream_t s = (hipStream_t)stream;

@@ -30,10 +30,13 @@ struct PwsArgs {
     float* stats;            // [2][N][gridDim.x] or NULL
     const void* red_y;       // MODE 1 fused reduce target (raw output of the ConvBlock whose gradient `out` is), or NULL
     const float* red_bn;
+    const float* gate;       // MODE 0 GATE instantiations: float[images][K] multiplier applied after the activation (csrc/mnas_se.hip)
+    int hw;                  // pixels per image (gate row = pixel / hw)
 };
 
-template <int MODE, int NT, int KSW, int NW>
+template <int MODE, int NT, int KSW, int NW, bool GATE = false>
 __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
+    static_assert(!GATE || MODE == 0, "the gate is an act-on-load extension of the forward");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NB = NT * 16, CROWS = MODE == 1 ? 5 : 2;
     constexpr int PP = NB + 4;                               // partial row pitch (floats)
@@ -99,8 +102,10 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
 
     const int ngroups = (a.M + 15) >> 4;
     uint4 v0[KSW], v1[MODE == 1 ? KSW : 1];
+    float gq[GATE ? KSW : 1][8];                             // GATE: the fragment's 8 multipliers, fetched with it
     auto issue = [&](int g) {
         const int m = g * 16 + l15;
+        const float* grow = GATE ? a.gate + (size_t)(m / a.hw) * a.K : nullptr;
 #pragma unroll
         for (int j = 0; j < KSW; ++j) {
             const int k = (wave + NW * j) * 32 + lg * 8;
@@ -108,6 +113,11 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
             if (MODE == 1) v1[j] = make_uint4(0, 0, 0, 0);
             if (m < a.M && k < a.K) {
                 const size_t off = (size_t)m * a.K + k;
+                if constexpr (GATE) {
+                    const float4 a0 = *(const float4*)(grow + k), a1 = *(const float4*)(grow + k + 4);
+                    gq[j][0] = a0.x; gq[j][1] = a0.y; gq[j][2] = a0.z; gq[j][3] = a0.w;
+                    gq[j][4] = a1.x; gq[j][5] = a1.y; gq[j][6] = a1.z; gq[j][7] = a1.w;
+                }
                 if (MODE == 0) v0[j] = *(const uint4*)((const uint16_t*)a.act.data + off);
                 else {
                     v0[j] = *(const uint4*)((const uint16_t*)a.grad.g + off);
@@ -133,8 +143,10 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
                     *(float4*)&cf[r][0] = *(const float4*)(lds_coef + r * a.Kpad + k);
                     *(float4*)&cf[r][4] = *(const float4*)(lds_coef + r * a.Kpad + k + 4);
                 }
-                if (MODE == 0) v = act8(v, cf[0], cf[1]);
-                else {
+                if (MODE == 0) {
+                    if constexpr (GATE) v = act8g(v, cf[0], cf[1], gq[j]);
+                    else v = act8(v, cf[0], cf[1]);
+                } else {
                     float o[8];
                     dy8(v, v1[j], cf[0], cf[1], cf[2 % CROWS], cf[3 % CROWS], cf[4 % CROWS], o);
                     v = pack8(o);
@@ -262,6 +274,14 @@ int mnas_pws_parts(int mode, int M, int K, int N) {
 
 template <int MODE, int NT, int KSW, int NW>
 static int pws_launch(const PwsArgs& a, const PwsPlan& p, int nparts, hipStream_t s) {
+    if (a.gate) {       // gated act-on-load: forward, short per-wave K slices only (registers: 8 more per k-step of the slice)
+        if constexpr (MODE == 0 && KSW <= 3) {
+            hipLaunchKernelGGL((k_pws<MODE, NT, KSW, NW, true>), dim3(nparts, p.nblocks), dim3(64 * NW), p.lds, s, a);
+            MNAS_CHECK_LAUNCH();
+            return MNAS_OK;
+        }
+        return MNAS_EINVAL;
+    }
     hipLaunchKernelGGL((k_pws<MODE, NT, KSW, NW>), dim3(nparts, p.nblocks), dim3(64 * NW), p.lds, s, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
@@ -275,6 +295,12 @@ static int pws_dispatch(const PwsArgs& a, const PwsPlan& p, int nparts, hipStrea
     return MNAS_EINVAL;
 }
 
+// 1 when the forward launch of this shape runs here AND takes a gate (mnas_conv_gemm_gate_ok)
+int mnas_pws_gate_ok(int M, int K, int N) {
+    PwsPlan p;
+    return (mnas_pws_enabled() && pws_plan(0, M, K, N, &p) && p.ksw <= 3) ? 1 : 0;
+}
+
 // called by mnas_conv_gemm for 1x1 convs when mnas_pws_parts(...) > 0
 int mnas_pws_run(const MnasConvGemm* c, void* stream) {
     const int M = c->N * c->Ho * c->Wo;
@@ -286,6 +312,8 @@ int mnas_pws_run(const MnasConvGemm* c, void* stream) {
     a.n_pad16 = (c->Co + 15) / 16 * 16;
     a.act = c->act; a.grad = c->grad; a.w = (const uint16_t*)c->w; a.bias = c->bias; a.resid = c->resid; a.out = c->out;
     a.stats = c->stats; a.red_y = c->mode == 1 ? c->red_y : nullptr; a.red_bn = c->red_bn;
+    a.gate = c->mode == 0 ? c->gate : nullptr; a.hw = c->Ho * c->Wo;
+    if (a.gate && (!c->act.scale || p.ksw > 3)) return MNAS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     return c->mode == 0 ? pws_dispatch<0>(a, p, c->nparts, s) : pws_dispatch<1>(a, p, c->nparts, s);
 }

@@ -148,6 +148,77 @@ __global__ __launch_bounds__(256) void k_se_bwd_apply(const uint4* __restrict__ 
     }
 }
 
+// ---- excitation applied ON LOAD (round 4): the project conv reads relu(bn2(y2)) * sigmoid(u)[n][c] through MnasConvGemm.gate
+// instead of a materialised a2s (k_se_scale's read + write and the project conv's second read of an E-wide tensor go away).
+__global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ u, int NC, float* __restrict__ gate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < NC) gate[i] = se_sigmoid(u[i]);
+}
+extern "C" int mnas_se_gate(const float* u, int N, int C, float* gate, void* stream) {
+    if (!u || !gate || N < 1 || C < 1) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_se_gate, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, u, N * C, gate);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+// Backward of the gated project conv WITHOUT a pass over the E-wide tensors for du.  mnas_pw_bwd ran in segment mode on the
+// UNGATED activation a2 = relu(bn2(y2)), `kseg` workgroups per image: wpartial[n*kseg + j][o][c] = sum over that pixel range of
+// dy3[pix][o] * a2[pix][c].  With gs = dy3 . W3 (the project conv's input gradient, = dL/d(a2*s)):
+//     du_pre[n][c] = sum_pix gs[pix][c] * a2[pix][c] = sum_o W3[o][c] * (sum_j wpartial[n*kseg+j][o][c])
+//     dW3[o][c]    = sum_n s[n][c] * (sum_j wpartial[n*kseg+j][o][c])                      (a2s = a2 * s)
+// k_se_proj_du: one workgroup per image; folds the image's kseg slabs into slab n*kseg scaled by s (what k_se_proj_dw then adds
+// over the images) and writes du = du_pre * s (1 - s).  Both sums run in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void k_se_proj_du(float* __restrict__ wpartial, int kseg, int Co, int Ci, const float* __restrict__ u,
+                                                    const float* __restrict__ W, float* __restrict__ du) {
+    const int n = blockIdx.x;
+    const size_t slab = (size_t)Co * Ci;
+    float* base = wpartial + (size_t)n * kseg * slab;
+    for (int c = threadIdx.x; c < Ci; c += 256) {
+        const float sg = se_sigmoid(u[(size_t)n * Ci + c]);
+        float acc = 0.f;
+        for (int o = 0; o < Co; ++o) {
+            float p = base[(size_t)o * Ci + c];
+            for (int j = 1; j < kseg; ++j) p += base[j * slab + (size_t)o * Ci + c];
+            acc = fmaf(W[(size_t)o * Ci + c], p, acc);
+            base[(size_t)o * Ci + c] = p * sg;
+        }
+        du[(size_t)n * Ci + c] = acc * sg * (1.f - sg);
+    }
+}
+// dW[i] (+)= sum_n wpartial[n*kseg][i]: thread column tx = element, 8 row groups ty combined through LDS in fixed order
+__global__ __launch_bounds__(256) void k_se_proj_dw(const float* __restrict__ wpartial, int N, size_t nstride, int total,
+                                                    float* __restrict__ dW, int accumulate) {
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    float s = 0.f;
+    if (i < total) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int n = ty; n < N; n += 32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += (n + 8 * j < N) ? wpartial[(size_t)(n + 8 * j) * nstride + i] : 0.f;
+        }
+        s = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < total) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += red[j][tx];
+        dW[i] = (accumulate ? dW[i] : 0.f) + s;
+    }
+}
+extern "C" int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, int Ci, const float* u, const float* W, float* dW,
+                                     int accumulate, float* du, void* stream) {
+    if (!wpartial || !u || !W || !dW || !du || N < 1 || kseg < 1 || Co < 1 || Ci < 1) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_se_proj_du, dim3(N), dim3(256), 0, (hipStream_t)stream, wpartial, kseg, Co, Ci, u, W, du);
+    const int total = Co * Ci;
+    hipLaunchKernelGGL(k_se_proj_dw, dim3((total + 31) / 32), dim3(256), 0, (hipStream_t)stream, wpartial,
+                       N, (size_t)kseg * total, total, dW, accumulate);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 // pixel splits per image: enough workgroups to fill the chip (>= ~2048), whole multiples of R pixels each
 static bool se_geom(int N, int HW, int C, SeGeom* g, int* splits) {
     if (N < 1 || HW < 1 || C < 8 || (C & 7) || C > 2048) return false;

@@ -115,10 +115,11 @@ def _trace(root, se_map=None):
 
 class _Act:
     """A (possibly virtual) activation: value = relu(scale*data+shift) if bn is not None else data."""
-    __slots__ = ("data", "bn", "H", "W", "C")
+    __slots__ = ("data", "bn", "H", "W", "C", "gate")
 
-    def __init__(self, data, bn, H, W, C_):
+    def __init__(self, data, bn, H, W, C_, gate=None):
         self.data, self.bn, self.H, self.W, self.C = data, bn, H, W, C_
+        self.gate = gate         # squeeze-excite applied on load: fp32 [N][C] multiplier on top of the virtual activation
 
     def act_ptrs(self):
         if self.bn is None:
@@ -263,7 +264,7 @@ class Program:
                     h = cur
                     for j_, ci_ in enumerate(cis):
                         if j_ == 2 and se is not None:
-                            h = self._se_fwd(se, h, Hc, Wc)
+                            h = self._se_fwd(se, h, Hc, Wc, ci_)
                         h = self._conv_fwd(ci_, h, Hc, Wc)
                 r = self._new((N, Hc, Wc, a_in.C))
                 fwd.add(L.OP_ADD_ACT, [a_in.C, Hc * Wc], [float(N * Hc * Wc)],
@@ -352,9 +353,16 @@ class Program:
                     g = self._block_bwd_irb(ops, start, G, g_red, (not first) or need_dx)
                     g_red = 0
                     continue
-                g2, c2 = self._conv_bwd(ops, rp, G, None, True, g_red, self._target_of(rp[2]))
-                if (start + 2) in self._se_records:
-                    g2, c2 = self._se_bwd(ops, start + 2, g2)             # g2 becomes dL/d(activated depthwise output)
+                se_rec = self._se_records.get(start + 2)
+                if se_rec is not None and se_rec[5]:
+                    # excitation on load: the project conv's backward runs on the UNGATED activation in segment mode; its
+                    # weight-gradient slabs give du and (gated) dW3 without a pass over gs / a2 (csrc/mnas_se.hip)
+                    du = self._conv_bwd_se_proj(ops, rp, G, g_red, se_rec)
+                    g2, c2 = self._se_bwd(ops, start + 2, du[0], du[1])
+                else:
+                    g2, c2 = self._conv_bwd(ops, rp, G, None, True, g_red, self._target_of(rp[2]))
+                    if se_rec is not None:
+                        g2, c2 = self._se_bwd(ops, start + 2, g2)         # g2 becomes dL/d(activated depthwise output)
                 g1, c1 = self._conv_bwd(ops, rd, g2, None, True, c2, self._target_of(rd[2]))
                 need = (not first) or need_dx
                 if need:
@@ -442,8 +450,9 @@ class Program:
             if nparts < 1:
                 raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, ci.cout, ci.k),))
         else:
+            gate = [None, None, a_in.gate.data_ptr()] if a_in.gate is not None else []
             fwd.add(L.OP_CONV_GEMM, [0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.k, ci.stride, ci.pad, nparts], [],
-                    a_in.act_ptrs() + [None, None, None, ci.w_fwd.data_ptr(), bias, None, y.data_ptr(), stats])
+                    a_in.act_ptrs() + [None, None, None, ci.w_fwd.data_ptr(), bias, None, y.data_ptr(), stats] + gate)
         fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, ci.cout, 1 if training else 0], [float(M), bnm.momentum, bnm.eps],
                 [stats, bnm.weight.data_ptr(), bnm.bias.data_ptr(), bnm.running_mean.data_ptr(),
                  bnm.running_var.data_ptr(), bnm.num_batches_tracked.data_ptr(), bn.data_ptr()])
@@ -549,22 +558,53 @@ class Program:
             self._irb_blocks[len(records) - 2] = (gd, nparts)
         return h2
 
-    def _se_fwd(self, se: _SEInfo, h2: _Act, Hi, Wi):
+    def _se_onload_kseg(self, p_ci: _ConvInfo, h2: _Act, Hi, Wi):
+        """Workgroups per image of the project conv's segment-mode backward when the excitation can be applied ON LOAD for this
+        block (Engine.se_on_load): forward = MnasConvGemm.gate, backward = mnas_pw_bwd on the ungated activation with
+        per-image weight-gradient slabs + mnas_se_proj_finalize.  0: keep the materialised a*s (k_se_scale) path."""
+        eng, lib, N = self.eng, self.eng.lib, self.N
+        HW, M, Ci, Co = Hi * Wi, self.N * Hi * Wi, p_ci.cin, p_ci.cout
+        if not eng.se_on_load or h2.bn is None or p_ci.kind != "pw" or not lib.mnas_conv_gemm_gate_ok(N, HW, Ci, Co):
+            return 0
+        if not self.training:
+            return 1
+        if M < eng.pw_fused_min_pixels or not lib.mnas_pw_bwd_supported(Ci, Co):
+            return 0
+        tile, slices = lib.mnas_pw_bwd_tile_pixels(Ci, Co), lib.mnas_pw_bwd_slices(Ci, Co)
+        best = None
+        for d in range(1, 65):
+            if HW % d or N * d > 4096 or N * d * Co * Ci > eng.scratch_wgrad2.numel():
+                continue
+            seg = HW // d
+            waste = _cdiv(seg, tile) * tile / seg            # pixel slots per pixel (ragged last tile of a segment)
+            rounds = N * d * slices / 512.0                  # two resident workgroups per CU
+            cost = waste * _cdiv(N * d * slices, 512) / rounds
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, d)
+        return best[1] if best is not None else 0
+
+    def _se_fwd(self, se: _SEInfo, h2: _Act, Hi, Wi, p_ci: _ConvInfo):
         """squeeze-excite on the activated depthwise output (csrc/mnas_se.hip): pooled mean -> fc1+ReLU -> fc2 -> a2 * sigmoid.
-        Returns the MATERIALISED scaled activation the project conv reads."""
+        Returns what the project conv reads: the MATERIALISED scaled activation, or (Engine.se_on_load, supported shapes) the
+        virtual activation with the excitation as a per-(image, channel) gate applied on load."""
         eng, lib, dev, N, H, W, training = self.eng, self.eng.lib, self.eng.device, self.N, self.H, self.W, self.training
         new, bnbuf, fwd, records = self._new, self._bnbuf, self._fwd, self._records
         E_, R_ = se.channels, se.reduced
         z = new((N, E_), torch.float32)
         hb = new((N, R_), torch.float32)
         u = new((N, E_), torch.float32)
-        a2s = new((N, Hi, Wi, E_))
         m_ = se.mod
         fwd.add(L.OP_POOL_ACT, [N, Hi * Wi, E_], [], h2.act_ptrs() + [z.data_ptr()])
         fwd.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 0], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), hb.data_ptr()])
         fwd.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 0], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), m_.fc2.bias.data_ptr(), u.data_ptr()])
+        kseg = self._se_onload_kseg(p_ci, h2, Hi, Wi)
+        self._se_records[len(records)] = (se, h2, z, hb, u, kseg)  # keyed by the record index of the project conv that follows
+        if kseg:
+            gate = new((N, E_), torch.float32)
+            fwd.add(L.OP_SE_GATE, [N, E_], [], [u.data_ptr(), gate.data_ptr()])
+            return _Act(h2.data, h2.bn, Hi, Wi, E_, gate)
+        a2s = new((N, Hi, Wi, E_))
         fwd.add(L.OP_SE_SCALE, [N, Hi * Wi, E_], [], h2.act_ptrs() + [u.data_ptr(), a2s.data_ptr()])
-        self._se_records[len(records)] = (se, h2, z, hb, u)        # keyed by the record index of the project conv that follows
         return _Act(a2s, None, Hi, Wi, E_)
 
     def _seg(self, stage):
@@ -820,24 +860,57 @@ class Program:
                 return ci.kind == "dw" and ci.k in self.eng.dw_fused_k and rec[2] is not None and rec[2].bn is not None
         return False
 
-    def _se_bwd(self, ops: _OpList, rec_index, gs):
+    def _conv_bwd_se_proj(self, ops: _OpList, rec, g, g_reduced, se_rec):
+        """Backward of the project conv of a squeeze-excite block whose excitation is applied on load.  Returns (gs, du): the
+        input gradient wrt the GATED activation and dL/du (fp32 [N][E])."""
+        eng, lib, N, merge = self.eng, self.eng.lib, self.N, self.eng.merge_post
+        new = self._new
+        _, ci, a_in, out, Hi, Wi = rec
+        se, h2, z, hb, u, kseg = se_rec
+        Co, M, HW = ci.cout, N * Hi * Wi, Hi * Wi
+        gy = [g.data_ptr(), out.data.data_ptr(), out.bn.data_ptr()]
+        if g_reduced:
+            nred, red_buf = g_reduced, eng.scratch_red
+        else:
+            nred = max(1, min(1024, _cdiv(M * Co, 256 * 8 * 8)))
+            red_buf = eng.scratch_stats
+            ops.add(L.OP_BN_BWD_REDUCE, [Co, nred], [float(M)], gy[:2] + [out.bn.data_ptr(), red_buf.data_ptr()])
+        if merge:
+            if self._pend["ops"] is not None and self._pend["ops"] is not ops:
+                self._flush_post()
+            self._emit_post(ops, (red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3), nred, Co, float(M)))
+        else:
+            ops.add(L.OP_BN_BWD_FINALIZE, [nred, Co, 1], [float(M)],
+                    [red_buf.data_ptr(), out.bn.data_ptr(), eng.gptr(ci, 2), eng.gptr(ci, 3)])
+        gs = new((N, Hi, Wi, ci.cin))
+        du = new((N, ci.cin), torch.float32)
+        wsc = self._next_scratch() if merge else eng.scratch_wgrad2
+        ops.add(L.OP_PW_BWD, [M, ci.cin, Co, N * kseg, 0, HW // kseg], [],
+                h2.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), None, gs.data_ptr(), wsc.data_ptr(), None, None, None, None, None, None], 0)
+        ops.add(L.OP_SE_PROJ_FIN, [N, kseg, Co, ci.cin, 1], [],
+                [wsc.data_ptr(), u.data_ptr(), ci.mod.conv.weight.data_ptr(), eng.gptr(ci, 0), du.data_ptr()], 0)
+        return gs, du
+
+    def _se_bwd(self, ops: _OpList, rec_index, gs, du=None):
         """Backward of the squeeze-excite stage: gs = dL/d(a2 * s) from the project conv's input gradient -> dL/d a2, and the
-        SE parameters' gradients (accumulated into the flat buffer; shared blocks sum their applications)."""
+        SE parameters' gradients (accumulated into the flat buffer; shared blocks sum their applications).  du: dL/du when the
+        project conv's backward already produced it (excitation on load), else it is reduced here from (gs, a2)."""
         eng, lib, N, merge, pend, records = self.eng, self.eng.lib, self.N, self.eng.merge_post, self._pend, self._records
         new = self._new
-        se, h2, z, hb, u = self._se_records[rec_index]
+        se, h2, z, hb, u = self._se_records[rec_index][:5]
         E_, R_ = se.channels, se.reduced
         HWl = h2.H * h2.W
         m_ = se.mod
-        du = new((N, E_), torch.float32)
         dh = new((N, R_), torch.float32)
         dzp = new((N, E_), torch.float32)
         ga = new((N, h2.H, h2.W, E_))
-        sb = lib.mnas_se_scratch_bytes(N, HWl, E_)
-        if sb < 0:
-            raise RuntimeError("unsupported squeeze-excite shape %s" % ((N, HWl, E_),))
-        dup = new((sb // 4,), torch.float32)
-        ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr(), dup.data_ptr()], 0)
+        if du is None:
+            du = new((N, E_), torch.float32)
+            sb = lib.mnas_se_scratch_bytes(N, HWl, E_)
+            if sb < 0:
+                raise RuntimeError("unsupported squeeze-excite shape %s" % ((N, HWl, E_),))
+            dup = new((sb // 4,), torch.float32)
+            ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr(), dup.data_ptr()], 0)
         # fc2: dW2 += du^T hb, db2 += sum du ; dh = (du W2) * [hb > 0]
         ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 1, 1], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
                                                             eng.gptr(se, 2), eng.gptr(se, 3)], 0)
@@ -1059,6 +1132,8 @@ class Engine:
         # (dz = g*[s*y+t>0], the mask the fused reduce computes anyway); the depthwise sweep's dy-on-read then skips the mask:
         # 40 of the 5x5 row body's ~530 vector instructions (round 4; results bit-identical)
         self.dw_masked_g = True
+        self.se_on_load = True           # squeeze-excite excitation applied in the project conv's load (forward) / folded into its
+                                         # weight-gradient slabs (backward) where the kernels support the shape; False: k_se_scale
         self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage

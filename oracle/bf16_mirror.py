@@ -80,14 +80,17 @@ def conv_fwd(spec: ConvSpec, a_in, st, train, image=None, dw_staged=False):
     t = (beta - mean * gamma * invstd).float()
     y = round_bf16(y32)
     out = MAct(y, s, t)
-    saved = dict(spec=spec, a=a, w=w, y=y, s=s, t=t, mean=mean.float(), invstd=invstd.float(), M=M,
+    saved = dict(spec=spec, a=a, w=w, w32=W, y=y, s=s, t=t, mean=mean.float(), invstd=invstd.float(), M=M,
                  in_shape=tuple(a.shape), dw_staged=dw_staged)
     return out, saved
 
 
-def conv_bwd(saved, g, grads, resid=None, need_gin=True):
+def conv_bwd(saved, g, grads, resid=None, need_gin=True, se=None):
     """g: bf16-valued grad wrt the activated output.  Accumulates parameter grads into ``grads`` (dict keyed by
-    state_dict names).  Returns bf16-valued grad wrt the activated input (or None)."""
+    state_dict names).  Returns bf16-valued grad wrt the activated input (or None).
+    se (the saved dict of se_fwd, excitation applied ON LOAD: Engine.se_on_load): this is the project conv of a squeeze-excite
+    block -- its weight gradient is formed per image on the UNGATED bf16 activation and gated in fp32, and the same per-image
+    sums give dL/du without a pass over (gs, a2) (csrc/mnas_se.hip k_se_proj_du); stored into se["du"]."""
     spec, a, w, y, s, t = saved["spec"], saved["a"], saved["w"], saved["y"], saved["s"], saved["t"]
     mean, invstd, M = saved["mean"], saved["invstd"], saved["M"]
     v = lambda c: c.view(1, -1, 1, 1)
@@ -111,8 +114,15 @@ def conv_bwd(saved, g, grads, resid=None, need_gin=True):
     acc(p + ".bn.weight", S2.float())
     acc(p + ".bn.bias", S1.float())
     acc(p + ".conv.bias", torch.zeros(spec.cout))
-    acc(p + ".conv.weight", torch.nn.grad.conv2d_weight(a, tuple(w.shape), dy, stride=spec.stride, padding=spec.pad,
-                                                        groups=spec.groups))
+    if se is not None:
+        sg = se["sg"]
+        Pn = torch.einsum("nohw,nchw->noc", dy.double(), round_bf16(se["a"]).double())        # per-image dy^T a2 (fp32 accumulate)
+        acc(p + ".conv.weight", (Pn * sg[:, None, :].double()).sum(0).float().view(tuple(w.shape)))
+        W32 = saved["w32"].double().view(1, w.shape[0], w.shape[1])
+        se["du"] = ((Pn * W32).sum(1) * (sg * (1 - sg)).double()).float()
+    else:
+        acc(p + ".conv.weight", torch.nn.grad.conv2d_weight(a, tuple(w.shape), dy, stride=spec.stride, padding=spec.pad,
+                                                            groups=spec.groups))
     if not need_gin:
         return None
     gin = torch.nn.grad.conv2d_input(saved["in_shape"], w, dy, stride=spec.stride, padding=spec.pad, groups=spec.groups)
@@ -139,7 +149,7 @@ def se_bwd(saved, gs, grads):
     """gs: bf16-valued dL/d(a * s).  Accumulates the SE parameters' gradients; returns bf16-valued dL/da."""
     se, a, z, h, sg, w1, w2 = (saved[k] for k in ("se", "a", "z", "h", "sg", "w1", "w2"))
     HW = a.shape[2] * a.shape[3]
-    du = (gs * a).sum((2, 3)) * sg * (1 - sg)
+    du = saved["du"] if "du" in saved else (gs * a).sum((2, 3)) * sg * (1 - sg)      # "du": excitation on load (conv_bwd above)
     dh = (du @ w2) * (h > 0)
     dz = dh @ w1
     p = se.prefix
@@ -153,9 +163,11 @@ def se_bwd(saved, gs, grads):
     return round_bf16(gs * sg[:, :, None, None] + dz[:, :, None, None] / HW)
 
 
-def run(program, st, x, train=True, cot=None, need_dx=False, irb=False):
+def run(program, st, x, train=True, cot=None, need_dx=False, irb=False, se_on_load=None):
     """program: list of ("conv", spec) / ("block", [e,d,p]) (oracle.build_program or hand-made).
     irb: mirror the engine's fused-block rounding points (Engine.fuse_irb = "full" / "fwd") on the shapes irb_supported() names.
+    se_on_load: None, or a predicate (N, H, W, E) -> bool naming the squeeze-excite blocks whose excitation the engine applies on
+    load (Engine.se_on_load; the forward values are the same, the project conv's backward rounds differently: conv_bwd).
     Returns dict(y=fp32 output, grads={name: tensor}, dx=fp32 or None)."""
     first = program[0][1] if program[0][0] == "conv" else program[0][1][0]
     is_image = first.kind == "dense" and first.cin == 3
@@ -175,6 +187,7 @@ def run(program, st, x, train=True, cot=None, need_dx=False, irb=False):
             for j, spec in enumerate(arg[:3]):
                 if j == 2 and len(arg) == 4:
                     h, sse = se_fwd(arg[3], h, st)
+                    sse["on_load"] = bool(se_on_load and se_on_load(N_, H_, W_, h.data.shape[1]))
                 h, sv = conv_fwd(spec, h, st, train, dw_staged=fused)
                 svs.append(sv)
             svs.append(sse)
@@ -193,7 +206,7 @@ def run(program, st, x, train=True, cot=None, need_dx=False, irb=False):
             g = conv_bwd(sv, g, grads, None, need)
         else:
             G = g
-            g2 = conv_bwd(sv[2], G, grads)
+            g2 = conv_bwd(sv[2], G, grads, se=sv[3] if (sv[3] is not None and sv[3]["on_load"]) else None)
             if sv[3] is not None:
                 g2 = se_bwd(sv[3], g2, grads)
             g1 = conv_bwd(sv[1], g2, grads)

@@ -46,7 +46,7 @@ def pack(w, kind):
 
 
 def conv_gemm(mode, N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, w, bias=None, act=None, grad=None, resid=None,
-              nparts=64, stats=False, red_y=None, red_bn=None):
+              nparts=64, stats=False, red_y=None, red_bn=None, gate=None, expect=0):
     lib = L.load()
     out = torch.empty((N, Ho, Wo, Co), dtype=torch.bfloat16, device="cuda")
     st = torch.full((2, Co, nparts), float("nan"), device="cuda") if stats else None
@@ -60,7 +60,12 @@ def conv_gemm(mode, N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, w, bias=None, act
         a.grad = grad
     a.w, a.bias, a.resid, a.out, a.stats = L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(out), L.ptr(st)
     a.red_y, a.red_bn = L.ptr(red_y), L.ptr(red_bn)
-    L.check(lib.mnas_conv_gemm(C.byref(a), L.cur_stream()), "conv_gemm")
+    a.gate = L.ptr(gate)
+    rc = lib.mnas_conv_gemm(C.byref(a), L.cur_stream())
+    if expect:
+        assert rc == expect, rc
+        return None, None
+    L.check(rc, "conv_gemm")
     return out, st
 
 

@@ -67,11 +67,115 @@ def test_se_kernels(shape, virt):
     assert relerr(st[0], dzr.sum((0, 2, 3))) < 2e-3 and relerr(st[1], (dzr * xh).sum((0, 2, 3))) < 2e-3
 
 
+GATE_SHAPES = [  # (N, H, W, Ci, Co): the project convs of the 112x112 / 56x56 / 28x28 stages (k_igemm and the K-streaming kernel)
+    (3, 112, 112, 48, 16), (5, 56, 56, 72, 24), (9, 28, 28, 240, 40), (2, 16, 9, 48, 16), (70, 28, 28, 240, 40)]
+
+
+@pytest.mark.parametrize("shape", GATE_SHAPES)
+def test_gated_project_forward(shape):
+    """MnasConvGemm.gate (ABI 5): the 1x1 forward on relu(s*y+t) * gate[n][c] applied ON LOAD equals the same launch on the
+    materialised product k_se_scale writes (same fp32 operations before the one bf16 rounding): bit-identical output and
+    statistics; and both match fp32 math."""
+    import torch.nn.functional as F
+    from gpu_util import conv_gemm, pack
+    N, H, W, Ci, Co = shape
+    lib = L.load()
+    assert lib.mnas_conv_gemm_gate_ok(N, H * W, Ci, Co) == 1
+    y = bf16r(O.det_uniform((N, Ci, H, W), 810))
+    s, t = 1 + 0.3 * O.det_uniform((Ci,), 811), 0.2 * O.det_uniform((Ci,), 812)
+    u = 2.0 * O.det_uniform((N, Ci), 813)
+    w = bf16r(O.det_param("g.conv.weight", (Co, Ci, 1, 1), 3))
+    bias = O.det_uniform((Co,), 814) * 0.1
+    yd, sd, td, ud = nhwc(y), s.cuda(), t.cuda(), u.cuda()
+    gate = torch.full((N, Ci), float("nan"), device="cuda")
+    L.check(lib.mnas_se_gate(ud.data_ptr(), N, Ci, gate.data_ptr(), L.cur_stream()), "se_gate")
+    assert relerr(gate.cpu(), torch.sigmoid(u)) < 1e-6
+    a2s = torch.empty((N, H, W, Ci), dtype=torch.bfloat16, device="cuda")
+    ai = act_in(yd, sd, td)
+    L.check(lib.mnas_se_scale(C_.byref(ai), ud.data_ptr(), N, H * W, Ci, a2s.data_ptr(), L.cur_stream()), "se_scale")
+    wp = pack(w, L.PACK_FWD)
+    M = N * H * W
+    nparts = lib.mnas_conv_gemm_parts(0, M, Ci, Co, 1)
+    if nparts < 1:
+        nparts = max(1, min(1024, (M + 127) // 128))
+    out_g, st_g = conv_gemm(0, N, H, W, Ci, H, W, Co, 1, 1, 0, wp, bias=bias.cuda(), act=ai, nparts=nparts, stats=True, gate=gate)
+    out_m, st_m = conv_gemm(0, N, H, W, Ci, H, W, Co, 1, 1, 0, wp, bias=bias.cuda(), act=act_in(a2s), nparts=nparts, stats=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, out_m) and torch.equal(st_g, st_m)
+    a = bf16r(torch.relu(y * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)) * torch.sigmoid(u)[:, :, None, None])
+    ref = F.conv2d(a, w, bias)
+    assert relerr(from_nhwc(out_g), ref) < 6e-3
+    # a gate without the virtual activation, or on a shape without a gated kernel, is refused
+    conv_gemm(0, N, H, W, Ci, H, W, Co, 1, 1, 0, wp, act=act_in(yd), nparts=nparts, gate=gate, expect=10001)
+
+
+@pytest.mark.parametrize("shape,kseg", [((3, 112, 112, 48, 16), 4), ((4, 56, 56, 72, 24), 2), ((6, 28, 28, 240, 40), 1),
+                                        ((5, 56, 56, 72, 24), 7), ((2, 28, 28, 240, 40), 4)])
+def test_se_project_backward_segments(shape, kseg):
+    """mnas_pw_bwd in segment mode (ABI 5: MnasPwBwd.seg_px) on the ungated activation + mnas_se_proj_finalize against fp32 math:
+    gs = dy . W (the same bits as the strided launch), dW = sum_n s[n] * (per-image dy^T a2), du = (sum_pix gs*a2) s (1-s)."""
+    import torch.nn.functional as F
+    from gpu_util import dy_ref, grad_in, pack, rand_bn_coefs
+    N, H, W, Ci, Co = shape
+    lib = L.load()
+    HW, M = H * W, N * H * W
+    assert HW % kseg == 0 and lib.mnas_pw_bwd_supported(Ci, Co) == 1
+    x = bf16r(O.det_uniform((N, Ci, H, W), 820))
+    bx = rand_bn_coefs(Ci, 821, O)
+    a2 = torch.relu(x * bx[0].view(1, -1, 1, 1) + bx[1].view(1, -1, 1, 1))
+    g, y = bf16r(O.det_uniform((N, Co, H, W), 822)), bf16r(O.det_uniform((N, Co, H, W), 823))
+    b = rand_bn_coefs(Co, 824, O)
+    dy = dy_ref(g, y, b)
+    w = O.det_param("p.conv.weight", (Co, Ci, 1, 1), 4)
+    wb = bf16r(w)
+    u = 2.0 * O.det_uniform((N, Ci), 825)
+    sg = torch.sigmoid(u)
+    xd, gd, yd, bd, bxd, ud, wd = nhwc(x), nhwc(g), nhwc(y), b.cuda(), bx.cuda(), u.cuda(), w.cuda().contiguous()
+    wpk = pack(wb, L.PACK_DGRAD)
+
+    def run(seg, nparts):
+        gin = torch.full((N, H, W, Ci), float("nan"), dtype=torch.bfloat16, device="cuda")
+        wpart = torch.full((nparts, Co, Ci), float("nan"), device="cuda")
+        c = L.MnasPwBwd()
+        c.M, c.Ci, c.Co, c.nparts, c.seg_px = M, Ci, Co, nparts, seg
+        c.x, c.dy = act_in(xd, bxd[0], bxd[1]), grad_in(gd, yd, bd)
+        c.w, c.gin, c.wpartial = L.ptr(wpk), L.ptr(gin), L.ptr(wpart)
+        L.check(lib.mnas_pw_bwd(C_.byref(c), L.cur_stream()), "pw_bwd")
+        return gin, wpart
+    gs, wpart = run(HW // kseg, N * kseg)
+    gs0, _ = run(0, max(1, min(64, M // 128)))
+    torch.cuda.synchronize()
+    assert torch.equal(gs, gs0)                                   # the tile walk does not change a tile's arithmetic
+    assert relerr(from_nhwc(gs), F.conv_transpose2d(dy, wb)) < 6e-3
+    # a segment size that does not cover M with exactly nparts workgroups is refused
+    c = L.MnasPwBwd()
+    c.M, c.Ci, c.Co, c.nparts, c.seg_px = M, Ci, Co, N * kseg + 1, HW // kseg
+    c.x, c.dy = act_in(xd, bxd[0], bxd[1]), grad_in(gd, yd, bd)
+    c.w, c.gin, c.wpartial = L.ptr(wpk), L.ptr(gs0), L.ptr(wpart)
+    assert lib.mnas_pw_bwd(C_.byref(c), L.cur_stream()) == 10001
+    dW = torch.full((Co, Ci), float("nan"), device="cuda")
+    du = torch.full((N, Ci), float("nan"), device="cuda")
+    L.check(lib.mnas_se_proj_finalize(wpart.data_ptr(), N, kseg, Co, Ci, ud.data_ptr(), wd.data_ptr(), dW.data_ptr(), 0,
+                                      du.data_ptr(), L.cur_stream()), "se_proj_finalize")
+    a2b = bf16r(a2)                                               # the MFMA operand
+    Pn = torch.einsum("nohw,nchw->noc", dy.double(), a2b.double())
+    assert relerr(dW.cpu(), (Pn * sg[:, None, :].double()).sum(0)) < 2e-3
+    du_ref = (Pn * w.view(1, Co, Ci).double()).sum(1) * (sg * (1 - sg)).double()
+    assert relerr(du.cpu(), du_ref) < 2e-3
+    # ... which is what the pass over (gs, a2) computes, up to gs's bf16 rounding
+    du_pass = (F.conv_transpose2d(dy, wb).double() * a2.double()).sum((2, 3)) * (sg * (1 - sg)).double()
+    assert relerr(du_ref, du_pass) < 5e-3
+
+
 SE_STAGES = {
     # (cin, cout, t, layers, k, reduce, ccf, N, H, W): shared SE block applied `layers` times, then the dense 3x3
     "se_features2_16_24": (16, 24, 3, 3, 5, True, False, 4, 56, 56),
     "se_features6_96_192": (96, 192, 6, 2, 5, True, False, 8, 14, 14),
     "se_features7_192_320": (192, 320, 6, 1, 5, False, False, 16, 7, 7),
+    # large enough (M >= Engine.pw_fused_min_pixels) for the excitation-on-load path: gate in the project conv's load,
+    # segment-mode mnas_pw_bwd + mnas_se_proj_finalize in its backward
+    "se_features2_16_24_n16": (16, 24, 3, 3, 5, True, False, 16, 56, 56),
+    "se_features4_40_80_n64": (40, 80, 6, 3, 5, True, False, 64, 28, 28),
 }
 
 
@@ -114,7 +218,10 @@ def test_se_stage_vs_mirror(name):
     y = m(x)
     cot = C.cotangent(tuple(y.shape))
     (y * cot.cuda()).sum().backward()
-    r = M.run(prog, st, x0, True, cot, need_dx=True)
+    on_load = [bool(r_[5]) for lst in m._engine().programs.values() for prog_ in lst for r_ in prog_._se_records.values()]
+    assert on_load and all(v == on_load[0] for v in on_load)
+    assert on_load[0] == name.endswith(("_n16", "_n64")), "the stage did not take the expected squeeze-excite path"
+    r = M.run(prog, st, x0, True, cot, need_dx=True, se_on_load=(lambda *a: True) if on_load[0] else None)
     ey, edx = rl2(y.detach().cpu(), r["y"]), rl2(x.grad.cpu(), r["dx"])
     worst = 0.0
     layers = SE_STAGES[name][3]
@@ -123,10 +230,41 @@ def test_se_stage_vs_mirror(name):
             continue
         e = rl2(p.grad.cpu(), r["grads"][kk])
         worst = max(worst, e)
-        assert e < (0.1 if kk.endswith("bn.weight") else 5e-2), (kk, e)
+        # the excite MLP's gradients on the large stages: 8e-2.  Measured at se_features2_16_24_n16: 5.6e-2 against the mirror
+        # for BOTH engine paths, which agree with each other to 0.7e-2 (test_se_on_load_matches_materialised) -- dh = (du W2) *
+        # [h > 0] over 16 images x 12 hidden units is a handful of terms, and a hidden unit near zero flips between two fp32
+        # summation orders of the pooled mean
+        tol = 0.1 if kk.endswith("bn.weight") else (8e-2 if (".se.fc" in kk and on_load[0]) else 5e-2)
+        assert e < tol, (kk, e)
     print(name, "SE stage vs mirror: y %.4f dx %.4f worst grad %.4f" % (ey, edx, worst))
     assert ey < 1e-2 and edx < 5e-2
     assert int(m.state_dict()["sequence.0.sequence.1.bn.num_batches_tracked"]) == layers
+
+
+@pytest.mark.parametrize("name", ["se_features2_16_24_n16", "se_features4_40_80_n64"])
+def test_se_on_load_matches_materialised(name):
+    """Engine.se_on_load on/off on the same stage: the forward is bit-identical (the gate is applied before the one bf16 rounding,
+    as k_se_scale does); the gradients differ by where the excitation meets the project conv's weight gradient and du (fp32
+    per-image slabs instead of a bf16 a2*s operand / a pass over the bf16 gs) and by what that perturbation becomes on its way
+    through three applications of the shared block (the stage tests hold either path to its own mirror at 5e-2): the two paths
+    agree within the same bounds."""
+    res = {}
+    for on in (True, False):
+        m, prog, st, shp = _se_stage(name)
+        m._engine().se_on_load = on
+        x = C.det_input(shp).cuda().requires_grad_(True)
+        y = m(x)
+        (y * C.cotangent(tuple(y.shape)).cuda()).sum().backward()
+        res[on] = (y.detach().cpu(), x.grad.cpu(), {k: v.grad.cpu() for k, v in m.named_parameters()})
+        used = [r for lst in m._engine().programs.values() for prog_ in lst for r in prog_._se_records.values()]
+        assert used and all(bool(r[5]) == on for r in used), "the stage did not take the expected squeeze-excite path"
+    assert torch.equal(res[True][0], res[False][0])
+    assert rl2(res[True][1], res[False][1]) < 5e-2
+    for k in res[True][2]:
+        if not k.endswith("conv.bias"):
+            e = rl2(res[True][2][k], res[False][2][k])
+            print(name, k, "on-load vs materialised %.4f" % e)
+            assert e < (0.1 if k.endswith("bn.weight") else 5e-2), k
 
 
 def test_se_variant_network_step_vs_oracle():
