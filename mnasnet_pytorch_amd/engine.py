@@ -752,7 +752,19 @@ class Program:
                     and (lib.mnas_pw_bwd_forms(ci.cin, Co) & 4) and self._feeds_fused_dw(a_in)):
                 masked = 1
                 self._masked_g.add(gin.data_ptr())
-            ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts, masked], [],
+            seg = 0
+            if eng.pw_bwd_segments and M >= 800000 and (lib.mnas_pw_bwd_forms(ci.cin, Co) & 4):
+                # the out-stage (project) convs of the 112x112 / 56x56 stages: contiguous pixel range per workgroup (segment mode of
+                # csrc/mnas_pwbwd.hip) and one resident round of workgroups instead of tiles strided over a 1024-wide grid:
+                # 48 -> 16 at 112x112 200 -> 189 us, 72 -> 24 at 56x56 87 -> 83 us (same call); the expand forms (3-4 resident
+                # workgroups per CU) and 240 -> 40 at 28x28 lose with it (16 -> 48: 155 -> 220 us at 512 segments)
+                tile = lib.mnas_pw_bwd_tile_pixels(ci.cin, Co)
+                nparts = max(1, min(nparts, eng.pw_bwd_segments))
+                seg = _cdiv(_cdiv(M, nparts), tile) * tile
+                nparts = _cdiv(M, seg)
+                if rt is not None:
+                    ncols = nparts
+            ops.add(L.OP_PW_BWD, [M, ci.cin, Co, nparts, masked, seg], [],
                     a_in.act_ptrs() + gyp + [ci.w_dgrad.data_ptr(), resid.data_ptr() if resid is not None else None,
                                              gin.data_ptr(), wsc.data_ptr()] + red + extra, 0)
             if merge:
@@ -1134,6 +1146,8 @@ class Engine:
         self.dw_masked_g = True
         self.se_on_load = True           # squeeze-excite excitation applied in the project conv's load (forward) / folded into its
                                          # weight-gradient slabs (backward) where the kernels support the shape; False: k_se_scale
+        self.pw_bwd_segments = 512       # > 0: the project convs' fused backward at >= 800 k pixels walks contiguous pixel segments,
+                                         # at most this many workgroups (0: tiles strided over the grid everywhere)
         self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
