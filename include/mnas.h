@@ -189,6 +189,11 @@ typedef struct MnasPwBwd {
      * (nparts-1)*seg_px) instead of striding over the tiles of the whole tensor, so that wpartial[b] is the weight-gradient sum
      * over a KNOWN pixel range -- with seg_px dividing H*W, a fraction of one image: what mnas_se_proj_finalize needs. */
     int32_t seg_px;
+    /* ABI 5, out-stage forms (mnas_pw_bwd_forms bit 2) with red_partial: FOUR reduce sums per channel, red_partial
+     * float[4][Ci][nparts] = (sum g*m, sum g*m*xhat, sum m, sum m*xhat), m = [s*x+t > 0] under red_bn -- with segment mode, the
+     * per-image ingredients of the BatchNorm-backward sums of (g*e[n][c] + z[n][c])*m for any per-(image, channel) e, z known
+     * only later (mnas_se_bn_assemble).  gin is stored unmasked; no resid. */
+    int32_t red4, reserved;
 } MnasPwBwd;
 int mnas_pw_bwd(const MnasPwBwd* a, void* stream);
 int mnas_pw_bwd_supported(int Ci, int Co);
@@ -350,6 +355,11 @@ typedef struct MnasDwBwd {
     /* round 4: dy.g already holds dz = g*[s*y+t>0] (written by mnas_pw_bwd with gin_masked): dy-on-read skips the mask.
      * Phase 0 with the fused reduce only; results are bit-identical to the plain form on the unmasked g. */
     int32_t g_masked, reserved;
+    /* ABI 5: dy.g is read as g*g_gate[n][c] + g_bias[n][c] (fp32 [N][C] tables, both or neither) -- the squeeze-excite backward
+     * dL/da2 = gs*sigmoid(u) + dz/HW formed on read instead of materialised by mnas_se_bwd_apply.  Phase 0 with the fused reduce
+     * only, not with g_masked / SRC. */
+    const float* g_gate;
+    const float* g_bias;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
 int mnas_dw_src_rows(int N, int H, int W, int C, int k, int cin, int nparts);
@@ -509,6 +519,13 @@ int mnas_se_bwd_apply_cols(int N, int HW, int C);
  *                           weight gradient dW[o][c] (+)= sum_n s[n][c] * P_n[o][c].  W: the conv's fp32 weight [Co][Ci].
  *                           wpartial is overwritten (scratch).  Deterministic (fixed summation order). */
 int mnas_se_gate(const float* u, int N, int C, float* gate, void* stream);
+/* After mnas_pw_bwd(seg_px = HW/kseg, red4 = 1) of the project conv (part4 = its red_partial, float[4][C][N*kseg]) and the excite
+ * MLP's backward (dz = dL/d(pooled a), fp32 [N][C]): g_bias[n][c] = dz/HW, and red float[2][C][N] = the BatchNorm-backward sums
+ * (sum dz2, sum dz2*xhat) of dz2 = (gs*gate + g_bias)*[a > 0] per image -- what mnas_se_bwd_apply's fused reduce produced from a
+ * pass over (gs, y2), here from the four per-image sums.  mnas_bn_bwd_finalize(red, nparts = N, ...) follows; mnas_dw_bwd reads gs
+ * with g_gate = gate, g_bias. */
+int mnas_se_bn_assemble(const float* part4, int N, int kseg, int C, const float* gate, const float* dz, int HW, float* g_bias,
+                        float* red, void* stream);
 int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, int Ci, const float* u, const float* W, float* dW,
                           int accumulate, float* du, void* stream);
 
@@ -578,6 +595,7 @@ int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 #define MNAS_OP_SE_BWD_APPLY 33
 #define MNAS_OP_SE_GATE 34          /* ABI 5 */
 #define MNAS_OP_SE_PROJ_FIN 35      /* ABI 5 */
+#define MNAS_OP_SE_BN_ASSEMBLE 36   /* ABI 5 */
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

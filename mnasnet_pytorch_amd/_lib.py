@@ -47,7 +47,7 @@ class MnasDwBwd(C.Structure):
                 ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
                 ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p), ("phase", C.c_int32),
                 ("src_cin", C.c_int32), ("src_x", MnasActIn), ("src_w1", c_void_p), ("src_b1", c_void_p), ("src_dy", c_void_p),
-                ("src_w3t", c_void_p), ("g_masked", C.c_int32), ("reserved", C.c_int32)]
+                ("src_w3t", c_void_p), ("g_masked", C.c_int32), ("reserved", C.c_int32), ("g_gate", c_void_p), ("g_bias", c_void_p)]
 
 
 class MnasDwExpFwd(C.Structure):
@@ -61,7 +61,7 @@ class MnasPwBwd(C.Structure):
     _fields_ = [("M", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32), ("nparts", C.c_int32), ("x", MnasActIn),
                 ("dy", MnasGradIn), ("w", c_void_p), ("resid", c_void_p), ("gin", c_void_p), ("wpartial", c_void_p),
                 ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p), ("dy_out", c_void_p), ("w_fwd", c_void_p),
-                ("b_fwd", c_void_p), ("gin_masked", C.c_int32), ("seg_px", C.c_int32)]
+                ("b_fwd", c_void_p), ("gin_masked", C.c_int32), ("seg_px", C.c_int32), ("red4", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasPostWgrad(C.Structure):
@@ -122,7 +122,7 @@ OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP
 OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
 OP_BWD_POST, OP_TCONV_DGRAD, OP_IRB_FWD, OP_IRB_BWD, OP_IRB_W1_FIN = 25, 26, 27, 28, 29
 OP_HEAD_LINEAR, OP_SE_SCALE, OP_SE_BWD_REDUCE, OP_SE_BWD_APPLY = 30, 31, 32, 33
-OP_SE_GATE, OP_SE_PROJ_FIN = 34, 35
+OP_SE_GATE, OP_SE_PROJ_FIN, OP_SE_BN_ASSEMBLE = 34, 35, 36
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 EINVAL = 10001      # MNAS_EINVAL
 
@@ -157,6 +157,7 @@ SYMBOLS = {
     "mnas_se_bwd_apply_cols": (c_int, [c_int, c_int, c_int]),
     "mnas_se_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mnas_se_proj_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "mnas_se_bn_assemble": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mnas_conv_gemm_gate_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),

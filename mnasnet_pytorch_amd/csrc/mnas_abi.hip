@@ -123,7 +123,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.w = p[6]; a.resid = p[7]; a.gin = p[8]; a.wpartial = (float*)p[9];
             a.red_partial = (float*)p[10]; a.red_y = p[11]; a.red_bn = (const float*)p[12];
             a.dy_out = p[13]; a.w_fwd = p[14]; a.b_fwd = (const float*)p[15];
-            a.gin_masked = i[4]; a.seg_px = i[5];
+            a.gin_masked = i[4]; a.seg_px = i[5]; a.red4 = i[6];
             return mnas_pw_bwd(&a, stream);
         }
         case MNAS_OP_GRAM: {
@@ -164,6 +164,8 @@ static int run_one(const MnasOp& o, void* stream) {
                 a.src_w1 = p[0]; a.src_w3t = p[3]; a.x.data = nullptr; a.dy.g = nullptr;
                 a.src_x.data = p[11]; a.src_x.scale = (const float*)p[12]; a.src_x.shift = (const float*)p[13];
                 a.src_dy = p[14]; a.src_b1 = (const float*)p[15];
+            } else {
+                a.g_gate = (const float*)p[11]; a.g_bias = (const float*)p[12];
             }
             return mnas_dw_bwd(&a, stream);
         }
@@ -273,6 +275,9 @@ static int run_one(const MnasOp& o, void* stream) {
         case MNAS_OP_SE_PROJ_FIN:
             return mnas_se_proj_finalize((float*)p[0], i[0], i[1], i[2], i[3], (const float*)p[1], (const float*)p[2], (float*)p[3],
                                          i[4], (float*)p[4], stream);
+        case MNAS_OP_SE_BN_ASSEMBLE:
+            return mnas_se_bn_assemble((const float*)p[0], i[0], i[1], i[2], (const float*)p[1], (const float*)p[2], i[3], (float*)p[3],
+                                       (float*)p[4], stream);
         case MNAS_OP_SE_BWD_APPLY:
             return mnas_se_bwd_apply(p[0], (const float*)p[1], (const float*)p[2], i[0], i[1], i[2], p[3], p[4], (const float*)p[5],
                                      (float*)p[6], stream);

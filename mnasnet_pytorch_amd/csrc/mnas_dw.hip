@@ -232,19 +232,34 @@ __device__ __forceinline__ void dw_fill_edges(const DwArgs& a, const DwDma& p, u
 // GM ("g is masked", round 4): the producer of g -- mnas_pw_bwd's out-stage forms with gin_masked, which compute the mask for
 // their fused reduce anyway -- stored dz = g*[s*y+t>0] instead of g: the window read drops the mask (one packed FMA, two
 // compares, two selects per channel pair and column: 40 of the 5x5 row body's ~530 vector instructions)
-template <int WIN_W, bool GM = false>
+// GA ("g affine", round 4): the stored gradient is read as g*ge + gz with per-(image, channel) ge, gz (the squeeze-excite backward
+// g*sigmoid(u) + dz/HW formed on read instead of materialised by k_se_bwd_apply: csrc/mnas_se.hip)
+template <int WIN_W, bool GM = false, bool GA = false>
 __device__ __forceinline__ void dw_read_dy(const uint32_t* growp, const uint32_t* yrowp, int ps, const f2 (&cf)[5],
-                                           unsigned colmask, f2 (&xr)[WIN_W]) {
+                                           unsigned colmask, f2 (&xr)[WIN_W], f2 ge = {1.f, 1.f}, f2 gz = {0.f, 0.f}) {
 #pragma unroll
     for (int xx = 0; xx < WIN_W; ++xx) {
         const f2 g = f2bf(growp[xx * ps]), y = f2bf(yrowp[xx * ps]);
-        f2 dz = g;
-        if constexpr (!GM) {
+        f2 d;
+        if constexpr (GA) {
+            // ge / gz arrive pre-multiplied by c1 (the caller folds them once per item: one register pair more than the plain form
+            // instead of two -- this kernel sits at 256 VGPRs and every further live value is reloaded from scratch inside the row
+            // loop, each reload draining the ring DMA with it): dy = [s*y+t>0] * (g*c1*e + c1*z) + c2*y + c3
             const f2 z = f2fma(y, cf[0], cf[1]);
-            dz.x = (z.x > 0.f) ? g.x : 0.f;
-            dz.y = (z.y > 0.f) ? g.y : 0.f;
+            const f2 t1 = f2fma(g, ge, gz);
+            f2 dz;
+            dz.x = (z.x > 0.f) ? t1.x : 0.f;
+            dz.y = (z.y > 0.f) ? t1.y : 0.f;
+            d = dz + f2fma(cf[3], y, cf[4]);
+        } else {
+            f2 dz = g;
+            if constexpr (!GM) {
+                const f2 z = f2fma(y, cf[0], cf[1]);
+                dz.x = (z.x > 0.f) ? g.x : 0.f;
+                dz.y = (z.y > 0.f) ? g.y : 0.f;
+            }
+            d = f2fma(cf[2], dz, f2fma(cf[3], y, cf[4]));
         }
-        const f2 d = f2fma(cf[2], dz, f2fma(cf[3], y, cf[4]));
         const bool in = (colmask >> xx) & 1u;
         xr[xx].x = in ? d.x : 0.f;
         xr[xx].y = in ? d.y : 0.f;
@@ -629,11 +644,13 @@ struct DwSrc {
     int Cin, Kpad;
 };
 
-template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false, int NTB = 1, bool GM = false>
+template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false, int NTB = 1, bool GM = false, bool GA = false>
 __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
-    float* __restrict__ red_partial, const float* __restrict__ red_bn, DwSrc e) {
+    float* __restrict__ red_partial, const float* __restrict__ red_bn, DwSrc e, const float* __restrict__ g_gate = nullptr,
+    const float* __restrict__ g_bias = nullptr) {
     static_assert(!SRC || (DG && WG), "the SRC form is the fused sweep");
+    static_assert(!GA || (!SRC && !GM), "g affine: plain fused sweep");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
     constexpr bool NEEDX = WG;                 // x ring only when the weight gradient is computed here
@@ -653,6 +670,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     const int ntb = (cblk + 15) >> 4;                     // MFMA cout tiles of the channel block
     const int ldw = e.Kpad + 8;
     const int cgs = e.Cin >> 3, rcs = a.iw * cgs;         // staging: 16-byte chunks per pixel / per ring row
+    float* lds_ga = (float*)(ring_x + (size_t)(2 * G) * a.rc * 4);            // GA: [2][cblk] (c1*gate, c1*bias) of the current item
     uint16_t* lds_w1 = (uint16_t*)(ring_x + (size_t)(2 * G) * a.rc * 4);      // [ntb*16][ldw]
     uint16_t* lds_w3 = lds_w1 + (size_t)ntb * 16 * ldw;                       // [ntb*16][ldw]
     float* lds_b1 = (float*)(lds_w3 + (size_t)ntb * 16 * ldw);               // [ntb*16]
@@ -816,6 +834,8 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 rmu.x = -red_bn[5 * a.C + ch] * ris.x; rmu.y = -red_bn[5 * a.C + ch + 1] * ris.y;
             }
         }
+        f2 ge = {1.f, 1.f}, gz = zero2;
+
         DwDma plan;
         dw_dma_plan<KS>(a, plan, wave, nwaves, lane, x0, c0);
         const int gx0 = x0 + sxi * DW_BW;
@@ -858,6 +878,21 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             }
         };
         __syncthreads();                             // previous item's last group consumed
+        if constexpr (GA) {
+            // per-item table (c1*gate, c1*bias) of this image's channel block, in LDS: the row loop fetches the pair it needs with
+            // the window reads.  As registers the two pairs pushed this 256-VGPR kernel's spill reloads (scratch = vector memory)
+            // behind the DMA issue of every row group -- a reload waits for everything older, so each group's DMA was drained
+            // before its predecessor was computed: 1.9x slower at 112x112
+            if (sxi == 0) {
+                const size_t o = (size_t)n * a.C + (ch_ok ? ch : 0);
+                const float e0 = g_gate[o], e1 = g_gate[o + 1], z0 = g_bias[o], z1 = g_bias[o + 1];
+                f2 ce, cz;
+                ce.x = ch_ok ? e0 : 1.f; ce.y = ch_ok ? e1 : 1.f;
+                cz.x = ch_ok ? z0 : 0.f; cz.y = ch_ok ? z1 : 0.f;
+                *(f2*)(lds_ga + 2 * cp) = ce * cf[2];
+                *(f2*)(lds_ga + cblk + 2 * cp) = cz * cf[2];
+            }
+        }
 #if MNAS_DW_XFILL
         if (NEEDX) dw_fill_edges<2 * G>(a, plan, ring_x, wave, nwaves, lane, has_coef);   // out-of-image columns of x act to 0
 #endif
@@ -895,7 +930,12 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 f2 xr[WIN_W];
                 if (row_in) {
                     const size_t ro = (size_t)dw_slot<2 * G>(iy) * a.rc * 4 + coloff;
-                    dw_read_dy<WIN_W, GM>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
+                    if constexpr (GA) {
+                        const f2 ge = *(const f2*)(lds_ga + 2 * cp), gz = *(const f2*)(lds_ga + cblk + 2 * cp);
+                        dw_read_dy<WIN_W, GM, GA>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr, ge, gz);
+                    } else {
+                        dw_read_dy<WIN_W, GM, GA>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
+                    }
                 } else {
 #pragma unroll
                     for (int xx = 0; xx < WIN_W; ++xx) xr[xx] = zero2;
@@ -1152,6 +1192,18 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
 #define MNAS_DWB(K_, DG_, WG_, R_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
                                                          c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{})
 #define MNAS_DWB_G(K_, DG_, WG_, R_) do { if (g == 4) MNAS_DWB(K_, DG_, WG_, R_, 4); else MNAS_DWB(K_, DG_, WG_, R_, 2); } while (0)
+    if (c->g_gate) {                         // g read as g*g_gate[n][c] + g_bias[n][c]: fused sweep only
+        if (!(want_dg && want_wg && red) || c->g_masked || !c->g_bias) return MNAS_EINVAL;
+        lds = (size_t)nrings * 2 * g * a.rc * 16 + (size_t)4 * a.cpw * sizeof(float);      // + the per-item (gate, bias) table
+        if (lds < red_need) lds = red_need;
+#define MNAS_DWA(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, false, 1, false, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
+                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{}, c->g_gate, c->g_bias)
+        if (c->k == 3) { if (g == 4) MNAS_DWA(3, 4); else MNAS_DWA(3, 2); }
+        else { if (g == 4) MNAS_DWA(5, 4); else MNAS_DWA(5, 2); }
+#undef MNAS_DWA
+        MNAS_CHECK_LAUNCH();
+        return MNAS_OK;
+    }
     if (c->g_masked) {                       // fused sweep only (what the engine runs behind a project conv's masked gradient)
         if (!(want_dg && want_wg && red)) return MNAS_EINVAL;
 #define MNAS_DWM(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, false, 1, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \

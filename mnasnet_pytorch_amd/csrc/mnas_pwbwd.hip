@@ -48,6 +48,7 @@ struct PwBwdArgs {
     int Kf;                  // FORM 2: Ci rounded up to 32
     int gin_masked;          // out-stage forms: store dz = gin*[s*x+t>0] (the fused reduce's mask) instead of gin
     int seg_px;              // > 0: segment mode (see the tile walk)
+    int red4;                // FORM 3: four reduce sums (see below)
 };
 
 __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
@@ -66,7 +67,11 @@ __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int
 // (partial lines) sustained 2-2.4 TB/s of writes; the same change took the widening forward convs from 2.4 to 4.7 TB/s.
 template <int NTO, int NTI, int PT, bool OS, int FORM>
 __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
-    static_assert(FORM == 0 || (FORM == 1 && OS) || (FORM == 2 && !OS), "NOGIN rides on the out-stage path, RECOMP on the plain epilogue");
+    // FORM 3 ("RED4", out-stage forms): the fused reduce keeps FOUR sums per channel under red_bn -- sum g*m, sum g*m*xhat, sum m,
+    // sum m*xhat with m = [s*x+t > 0] -- red_partial float[4][Ci][P].  With segment mode a workgroup is a fraction of one image, and
+    // the BatchNorm-backward sums of ANY per-(image, channel) affine map of g, (g*e[n][c] + z[n][c])*m, follow from the table
+    // without another pass over (g, x): sum dz = e*R0 + z*R2, sum dz*xhat = e*R1 + z*R3 (csrc/mnas_se.hip k_se_bn_assemble).
+    static_assert(FORM == 0 || (FORM == 1 && OS) || (FORM == 2 && !OS) || (FORM == 3 && OS), "NOGIN / RED4 ride on the out-stage path, RECOMP on the plain epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
     constexpr int COP = NTO * 16, CIP = NTI * 16;
@@ -177,9 +182,11 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     // OS copy-out role: thread -> fixed 16-byte channel column c8 of the out-stage rows orow0 + k*OROWS
     const int oc8 = tid % NCH8, orow0 = tid / NCH8;
     const bool ocol_ok = tid < TCOLS && oc8 * 8 < cis;
-    float r1[8], r2[8];
+    float r1[8], r2[8], r3[FORM == 3 ? 8 : 1], r4[FORM == 3 ? 8 : 1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < (FORM == 3 ? 8 : 1); ++j) { r3[j] = 0.f; r4[j] = 0.f; }
     constexpr bool REGSTAT = NTI <= 6;
     float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
 #pragma unroll
@@ -408,6 +415,14 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                         const mnas_f2 a1 = mnas_ld2(r1 + 2 * j) + dz, a2 = mnas_f2fma(dz, xh, mnas_ld2(r2 + 2 * j));
                         r1[2 * j] = a1.x; r1[2 * j + 1] = a1.y;
                         r2[2 * j] = a2.x; r2[2 * j + 1] = a2.y;
+                        if constexpr (FORM == 3) {
+                            mnas_f2 mk;
+                            mk.x = (z.x > 0.f) ? 1.f : 0.f;
+                            mk.y = (z.y > 0.f) ? 1.f : 0.f;
+                            const mnas_f2 a3 = mnas_ld2(r3 + 2 * j) + mk, a4 = mnas_f2fma(mk, xh, mnas_ld2(r4 + 2 * j));
+                            r3[2 * j] = a3.x; r3[2 * j + 1] = a3.y;
+                            r4[2 * j] = a4.x; r4[2 * j + 1] = a4.y;
+                        }
                     }
                     if (FORM != 1 && a.gin_masked) st_u4(gdst, make_uint4(mz[0], mz[1], mz[2], mz[3]), true);
                 }
@@ -506,6 +521,18 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             for (int th = c >> 3; th < TCOLS; th += NCH8) v += fin[th * 16 + r * 8 + (c & 7)];
             if (c < cis) a.red_partial[((size_t)r * a.Ci + ci0 + c) * gridDim.x + blockIdx.x] = v;   // [2][Ci][P]
         }
+        if constexpr (FORM == 3) {                           // rows 2, 3 of float[4][Ci][P]: second pass through the same scratch
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { fin[tid * 16 + j] = r3[j]; fin[tid * 16 + 8 + j] = r4[j]; }
+            __syncthreads();
+            for (int i = tid; i < 2 * CIP; i += 256) {
+                const int r = i / CIP, c = i % CIP;
+                float v = 0.f;
+                for (int th = c >> 3; th < TCOLS; th += NCH8) v += fin[th * 16 + r * 8 + (c & 7)];
+                if (c < cis) a.red_partial[((size_t)(2 + r) * a.Ci + ci0 + c) * gridDim.x + blockIdx.x] = v;
+            }
+        }
     } else if (do_red) {
         if (REGSTAT) {
 #pragma unroll
@@ -560,6 +587,12 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
             }
         }
         if (nogin) return MNAS_EINVAL;
+        if (a.red4) {
+            if (!a.red_partial || !redx || a.resid || a.gin_masked) return MNAS_EINVAL;
+            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 3>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+            MNAS_CHECK_LAUNCH();
+            return MNAS_OK;
+        }
         if (pw_bwd_outstage() >= (NTI == NTO ? 2 : 1) && !a.resid && redx) {
             hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 0>), dim3(nparts, nslices), dim3(256), lds, stream, a);
             MNAS_CHECK_LAUNCH();
@@ -626,6 +659,8 @@ extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     a.dy_out = c->dy_out; a.w_fwd = (const uint16_t*)c->w_fwd; a.b_fwd = c->b_fwd; a.Kf = (c->Ci + 31) / 32 * 32;
     a.gin_masked = c->gin_masked;
     a.seg_px = c->seg_px;
+    a.red4 = c->red4;
+    if (a.red4 && !(mnas_pw_bwd_forms(c->Ci, c->Co) & 4)) return MNAS_EINVAL;
     if (a.seg_px < 0 || (a.seg_px > 0 && ((int64_t)a.seg_px * c->nparts < c->M || (int64_t)a.seg_px * (c->nparts - 1) >= c->M))) return MNAS_EINVAL;
     if (a.gin_masked && (!c->red_partial || c->resid || c->red_y != c->x.data || !(mnas_pw_bwd_forms(c->Ci, c->Co) & 4))) return MNAS_EINVAL;
     const PwCfg* cfg = pw_cfg(c->Ci, c->Co);

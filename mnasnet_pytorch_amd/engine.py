@@ -326,6 +326,7 @@ class Program:
 
 
         self._masked_g = set()       # data_ptr of gradient tensors stored masked (dz) by their producer
+        self._g_affine = {}          # data_ptr of a gradient tensor -> (gate, bias) fp32 [N][C]: read as g*gate + bias (squeeze-excite)
         g = g_final
         g_red = 0            # number of fused-reduce partial columns already written for the layer g belongs to
         self.patch_x_bwd = None
@@ -357,8 +358,12 @@ class Program:
                 if se_rec is not None and se_rec[5]:
                     # excitation on load: the project conv's backward runs on the UNGATED activation in segment mode; its
                     # weight-gradient slabs give du and (gated) dW3 without a pass over gs / a2 (csrc/mnas_se.hip)
-                    du = self._conv_bwd_se_proj(ops, rp, G, g_red, se_rec)
-                    g2, c2 = self._se_bwd(ops, start + 2, du[0], du[1])
+                    # ... and, with Engine.se_affine_on_read, four per-image reduce sums from which the BatchNorm2-backward sums
+                    # are assembled once the excite MLP's backward is through; the depthwise backward then reads gs*s + dz/HW on
+                    # the fly: no k_se_bwd_apply pass either
+                    r4 = bool(eng.se_affine_on_read and rd[1].kind == "dw" and rd[1].k in eng.dw_fused_k and N <= _STATS_PARTS)
+                    gs_, du_, part4 = self._conv_bwd_se_proj(ops, rp, G, g_red, se_rec, r4)
+                    g2, c2 = self._se_bwd(ops, start + 2, gs_, du_, part4)
                 else:
                     g2, c2 = self._conv_bwd(ops, rp, G, None, True, g_red, self._target_of(rp[2]))
                     if se_rec is not None:
@@ -598,9 +603,9 @@ class Program:
         fwd.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 0], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), hb.data_ptr()])
         fwd.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 0], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), m_.fc2.bias.data_ptr(), u.data_ptr()])
         kseg = self._se_onload_kseg(p_ci, h2, Hi, Wi)
-        self._se_records[len(records)] = (se, h2, z, hb, u, kseg)  # keyed by the record index of the project conv that follows
+        gate = new((N, E_), torch.float32) if kseg else None
+        self._se_records[len(records)] = (se, h2, z, hb, u, kseg, gate)    # keyed by the record index of the project conv that follows
         if kseg:
-            gate = new((N, E_), torch.float32)
             fwd.add(L.OP_SE_GATE, [N, E_], [], [u.data_ptr(), gate.data_ptr()])
             return _Act(h2.data, h2.bn, Hi, Wi, E_, gate)
         a2s = new((N, Hi, Wi, E_))
@@ -714,14 +719,19 @@ class Program:
                 gm = 1 if g.data_ptr() in self._masked_g else 0
                 if gm and rt is None:
                     raise AssertionError("masked gradient handed to a depthwise backward without the fused reduce")
+                aff = self._g_affine.get(g.data_ptr())
+                if aff is not None:
+                    if rt is None or gm:
+                        raise AssertionError("gradient with an on-read affine map needs the plain fused sweep with its reduce")
+                    dwp = dwp + [aff[0].data_ptr(), aff[1].data_ptr()]
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0, 0, gm], [], dwp, 0)
                 if merge:
                     self._queue_wgrad(ops, wsc.data_ptr(), wrows, Co, 1, ci.k * ci.k, True, eng.gptr(ci, 0))
                 else:
                     ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
             else:
-                if g.data_ptr() in self._masked_g:
-                    raise AssertionError("masked gradient handed to the two-launch depthwise backward")
+                if g.data_ptr() in self._masked_g or g.data_ptr() in self._g_affine:
+                    raise AssertionError("masked / on-read-affine gradient handed to the two-launch depthwise backward")
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
                 ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
@@ -872,13 +882,14 @@ class Program:
                 return ci.kind == "dw" and ci.k in self.eng.dw_fused_k and rec[2] is not None and rec[2].bn is not None
         return False
 
-    def _conv_bwd_se_proj(self, ops: _OpList, rec, g, g_reduced, se_rec):
-        """Backward of the project conv of a squeeze-excite block whose excitation is applied on load.  Returns (gs, du): the
-        input gradient wrt the GATED activation and dL/du (fp32 [N][E])."""
+    def _conv_bwd_se_proj(self, ops: _OpList, rec, g, g_reduced, se_rec, red4=False):
+        """Backward of the project conv of a squeeze-excite block whose excitation is applied on load.  Returns (gs, du, part4):
+        the input gradient wrt the GATED activation, dL/du (fp32 [N][E]) and (red4) the table of the four per-image reduce sums
+        float[4][E][N*kseg] (else None)."""
         eng, lib, N, merge = self.eng, self.eng.lib, self.N, self.eng.merge_post
         new = self._new
         _, ci, a_in, out, Hi, Wi = rec
-        se, h2, z, hb, u, kseg = se_rec
+        se, h2, z, hb, u, kseg = se_rec[:6]
         Co, M, HW = ci.cout, N * Hi * Wi, Hi * Wi
         gy = [g.data_ptr(), out.data.data_ptr(), out.bn.data_ptr()]
         if g_reduced:
@@ -897,13 +908,15 @@ class Program:
         gs = new((N, Hi, Wi, ci.cin))
         du = new((N, ci.cin), torch.float32)
         wsc = self._next_scratch() if merge else eng.scratch_wgrad2
-        ops.add(L.OP_PW_BWD, [M, ci.cin, Co, N * kseg, 0, HW // kseg], [],
-                h2.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), None, gs.data_ptr(), wsc.data_ptr(), None, None, None, None, None, None], 0)
+        part4 = new((4 * ci.cin * N * kseg,), torch.float32) if red4 else None
+        red = [part4.data_ptr(), h2.data.data_ptr(), h2.bn.data_ptr()] if red4 else [None, None, None]
+        ops.add(L.OP_PW_BWD, [M, ci.cin, Co, N * kseg, 0, HW // kseg, 1 if red4 else 0], [],
+                h2.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), None, gs.data_ptr(), wsc.data_ptr()] + red + [None, None, None], 0)
         ops.add(L.OP_SE_PROJ_FIN, [N, kseg, Co, ci.cin, 1], [],
                 [wsc.data_ptr(), u.data_ptr(), ci.mod.conv.weight.data_ptr(), eng.gptr(ci, 0), du.data_ptr()], 0)
-        return gs, du
+        return gs, du, part4
 
-    def _se_bwd(self, ops: _OpList, rec_index, gs, du=None):
+    def _se_bwd(self, ops: _OpList, rec_index, gs, du=None, part4=None):
         """Backward of the squeeze-excite stage: gs = dL/d(a2 * s) from the project conv's input gradient -> dL/d a2, and the
         SE parameters' gradients (accumulated into the flat buffer; shared blocks sum their applications).  du: dL/du when the
         project conv's backward already produced it (excitation on load), else it is reduced here from (gs, a2)."""
@@ -915,7 +928,7 @@ class Program:
         m_ = se.mod
         dh = new((N, R_), torch.float32)
         dzp = new((N, E_), torch.float32)
-        ga = new((N, h2.H, h2.W, E_))
+        ga = new((N, h2.H, h2.W, E_)) if part4 is None else None
         if du is None:
             du = new((N, E_), torch.float32)
             sb = lib.mnas_se_scratch_bytes(N, HWl, E_)
@@ -933,6 +946,15 @@ class Program:
                                                             eng.gptr(se, 0), eng.gptr(se, 1)], 0)
         ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 2], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
                                                             None, None, dzp.data_ptr(), None], 0)
+        if part4 is not None:
+            # dL/da2 = gs*s + dz/HW is never materialised: the depthwise backward forms it on read (g_gate, g_bias), and the
+            # BatchNorm2-backward sums of its masked value come from the project conv's four per-image sums
+            kseg, gate = self._se_records[rec_index][5], self._se_records[rec_index][6]
+            zs = new((N, E_), torch.float32)
+            ops.add(L.OP_SE_BN_ASSEMBLE, [N, kseg, E_, HWl], [],
+                    [part4.data_ptr(), gate.data_ptr(), dzp.data_ptr(), zs.data_ptr(), eng.scratch_red.data_ptr()], 0)
+            self._g_affine[gs.data_ptr()] = (gate, zs)
+            return gs, N
         # the BatchNorm2-backward reduce of the depthwise conv rides in the same pass (ga is its g; h2 = its raw output + bnbuf)
         ncols = lib.mnas_se_bwd_apply_cols(N, HWl, E_)
         fused = h2.bn is not None and 0 < ncols <= _STATS_PARTS
@@ -1146,6 +1168,10 @@ class Engine:
         self.dw_masked_g = True
         self.se_on_load = True           # squeeze-excite excitation applied in the project conv's load (forward) / folded into its
                                          # weight-gradient slabs (backward) where the kernels support the shape; False: k_se_scale
+        self.se_affine_on_read = False   # with se_on_load: dL/da2 = gs*s + dz/HW formed on read in the depthwise backward, BatchNorm2
+                                         # sums assembled from per-image partials (no k_se_bwd_apply pass).  Correct and tested, but
+                                         # OFF: the 5x5 fused sweep sits at 256 VGPRs and the two extra per-item pairs move its spill
+                                         # reloads behind the ring DMA of every row group (1.5-1.9x slower: DESIGN.md section 7)
         self.pw_bwd_segments = 512       # > 0: the project convs' fused backward at >= 800 k pixels walks contiguous pixel segments,
                                          # at most this many workgroups (0: tiles strided over the grid everywhere)
         self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch

@@ -160,14 +160,17 @@ def se_bwd(saved, gs, grads):
     acc(p + ".fc2.bias", du.sum(0))
     acc(p + ".fc1.weight", dh.t() @ z)
     acc(p + ".fc1.bias", dh.sum(0))
-    return round_bf16(gs * sg[:, :, None, None] + dz[:, :, None, None] / HW)
+    ga = gs * sg[:, :, None, None] + dz[:, :, None, None] / HW
+    # Engine.se_affine_on_read: the depthwise backward forms this value on read in fp32 (never stored, never rounded)
+    return ga if saved.get("affine") else round_bf16(ga)
 
 
-def run(program, st, x, train=True, cot=None, need_dx=False, irb=False, se_on_load=None):
+def run(program, st, x, train=True, cot=None, need_dx=False, irb=False, se_on_load=None, se_affine=True):
     """program: list of ("conv", spec) / ("block", [e,d,p]) (oracle.build_program or hand-made).
     irb: mirror the engine's fused-block rounding points (Engine.fuse_irb = "full" / "fwd") on the shapes irb_supported() names.
     se_on_load: None, or a predicate (N, H, W, E) -> bool naming the squeeze-excite blocks whose excitation the engine applies on
-    load (Engine.se_on_load; the forward values are the same, the project conv's backward rounds differently: conv_bwd).
+    load (Engine.se_on_load; the forward values are the same, the project conv's backward rounds differently: conv_bwd);
+    se_affine: for those blocks, dL/da2 is formed on read by the depthwise backward (Engine.se_affine_on_read) instead of stored.
     Returns dict(y=fp32 output, grads={name: tensor}, dx=fp32 or None)."""
     first = program[0][1] if program[0][0] == "conv" else program[0][1][0]
     is_image = first.kind == "dense" and first.cin == 3
@@ -188,6 +191,7 @@ def run(program, st, x, train=True, cot=None, need_dx=False, irb=False, se_on_lo
                 if j == 2 and len(arg) == 4:
                     h, sse = se_fwd(arg[3], h, st)
                     sse["on_load"] = bool(se_on_load and se_on_load(N_, H_, W_, h.data.shape[1]))
+                    sse["affine"] = sse["on_load"] and bool(se_affine)
                 h, sv = conv_fwd(spec, h, st, train, dw_staged=fused)
                 svs.append(sv)
             svs.append(sse)
