@@ -55,7 +55,8 @@ typedef struct MnasGradIn {
     const float* coef;    /* float[5][C] */
 } MnasGradIn;
 
-int mnas_version(void);                 /* ABI version: 4 (= the round whose header this is: struct layouts changed in rounds 2, 3 and 4) */
+int mnas_version(void);                 /* ABI version: 5 (struct layouts changed in rounds 2, 3 and twice in round 4: 4 = the tiled-block forms,
+                                         * 5 = squeeze-excite on load: MnasConvGemm.gate, MnasPwBwd.seg_px / red4, MnasDwBwd.g_gate / g_bias) */
 const char* mnas_arch(void);            /* "gfx950" */
 
 /* ---- 1x1 / dense kxk convolution as an implicit GEMM on MFMA (bf16 in, fp32 accumulate) -------------
