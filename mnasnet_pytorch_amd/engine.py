@@ -85,6 +85,23 @@ class _SEInfo:
         self.gslice = {}
 
 
+def se_segments_per_image(N, HW, tile, slices, max_slabs, resident=512):
+    """Workgroups per image (a divisor of HW, so that no segment straddles two images) for the segment-mode backward of a
+    squeeze-excite project conv: the divisor with the least (ragged-last-tile waste) x (idle share of the last round of `resident`
+    workgroups), ties to the smaller one; 0 if no divisor keeps the N*d weight-gradient slabs within `max_slabs` / 4096."""
+    best = None
+    for d in range(1, 65):
+        if HW % d or N * d > 4096 or N * d > max_slabs:
+            continue
+        seg = HW // d
+        waste = _cdiv(seg, tile) * tile / seg            # pixel slots per pixel (ragged last tile of a segment)
+        rounds = N * d * slices / float(resident)        # two resident workgroups per CU
+        cost = waste * _cdiv(N * d * slices, resident) / rounds
+        if best is None or cost < best[0] - 1e-9:
+            best = (cost, d)
+    return best[1] if best is not None else 0
+
+
 def _trace(root, se_map=None):
     """Flatten a module subtree into steps: ("conv", ConvBlock, stage) / ("block", [e,d,p], stage).  se_map (optional dict)
     receives id(expand ConvBlock) -> SqueezeExcite module for blocks that carry one."""
@@ -576,17 +593,7 @@ class Program:
         if M < eng.pw_fused_min_pixels or not lib.mnas_pw_bwd_supported(Ci, Co):
             return 0
         tile, slices = lib.mnas_pw_bwd_tile_pixels(Ci, Co), lib.mnas_pw_bwd_slices(Ci, Co)
-        best = None
-        for d in range(1, 65):
-            if HW % d or N * d > 4096 or N * d * Co * Ci > eng.scratch_wgrad2.numel():
-                continue
-            seg = HW // d
-            waste = _cdiv(seg, tile) * tile / seg            # pixel slots per pixel (ragged last tile of a segment)
-            rounds = N * d * slices / 512.0                  # two resident workgroups per CU
-            cost = waste * _cdiv(N * d * slices, 512) / rounds
-            if best is None or cost < best[0] - 1e-9:
-                best = (cost, d)
-        return best[1] if best is not None else 0
+        return se_segments_per_image(N, HW, tile, slices, eng.scratch_wgrad2.numel() // (Co * Ci))
 
     def _se_fwd(self, se: _SEInfo, h2: _Act, Hi, Wi, p_ci: _ConvInfo):
         """squeeze-excite on the activated depthwise output (csrc/mnas_se.hip): pooled mean -> fc1+ReLU -> fc2 -> a2 * sigmoid.
