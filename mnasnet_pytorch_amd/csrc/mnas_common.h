@@ -152,6 +152,8 @@ int mnas_stem_fwd_band(const MnasStemFwd* c, void* stream);      // csrc/mnas_st
 int mnas_stem_wgrad_band(const MnasStemWgrad* c, void* stream);
 int mnas_dimg_parts(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad);
 int mnas_dimg_run(const MnasConvGemm* c, void* stream);          // csrc/mnas_dimg.hip: dense 3x3 on the small feature maps
+int mnas_c3r_parts(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad);
+int mnas_c3r_run(const MnasConvGemm* c, void* stream);           // csrc/mnas_c3r.hip: weight-heavy dense 3x3 on the 7x7 planes, weights register-resident
 int mnas_pwd_enabled();      // MNAS_PWD (default 1): DMA-pipelined 1x1 input gradient for the few-dy-channel convs
 int mnas_pwd_parts(int M, int Ci, int Co);
 int mnas_pwd_dgrad(const MnasConvGemm* c, void* stream);

@@ -332,6 +332,8 @@ static bool dimg_plan(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, i
 }
 // > 0: this problem runs on k_dimg with that many persistent workgroups along grid.x (the caller passes it as nparts)
 extern "C" int mnas_conv_img_parts(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int k, int stride, int pad) {
+    const int r = mnas_c3r_parts(mode, N, Hi, Wi, Ci, Ho, Wo, Co, k, k, stride, pad);      // (mnas_conv_gemm tries that kernel first)
+    if (r > 0) return r;
     return mnas_dimg_parts(mode, N, Hi, Wi, Ci, Ho, Wo, Co, k, k, stride, pad);
 }
 int mnas_dimg_parts(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad) {

@@ -650,6 +650,10 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (c->mode == 1 && a.is_pw && !c->resid && !c->bias && mnas_pwd_enabled() && mnas_pwd_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwd_dgrad(c, stream);
 
+    // weight-heavy dense 3x3 on the 7x7 planes: weight slices register-resident, images streamed (csrc/mnas_c3r.hip)
+    if (a.taps == 9 && !c->resid && !(c->mode == 1 && c->grad.y) &&
+        mnas_c3r_parts(c->mode, c->N, c->Hi, c->Wi, c->Ci, c->Ho, c->Wo, c->Co, c->kh, c->kw, c->stride, c->pad) > 0)
+        return mnas_c3r_run(c, stream);
     // dense 3x3 on the 14x14 / 7x7 maps: whole image per workgroup (csrc/mnas_dimg.hip); MODE 1 there takes a materialised dy
     if (a.taps == 9 && !(c->mode == 0 && c->resid) && !(c->mode == 1 && (c->grad.y || c->resid)) &&
         mnas_dimg_parts(c->mode, c->N, c->Hi, c->Wi, c->Ci, c->Ho, c->Wo, c->Co, c->kh, c->kw, c->stride, c->pad) > 0)

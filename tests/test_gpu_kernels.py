@@ -91,6 +91,8 @@ DENSE = [  # N,H,W,Ci,Co,stride
     # N >= 32 with an output plane of <= 256 pixels: the whole-image kernel (csrc/mnas_dimg.hip); ragged planes, cout groups
     (32, 14, 14, 80, 96, 1), (33, 14, 14, 96, 192, 2), (32, 7, 7, 192, 320, 1), (40, 9, 11, 24, 40, 2), (32, 16, 16, 16, 24, 1),
     (35, 13, 15, 40, 80, 2),
+    # weight-heavy layer on the 7x7 plane: weight slices register-resident, persistent over images (csrc/mnas_c3r.hip)
+    (67, 7, 7, 192, 320, 1), (33, 7, 6, 192, 328, 1), (41, 14, 14, 96, 192, 2), (32, 13, 11, 104, 200, 2),
 ]
 
 
@@ -172,7 +174,8 @@ def test_dense_dgrad(shape):
     assert relerr(from_nhwc(out), ref) < TOL_BF16
 
 
-@pytest.mark.parametrize("shape", [(32, 14, 14, 80, 96), (32, 7, 7, 192, 320), (36, 9, 11, 24, 40), (32, 16, 16, 16, 24), (2, 14, 14, 80, 96)])
+@pytest.mark.parametrize("shape", [(32, 14, 14, 80, 96), (32, 7, 7, 192, 320), (36, 9, 11, 24, 40), (32, 16, 16, 16, 24), (2, 14, 14, 80, 96),
+                                   (45, 7, 7, 192, 320), (33, 6, 7, 200, 328)])
 @pytest.mark.parametrize("nparts", [5, 32])
 def test_dense_dgrad_plain_dy_with_reduce(shape, nparts):
     """stride-1 3x3 input gradient over a MATERIALISED dy (what the engine hands the dense convs), fused BatchNorm-backward
