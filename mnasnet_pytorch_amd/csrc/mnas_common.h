@@ -162,6 +162,8 @@ int mnas_pws_enabled();
 int mnas_pws_parts(int mode, int M, int K, int N);
 int mnas_pws_run(const MnasConvGemm* c, void* stream);
 int mnas_pws_gate_ok(int M, int K, int N);
+int mnas_pwx_parts(int M, int Ci, int Co);                       // csrc/mnas_pwx.hip: widening 1x1 forward, weight-stationary
+int mnas_pwx_forward(const MnasConvGemm* c, void* stream);
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

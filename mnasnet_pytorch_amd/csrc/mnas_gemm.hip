@@ -589,6 +589,10 @@ extern "C" int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps) {
         const int p = mnas_pws_parts(mode, M, Ci, Co);      // Ci = reduction length of the mode (dy channels for mode 1)
         if (p > 0) return p;
     }
+    if (mode == 0 && taps == 1) {
+        const int p = mnas_pwx_parts(M, Ci, Co);
+        if (p > 0) return p;
+    }
     if (mode == 0 && taps == 1 && mnas_pwf_enabled()) return mnas_pwf_parts(M, Ci, Co);
     if (mode == 1 && taps == 1 && mnas_pwd_enabled()) return mnas_pwd_parts(M, Ci, Co);
     return -1;
@@ -645,6 +649,8 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
         const int rc = mnas_pws_run(c, stream);          // MNAS_EINVAL: not that kernel's case (a materialised dy): fall through
         if (rc != MNAS_EINVAL) return rc;
     }
+    if (c->mode == 0 && a.is_pw && !c->resid && !c->gate && mnas_pwx_parts(a.M, c->Ci, c->Co) > 0)
+        return mnas_pwx_forward(c, stream);
     if (c->mode == 0 && a.is_pw && !c->resid && !c->gate && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwf_forward(c, stream);
     if (c->mode == 1 && a.is_pw && !c->resid && !c->bias && mnas_pwd_enabled() && mnas_pwd_parts(a.M, c->Ci, c->Co) > 0)

@@ -63,6 +63,9 @@ def test_bn_fwd_finalize(C_, nparts, count):
 PW = [  # N,H,W,Ci,Co
     (2, 12, 12, 16, 48), (2, 12, 12, 48, 16), (3, 9, 7, 72, 24), (2, 6, 7, 96, 576), (2, 5, 5, 1152, 192),
     (5, 16, 16, 32, 16), (2, 7, 7, 240, 40), (1, 28, 28, 40, 240), (2, 14, 14, 576, 96), (1, 9, 9, 480, 80), (3, 5, 5, 120, 40),
+    # the widening convs of the <= 28x28 maps: weight-stationary kernel (csrc/mnas_pwx.hip); ragged last pixel group, several
+    # groups per workgroup (nparts 13), cout counts that do and do not fill the waves' tiles
+    (3, 14, 14, 96, 576), (5, 13, 11, 80, 480), (2, 28, 27, 40, 240), (7, 9, 9, 96, 568), (1, 5, 3, 40, 232),
 ]
 
 
