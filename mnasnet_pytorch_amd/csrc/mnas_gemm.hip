@@ -585,12 +585,12 @@ extern "C" int mnas_conv_gemm_tile_pixels(int M, int Co, int K) {
 // Preferred number of pixel-workgroups (nparts) for a launch: > 0 for the kernels that size their own persistent grid
 // (the DMA-pipelined 1x1 forward), -1 = "caller's choice" (k_igemm: whole tiles, see mnas_conv_gemm_tile_pixels).
 extern "C" int mnas_conv_gemm_parts(int mode, int M, int Ci, int Co, int taps) {
-    if (taps == 1) {
-        const int p = mnas_pws_parts(mode, M, Ci, Co);      // Ci = reduction length of the mode (dy channels for mode 1)
-        if (p > 0) return p;
-    }
     if (mode == 0 && taps == 1) {
         const int p = mnas_pwx_parts(M, Ci, Co);
+        if (p > 0) return p;
+    }
+    if (taps == 1) {
+        const int p = mnas_pws_parts(mode, M, Ci, Co);      // Ci = reduction length of the mode (dy channels for mode 1)
         if (p > 0) return p;
     }
     if (mode == 0 && taps == 1 && mnas_pwf_enabled()) return mnas_pwf_parts(M, Ci, Co);
@@ -645,12 +645,12 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
     if (a.taps == 1 && !a.is_pw) return MNAS_EINVAL;   // strided / padded 1x1 does not occur in this network
     if (c->mode == 0 && !c->act.data) return MNAS_EINVAL;
     if (c->mode == 1 && (!c->grad.g || (!c->grad.y) != (!c->grad.coef))) return MNAS_EINVAL;    // (y, coef) both or neither
+    if (c->mode == 0 && a.is_pw && !c->resid && !c->gate && mnas_pwx_parts(a.M, c->Ci, c->Co) > 0)
+        return mnas_pwx_forward(c, stream);
     if (a.is_pw && (c->mode == 1 || !c->resid) && mnas_pws_parts(c->mode, a.M, c->Ci, c->Co) > 0) {
         const int rc = mnas_pws_run(c, stream);          // MNAS_EINVAL: not that kernel's case (a materialised dy): fall through
         if (rc != MNAS_EINVAL) return rc;
     }
-    if (c->mode == 0 && a.is_pw && !c->resid && !c->gate && mnas_pwx_parts(a.M, c->Ci, c->Co) > 0)
-        return mnas_pwx_forward(c, stream);
     if (c->mode == 0 && a.is_pw && !c->resid && !c->gate && mnas_pwf_enabled() && mnas_pwf_parts(a.M, c->Ci, c->Co) > 0)
         return mnas_pwf_forward(c, stream);
     if (c->mode == 1 && a.is_pw && !c->resid && !c->bias && mnas_pwd_enabled() && mnas_pwd_parts(a.M, c->Ci, c->Co) > 0)

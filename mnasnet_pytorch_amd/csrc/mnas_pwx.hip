@@ -41,13 +41,14 @@ __global__ __launch_bounds__(64 * NW) void k_pwx(PwxArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const bool has_coef = a.act.scale != nullptr;
-    const int cw0 = wave * WC;                                     // first cout of this wave
+    const int cb0 = blockIdx.y * NW * WC;                          // first cout of this workgroup's block (grid.y: wide outputs)
+    const int cw0 = cb0 + wave * WC;                               // first cout of this wave
 
     for (int i = tid; i < 2 * a.Kpad; i += NTH) {
         const int r = i / a.Kpad, c = i - r * a.Kpad;
         lds_coef[i] = (has_coef && c < a.Ci) ? (r == 0 ? a.act.scale[c] : a.act.shift[c]) : 0.f;
     }
-    for (int i = tid; i < NW * WC; i += NTH) lds_bias[i] = (a.bias && i < a.Co) ? a.bias[i] : 0.f;
+    for (int i = tid; i < NW * WC; i += NTH) lds_bias[i] = (a.bias && cb0 + i < a.Co) ? a.bias[cb0 + i] : 0.f;
     // ---- this wave's cout tiles, full K: A fragments [cout l15][k = ks*32 + lg*8 ..]
     bf16x8_t wf[TPW][KS];
 #pragma unroll
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(64 * NW) void k_pwx(PwxArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], bf[ks], acc, 0, 0, 0);
             // lane holds couts cw0 + t*16 + lg*4 + {0..3} of pixel m0 + l15
-            const float4 bb = *(const float4*)(lds_bias + cw0 + t * 16 + lg * 4);
+            const float4 bb = *(const float4*)(lds_bias + wave * WC + t * 16 + lg * 4);
             const mnas_f2 a0 = {acc[0] + bb.x, acc[1] + bb.y}, a1 = {acc[2] + bb.z, acc[3] + bb.w};
             if (mok) {
                 mnas_stat2(a0, &s1[t][0], &s2[t][0]);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64 * NW) void k_pwx(PwxArgs a) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-struct PwxPlan { int tpw, ks, nw; size_t lds; };
+struct PwxPlan { int tpw, ks, nw, nblocks; size_t lds; };
 
 int mnas_pwx_enabled() {
     static int on = -1;
@@ -155,15 +156,23 @@ int mnas_pwx_enabled() {
 }
 static bool pwx_plan(int M, int Ci, int Co, PwxPlan* p) {
     if (!mnas_pwx_enabled() || (Ci & 7) || (Co & 7) || Ci < 8 || Co < 8 || M < 1) return false;
-    if (Ci > 96 || Co < 4 * Ci || M > 250000) return false;        // widening convs on the <= 28x28 maps (bs 256)
-    const int tiles = (Co + 15) / 16, ks = (Ci + 31) / 32;
+    // widening convs on the <= 28x28 maps (bs 256).  192 -> 1152 at 7x7 (three cout blocks over grid.y, 6 waves x 4 tiles x 6 k-steps)
+    // was measured too: 32.7 us against 30.4 for the K-streaming kernel (csrc/mnas_pws.hip) -- not instantiated
+    if (Ci > 96 || Co < 4 * Ci || M > 250000) return false;
+    const int ks = (Ci + 31) / 32;
+    int tiles = (Co + 15) / 16;
+    p->nblocks = 1;
+    if (ks > 3) {                                                  // 192 -> 1152: three blocks of 24 cout tiles over grid.y (6 waves x 4 tiles)
+        if (tiles % 24) return false;
+        p->nblocks = tiles / 24; tiles = 24;
+    }
     // waves x tiles-per-wave covering the cout tiles with the least padding; fragments TPW*KS*4 <= 72 VGPRs
     int best = 1 << 30;
     p->nw = 0;
     static const int nws[] = {4, 6, 8};
     for (int nw : nws) {
         const int tpw = (tiles + nw - 1) / nw;
-        if (tpw < 1 || tpw > 6 || tpw * ks > 18) continue;
+        if (tpw < 1 || tpw > 6 || tpw * ks > 24) continue;
         const int waste = nw * tpw - tiles;
         if (waste < best) { best = waste; p->nw = nw; p->tpw = tpw; }
     }
@@ -186,7 +195,9 @@ int mnas_pwx_parts(int M, int Ci, int Co) {
     // (40 -> 240: 52 -> 36 us with 512, 39-47 with 256)
     static int wgs = -1;
     if (wgs < 0) wgs = mnas_diag_env("MNAS_PWX_WGS", 0);
-    const int want = wgs > 0 ? wgs : (p.nw == 6 ? 256 : 512);
+    int want = wgs > 0 ? wgs : (p.nw == 6 ? 256 : 512);
+    want = want / p.nblocks;
+    if (want < 32) want = 32;
     return ngroups < want ? ngroups : want;
 }
 
@@ -202,7 +213,7 @@ int mnas_pwx_forward(const MnasConvGemm* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_PWX(T_, K_, W_) \
     if (p.tpw == T_ && p.ks == K_ && p.nw == W_) { \
-        hipLaunchKernelGGL((k_pwx<T_, K_, W_>), dim3(c->nparts), dim3(64 * W_), p.lds, s, a); \
+        hipLaunchKernelGGL((k_pwx<T_, K_, W_>), dim3(c->nparts, p.nblocks), dim3(64 * W_), p.lds, s, a); \
         MNAS_CHECK_LAUNCH(); \
         return MNAS_OK; \
     }

@@ -65,7 +65,7 @@ PW = [  # N,H,W,Ci,Co
     (5, 16, 16, 32, 16), (2, 7, 7, 240, 40), (1, 28, 28, 40, 240), (2, 14, 14, 576, 96), (1, 9, 9, 480, 80), (3, 5, 5, 120, 40),
     # the widening convs of the <= 28x28 maps: weight-stationary kernel (csrc/mnas_pwx.hip); ragged last pixel group, several
     # groups per workgroup (nparts 13), cout counts that do and do not fill the waves' tiles
-    (3, 14, 14, 96, 576), (5, 13, 11, 80, 480), (2, 28, 27, 40, 240), (7, 9, 9, 96, 568), (1, 5, 3, 40, 232),
+    (3, 14, 14, 96, 576), (5, 13, 11, 80, 480), (2, 28, 27, 40, 240), (7, 9, 9, 96, 568), (1, 5, 3, 40, 232), (9, 7, 7, 192, 1152),
 ]
 
 
