@@ -162,6 +162,9 @@ int mnas_pws_enabled();
 int mnas_pws_parts(int mode, int M, int K, int N);
 int mnas_pws_run(const MnasConvGemm* c, void* stream);
 int mnas_pws_gate_ok(int M, int K, int N);
+int mnas_tcx_ok(int Ho, int Wo, int Co, int Ci);                 // csrc/mnas_tcx.hip: stride-2 3x3 input gradient, weight-stationary
+int mnas_tcx_parts(int N, int Ho, int Wo, int Co, int Ci);
+int mnas_tcx_dgrad(const MnasTconvDgrad* c, void* stream);
 int mnas_pwx_parts(int M, int Ci, int Co);                       // csrc/mnas_pwx.hip: widening 1x1 forward, weight-stationary
 int mnas_pwx_forward(const MnasConvGemm* c, void* stream);
 
