@@ -162,6 +162,8 @@ int mnas_pws_enabled();
 int mnas_pws_parts(int mode, int M, int K, int N);
 int mnas_pws_run(const MnasConvGemm* c, void* stream);
 int mnas_pws_gate_ok(int M, int K, int N);
+int mnas_c3x_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad);
+int mnas_c3x_run(const MnasConvGemm* c, void* stream);           // csrc/mnas_c3x.hip: stride-2 3x3 forward on the large maps, weight-stationary
 int mnas_tcx_ok(int Ho, int Wo, int Co, int Ci);                 // csrc/mnas_tcx.hip: stride-2 3x3 input gradient, weight-stationary
 int mnas_tcx_parts(int N, int Ho, int Wo, int Co, int Ci);
 int mnas_tcx_dgrad(const MnasTconvDgrad* c, void* stream);

@@ -665,6 +665,11 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
         mnas_dimg_parts(c->mode, c->N, c->Hi, c->Wi, c->Ci, c->Ho, c->Wo, c->Co, c->kh, c->kw, c->stride, c->pad) > 0)
         return mnas_dimg_run(c, stream);
 
+    // stride-2 3x3 forward on the large maps: every wave weight-stationary, fragments gathered from global memory (csrc/mnas_c3x.hip)
+    if (c->mode == 0 && a.taps == 9 && !c->resid && !c->gate &&
+        mnas_c3x_ok(c->N, c->Hi, c->Wi, c->Ci, c->Ho, c->Wo, c->Co, c->kh, c->kw, c->stride, c->pad))
+        return mnas_c3x_run(c, stream);
+
     int best_nt, nblocks, pt;
     igemm_tiling(c->Co, a.Kpad, a.M, &best_nt, &nblocks, &pt);
     if (pt == 1 && a.Kpad >= 256 && (best_nt == 2 || best_nt == 3 || best_nt == 6)) a.kch = 128;

@@ -96,6 +96,8 @@ DENSE = [  # N,H,W,Ci,Co,stride
     (35, 13, 15, 40, 80, 2),
     # weight-heavy layer on the 7x7 plane: weight slices register-resident, persistent over images (csrc/mnas_c3r.hip)
     (67, 7, 7, 192, 320, 1), (33, 7, 6, 192, 328, 1), (41, 14, 14, 96, 192, 2), (32, 13, 11, 104, 200, 2),
+    # stride 2 on the large maps (>= 100 k output pixels): every wave weight-stationary, gather from global (csrc/mnas_c3x.hip)
+    (36, 112, 112, 16, 24, 2), (35, 111, 113, 24, 40, 2), (140, 56, 56, 24, 40, 2),
 ]
 
 
