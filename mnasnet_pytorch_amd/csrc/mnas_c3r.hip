@@ -141,6 +141,18 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
         __syncthreads();                                           // image n published; partials of image n-1 consumed
         const int nn = n + gridDim.x;
         if (nn < a.N) fetch(nn);                                   // lands under the MFMA phase
+        // MODE 1: the fused reduce's operand of this thread's epilogue row(s), fetched here: loaded in the epilogue itself its
+        // latency was exposed once per image
+        constexpr int NEP = (PT * 16 + PROWS - 1) / PROWS;
+        uint2 ypre[NEP];
+        if (do_red) {
+#pragma unroll
+            for (int e = 0; e < NEP; ++e) {
+                const int p = prow + e * PROWS;
+                ypre[e] = make_uint2(0, 0);
+                if (p < npix && coe < a.Co) ypre[e] = *(const uint2*)((const uint16_t*)a.red_y + (size_t)n * npix * a.Co + (size_t)p * a.Co + coe);
+            }
+        }
         const uint16_t* im = img + (it & 1) * img_elems;
         f32x4_t acc[PTW][NT];
 #pragma unroll
@@ -181,7 +193,9 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
         __syncthreads();
         // ---- combine + epilogue
         const size_t obase = (size_t)n * npix * a.Co;
-        for (int p = prow; p < PT * 16; p += PROWS) {
+#pragma unroll
+        for (int e = 0; e < NEP; ++e) {
+            const int p = prow + e * PROWS;
             if (p >= npix || coe >= a.Co) continue;
             const float* src = part + (size_t)p * PP + c4 * 4;
             float4 v = *(const float4*)src;
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
                 pk.y = pack_bf16(v.z, v.w);
                 *(uint2*)((uint16_t*)a.out + o) = pk;
                 if (do_red) {
-                    const uint2 yv = *(const uint2*)((const uint16_t*)a.red_y + o);
+                    const uint2 yv = ypre[e];
                     const int cl = c4 * 4;
                     mnas_red2(pk.x, yv.x, mnas_ld2(lds_rc + cl), mnas_ld2(lds_rc + NB + cl), mnas_ld2(lds_rc + 2 * NB + cl),
                               mnas_ld2(lds_rc + 3 * NB + cl), s1, s2);
