@@ -167,6 +167,9 @@ int mnas_c3x_run(const MnasConvGemm* c, void* stream);           // csrc/mnas_c3
 int mnas_tcx_ok(int Ho, int Wo, int Co, int Ci);                 // csrc/mnas_tcx.hip: stride-2 3x3 input gradient, weight-stationary
 int mnas_tcx_parts(int N, int Ho, int Wo, int Co, int Ci);
 int mnas_tcx_dgrad(const MnasTconvDgrad* c, void* stream);
+int mnas_tcr_ok(int Ho, int Wo, int Co, int Ci);
+int mnas_tcr_parts(int N, int Ho, int Wo, int Co, int Ci);
+int mnas_tcr_dgrad(const MnasTconvDgrad* c, void* stream);
 int mnas_pwx_parts(int M, int Ci, int Co);                       // csrc/mnas_pwx.hip: widening 1x1 forward, weight-stationary
 int mnas_pwx_forward(const MnasConvGemm* c, void* stream);
 

@@ -256,13 +256,15 @@ static bool tconv_ok(int Ho, int Wo, int Co, int Ci, int* nt, int* pt, size_t* l
     return false;
 }
 extern "C" int mnas_tconv_supported(int Ho, int Wo, int Co, int Ci) {
-    if (mnas_tcx_ok(Ho, Wo, Co, Ci)) return 1;              // the weight-stationary kernel (csrc/mnas_tcx.hip) takes the shape
+    if (mnas_tcx_ok(Ho, Wo, Co, Ci) || mnas_tcr_ok(Ho, Wo, Co, Ci)) return 1;      // the weight-stationary kernels (csrc/mnas_tcx.hip)
     int nt, pt; size_t lds;
     return tconv_ok(Ho, Wo, Co, Ci, &nt, &pt, &lds, 1 << 20) ? 1 : 0;
 }
 extern "C" int mnas_tconv_parts(int N, int Ho, int Wo, int Co, int Ci) {
     {
-        const int r = mnas_tcx_parts(N, Ho, Wo, Co, Ci);
+        int r = mnas_tcx_parts(N, Ho, Wo, Co, Ci);
+        if (r > 0) return r;
+        r = mnas_tcr_parts(N, Ho, Wo, Co, Ci);
         if (r > 0) return r;
     }
     int nt, pt; size_t lds;
@@ -280,6 +282,7 @@ extern "C" int mnas_tconv_dgrad(const MnasTconvDgrad* c, void* stream) {
     if (!c || !c->dy || !c->w || !c->out || c->nparts < 1) return MNAS_EINVAL;
     if (c->red_y && (!c->red_bn || !c->stats)) return MNAS_EINVAL;
     if (mnas_tcx_ok(c->Ho, c->Wo, c->Co, c->Ci)) return mnas_tcx_dgrad(c, stream);
+    if (mnas_tcr_parts(c->N, c->Ho, c->Wo, c->Co, c->Ci) > 0) return mnas_tcr_dgrad(c, stream);
     int nt, pt; size_t lds;
     const long long M2 = (long long)c->N * c->Ho * c->Wo;
     if (M2 * 4 * c->Ci > 0x7fffffff || !tconv_ok(c->Ho, c->Wo, c->Co, c->Ci, &nt, &pt, &lds, M2)) return MNAS_EINVAL;

@@ -270,3 +270,238 @@ int mnas_tcx_dgrad(const MnasTconvDgrad* c, void* stream) {
 #undef MNAS_TCX
     return MNAS_EINVAL;
 }
+
+// =====================================================================================================================================
+// k_tcr: the same transposed convolution for the WEIGHT-HEAVY transition onto the 7x7 plane (96 -> 192 stride 2: its input gradient
+// reads dy (N,7,7,192) and writes gin (N,14,14,96); the packed weight matrix is 4*96 x 4*192 x 2 B = 590 KB against 19 KB of dy per
+// image).  k_igemm's parity form: 68 us for 14 MB of traffic.  Structure of k_c3r (csrc/mnas_c3r.hip):
+//   * a workgroup (8 waves) owns 16 result channels and walks images persistently; the weight rows of ALL FOUR parity classes for
+//     those channels are register-resident, each class's compact K (its 1/2/2/4 neighbours x Co) split four ways over the waves
+//     (wave w: k-steps (w & 3) + 4j of every class): 14 k-steps = 56 VGPRs for Co = 192;
+//   * the image's dy plane is staged once in LDS with a zero row / column at the bottom / right ([Ho+1][Wo+1][Co+8]); the output
+//     pixels are taken class-major, each class padded to PC = 64 slots, so a 16-pixel tile belongs to one class and needs only that
+//     class's k-steps; the two wave groups (w >> 2) split a class's tiles;
+//   * the four K-partials meet in LDS, 512 threads combine them, store 8 bytes per (pixel, 4 channels) to the class's pixel of the
+//     2x2 block and run the fused BatchNorm-backward reduce (operand prefetched before the MFMA phase).
+// =====================================================================================================================================
+struct TcrArgs {
+    int N, Ho, Wo, Co, Ci;   // dy plane / channels, gin channels
+    int Kpad, rows_pad;
+    int LW, Cp;              // LDS image: (Ho+1) rows x LW = Wo+1 pixels x Cp = Co+8 elements
+    const uint16_t* dy;
+    const uint16_t* w;
+    void* out;
+    float* stats;
+    const void* red_y;
+    const float* red_bn;
+};
+
+// KQ0..KQ3: per-wave k-step counts (upper bounds) of the classes (0,0), (0,1), (1,0), (1,1); PC = 64 pixel slots per class
+template <int KQ0, int KQ1, int KQ3>
+__global__ __launch_bounds__(512) void k_tcr(TcrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NB = 16, PPW = NB + 4, NSLOT = 256, MAXS = 6;
+    constexpr int KQ[4] = {KQ0, KQ1, KQ1, KQ3};
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = wave & 3, phalf = wave >> 2;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int img_elems = ((a.Ho + 1) * a.LW * a.Cp + 7) & ~7;
+    uint16_t* img = (uint16_t*)smem;                               // [img_elems]
+    float* part = (float*)(img + img_elems);                       // [4][NSLOT][PPW]
+    float* lds_rc = part + 4 * NSLOT * PPW;                        // [4][NB]
+    float* lds_fin = part;                                         // end of kernel: [128][2][NB]
+    const int ci0 = blockIdx.y * NB;
+    const bool do_red = a.red_y != nullptr;
+    const int npc = a.Ho * a.Wo;                                   // pixels per class
+
+    for (int i = tid; i < img_elems >> 3; i += 512) ((uint4*)img)[i] = make_uint4(0, 0, 0, 0);           // zero border (and interior)
+    if (do_red)
+        for (int i = tid; i < 4 * NB; i += 512) {
+            const int r = i / NB, cc = ci0 + i % NB;
+            float v = 0.f;
+            if (cc < a.Ci) {
+                if (r == 0) v = a.red_bn[cc];
+                else if (r == 1) v = a.red_bn[a.Ci + cc];
+                else if (r == 2) v = a.red_bn[6 * a.Ci + cc];
+                else v = -a.red_bn[5 * a.Ci + cc] * a.red_bn[6 * a.Ci + cc];
+            }
+            lds_rc[i] = v;
+        }
+    // ---- weight fragments: class c, this wave's k-steps ks = kq + 4j of the class's compact K; LDS offset of the lane's 8 channels
+    bf16x8_t wf0[KQ0], wf1[KQ1], wf2[KQ1], wf3[KQ3];
+    int to0[KQ0], to1[KQ1], to2[KQ1], to3[KQ3];
+    auto load_class = [&](auto& wf, auto& to, int cls, int kqn) {
+        const int ph = cls >> 1, pw = cls & 1;
+        const int kc = (1 + ph) * (1 + pw) * a.Co;
+#pragma unroll
+        for (int j = 0; j < kqn; ++j) {
+            const int k = (kq + 4 * j) * 32 + lg * 8;
+            const bool kok = k < kc;
+            const int slot = kok ? k / a.Co : 0, co = kok ? k - slot * a.Co : 0;
+            int dh = 0, dw = 0;
+            if (ph && pw) { dh = slot >> 1; dw = slot & 1; }
+            else if (ph) dh = slot;
+            else if (pw) dw = slot;
+            to[j] = kok ? (dh * a.LW + dw) * a.Cp + co : -1;
+            const int row = cls * a.Ci + ci0 + l15, col = (dh * 2 + dw) * a.Co + co;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kok && ci0 + l15 < a.Ci && row < a.rows_pad) v = *(const uint4*)(a.w + (size_t)row * a.Kpad + col);
+            wf[j] = *(const bf16x8_t*)&v;
+        }
+    };
+    load_class(wf0, to0, 0, KQ0); load_class(wf1, to1, 1, KQ1); load_class(wf2, to2, 2, KQ1); load_class(wf3, to3, 3, KQ3);
+    // ---- this lane's pixels: tile t (0, 1) of its wave group within a class -> super-pixel p = (phalf*2 + t)*16 + l15
+    int pbase[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int p = (phalf * 2 + t) * 16 + l15;
+        const int pp = p < npc ? p : 0;
+        const int i = pp / a.Wo, j = pp - i * a.Wo;
+        pbase[t] = (i * a.LW + j) * a.Cp;
+    }
+    // ---- epilogue role: thread -> 4 channels c4 of slots srow + 128*e
+    const int c4 = tid & 3, srow = tid >> 2;
+    const int coe = ci0 + c4 * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int co8 = a.Co >> 3, in_slots = npc * co8;
+    uint4 vimg[MAXS];
+    auto fetch = [&](int n) {
+        const uint16_t* src = a.dy + (size_t)n * npc * a.Co;
+#pragma unroll
+        for (int j = 0; j < MAXS; ++j) {
+            const int q = tid + 512 * j;
+            vimg[j] = make_uint4(0, 0, 0, 0);
+            if (q < in_slots) vimg[j] = *(const uint4*)(src + (size_t)q * 8);
+        }
+    };
+    auto place = [&]() {
+#pragma unroll
+        for (int j = 0; j < MAXS; ++j) {
+            const int q = tid + 512 * j;
+            if (q >= in_slots) continue;
+            const int pixq = q / co8, c8 = q - pixq * co8;
+            const int iy = pixq / a.Wo, ix = pixq - iy * a.Wo;
+            *(uint4*)(img + (iy * a.LW + ix) * a.Cp + c8 * 8) = vimg[j];
+        }
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < a.N) { fetch(blockIdx.x); place(); }
+    for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+        __syncthreads();                                           // image n published; partials of image n-1 consumed
+        const int nn = n + gridDim.x;
+        if (nn < a.N) fetch(nn);
+        // epilogue operands (output offset, reduce operand) of this thread's two slots, fetched under the MFMA phase
+        int ooff[2];
+        uint2 ypre[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int slot = srow + 128 * e, cls = slot >> 6, p = slot & 63;
+            ooff[e] = -1; ypre[e] = make_uint2(0, 0);
+            if (p < npc && coe < a.Ci) {
+                const int i = p / a.Wo, j = p - i * a.Wo;
+                ooff[e] = (((n * 2 * a.Ho) + 2 * i + (cls >> 1)) * (2 * a.Wo) + 2 * j + (cls & 1)) * a.Ci + coe;
+                if (do_red) ypre[e] = *(const uint2*)((const uint16_t*)a.red_y + ooff[e]);
+            }
+        }
+        f32x4_t acc[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[c][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        auto run_class = [&](const auto& wf, const auto& to, int cls, int kqn, f32x4_t (&ac)[2]) {
+#pragma unroll
+            for (int j = 0; j < kqn; ++j) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    uint4 bv = make_uint4(0, 0, 0, 0);
+                    if (to[j] >= 0) bv = *(const uint4*)(img + pbase[t] + to[j]);
+                    ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], *(const bf16x8_t*)&bv, ac[t], 0, 0, 0);
+                }
+            }
+        };
+        run_class(wf0, to0, 0, KQ0, acc[0]); run_class(wf1, to1, 1, KQ1, acc[1]);
+        run_class(wf2, to2, 2, KQ1, acc[2]); run_class(wf3, to3, 3, KQ3, acc[3]);
+        // ---- park the K-partials: part[kq][slot = cls*64 + (phalf*2 + t)*16 + l15][channel lg*4 ..]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                *(float4*)(part + ((size_t)kq * NSLOT + c * 64 + (phalf * 2 + t) * 16 + l15) * PPW + lg * 4) = *(const float4*)&acc[c][t];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (ooff[e] < 0) continue;
+            const int slot = srow + 128 * e;
+            const float* src = part + (size_t)slot * PPW + c4 * 4;
+            float4 v = *(const float4*)src;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const float4 x = *(const float4*)(src + (size_t)q * NSLOT * PPW);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            uint2 pk;
+            pk.x = pack_bf16(v.x, v.y);
+            pk.y = pack_bf16(v.z, v.w);
+            *(uint2*)((uint16_t*)a.out + ooff[e]) = pk;
+            if (do_red) {
+                const int cl = c4 * 4;
+                mnas_red2(pk.x, ypre[e].x, mnas_ld2(lds_rc + cl), mnas_ld2(lds_rc + NB + cl), mnas_ld2(lds_rc + 2 * NB + cl),
+                          mnas_ld2(lds_rc + 3 * NB + cl), s1, s2);
+                mnas_red2(pk.y, ypre[e].y, mnas_ld2(lds_rc + cl + 2), mnas_ld2(lds_rc + NB + cl + 2), mnas_ld2(lds_rc + 2 * NB + cl + 2),
+                          mnas_ld2(lds_rc + 3 * NB + cl + 2), s1 + 2, s2 + 2);
+            }
+        }
+        if (nn < a.N) place();                                     // all MFMA reads of the tile finished before the barrier above
+    }
+    if (do_red && a.stats) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lds_fin[(srow * 2 + 0) * NB + c4 * 4 + r] = s1[r];
+            lds_fin[(srow * 2 + 1) * NB + c4 * 4 + r] = s2[r];
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * NB; i += 512) {
+            const int r = i / NB, cl = i - r * NB, cc = ci0 + cl;
+            float v = lds_fin[r * NB + cl];
+            for (int q = 1; q < 128; ++q) v += lds_fin[(q * 2 + r) * NB + cl];
+            if (cc < a.Ci) a.stats[((size_t)r * a.Ci + cc) * gridDim.x + blockIdx.x] = v;
+        }
+    }
+}
+
+static bool tcr_plan(int Ho, int Wo, int Co, int Ci, int* parts_max, size_t* lds) {
+    if (!mnas_tcx_enabled() || (Co & 31) || (Ci & 15) || Ho * Wo > 64 || Ho < 1 || Wo < 1) return false;
+    if (Co != 192) return false;                                   // instantiated for 192 dy channels (k-steps per wave: 2, 3, 3, 6)
+    if ((long long)Co * Ci < 16 * 1024) return false;
+    const size_t img = (((size_t)(Ho + 1) * (Wo + 1) * (Co + 8) + 7) & ~(size_t)7) * 2;
+    *lds = img + (size_t)4 * 256 * 20 * 4 + (size_t)4 * 16 * 4;
+    if ((size_t)Ho * Wo * (Co / 8) > 512 * 6 || *lds > 160 * 1024) return false;
+    const int slices = Ci / 16;
+    *parts_max = 256 / slices < 1 ? 1 : 256 / slices;
+    return true;
+}
+int mnas_tcr_ok(int Ho, int Wo, int Co, int Ci) {
+    int pm; size_t lds;
+    return tcr_plan(Ho, Wo, Co, Ci, &pm, &lds) ? 1 : 0;
+}
+int mnas_tcr_parts(int N, int Ho, int Wo, int Co, int Ci) {
+    int pm; size_t lds;
+    if (N < 32 || !tcr_plan(Ho, Wo, Co, Ci, &pm, &lds)) return -1;
+    return pm < N ? pm : N;
+}
+int mnas_tcr_dgrad(const MnasTconvDgrad* c, void* stream) {
+    int pm; size_t lds;
+    if (c->N < 32 || !tcr_plan(c->Ho, c->Wo, c->Co, c->Ci, &pm, &lds)) return MNAS_EINVAL;
+    if ((long long)c->N * 4 * c->Ho * c->Wo * c->Ci > 0x7fffffff) return MNAS_EINVAL;
+    TcrArgs a;
+    a.N = c->N; a.Ho = c->Ho; a.Wo = c->Wo; a.Co = c->Co; a.Ci = c->Ci;
+    a.Kpad = (4 * c->Co + 31) / 32 * 32; a.rows_pad = (4 * c->Ci + 15) / 16 * 16;
+    a.LW = c->Wo + 1; a.Cp = c->Co + 8;
+    a.dy = (const uint16_t*)c->dy; a.w = (const uint16_t*)c->w; a.out = c->out; a.stats = c->stats;
+    a.red_y = c->red_y; a.red_bn = c->red_bn;
+    hipLaunchKernelGGL((k_tcr<2, 3, 6>), dim3(c->nparts, c->Ci / 16), dim3(512), lds, (hipStream_t)stream, a);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}

@@ -807,7 +807,11 @@ class Program:
                 tconv = (eng.use_tconv and ci.kind == "dense" and getattr(ci, "w_tconv", None) is not None and gyd is not gy and resid is None
                          and Hi == 2 * Ho and Wi == 2 * Wo and lib.mnas_tconv_supported(Ho, Wo, Co, ci.cin))
                 if tconv:
-                    nparts = lib.mnas_tconv_parts(N, Ho, Wo, Co, ci.cin)
+                    tp = lib.mnas_tconv_parts(N, Ho, Wo, Co, ci.cin)       # (-1: a form that needs a larger batch)
+                    tconv = tp > 0
+                    nparts = tp if tconv else nparts
+                if tconv:
+                    pass
                 elif ci.kind == "dense" and gyd is not gy and resid is None:
                     ip = lib.mnas_conv_img_parts(1, N, Ho, Wo, Co, Hi, Wi, ci.cin, ci.k, ci.stride, ci.pad)
                     nparts = ip if ip > 0 else nparts

@@ -128,6 +128,8 @@ TCONV = [  # N,Ho,Wo,Co,Ci  (forward conv: Ci -> Co, 3x3 stride 2 pad 1, input p
     (2, 6, 6, 24, 16), (3, 5, 7, 32, 16), (2, 28, 28, 24, 16), (1, 56, 56, 24, 16), (5, 9, 4, 16, 8), (2, 7, 9, 24, 24),
     # the 112x112 / 56x56 stage transitions on the weight-stationary kernel (csrc/mnas_tcx.hip: 1 / 2 channel tiles per class)
     (2, 28, 28, 40, 24), (7, 5, 9, 40, 24), (3, 6, 5, 32, 32), (1, 3, 2, 8, 8),
+    # 96 -> 192 onto the 7x7 plane: K-split register-resident weights over an LDS image of dy (k_tcr), N >= 32
+    (33, 7, 7, 192, 96), (40, 7, 6, 192, 112), (70, 5, 8, 192, 96),
 ]
 
 
