@@ -1222,8 +1222,10 @@ class Engine:
                 ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
                 ci.w_dgrad = torch.empty(nbytes(L.PACK_DGRAD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
                 ci.w_tconv = None
+                # (the transposed-conv kernels are picked per dy plane size: pack the weights if any of the planes this network
+                # can see has one; the program builder asks again with the real plane)
                 if ci.kind == "dense" and ci.stride == 2 and self.use_tconv and self.materialize_dy and \
-                        self.lib.mnas_tconv_supported(8, 8, ci.cout, ci.cin):
+                        any(self.lib.mnas_tconv_supported(h, h, ci.cout, ci.cin) for h in (7, 8, 14, 28, 56)):
                     ci.w_tconv = torch.empty(nbytes(L.PACK_TCONV, ci.cout, ci.cin, 3, 3), dtype=torch.uint8, device=device)
                 K = ci.k * ci.k * ci.cin
                 slabs = self.lib.mnas_conv_wgrad_slabs(ci.cout, ci.cin, ci.k * ci.k)
