@@ -46,6 +46,9 @@ def parse():
                                                      "(the SE block of that config has no counterpart in the reference: not built)")
     ap.add_argument("--se", action="store_true", help="BASELINE config 4 in full: 5x5 depthwise convs AND a squeeze-excite block "
                                                      "(se_ratio 0.25, build-defined: the reference has none) in every MBConv_block")
+    ap.add_argument("--ccf", action="store_true", help="the reference's DEFAULT topology Mnasnet(cut_channels_first=True) (mnasnet.py:176: stride-2 conv "
+                                                      "first, blocks at the OUT width, 2.80 M parameters) instead of the one train.py "
+                                                      "trains (classifiers.py:13: cut_channels_first=False); a variant line, never the headline")
     ap.add_argument("--clusters", action="store_true",
                     help="BASELINE config 5: rectangular-crop resolution clusters (384x512 / 512x512 / 512x384, datasets.py:331-335), "
                          "ONE cluster per step drawn by DistributedClusterSampler (cluster_random_sampler.py:31-55 made rank-aware), "
@@ -55,6 +58,7 @@ def parse():
                                                       "double-buffered upload on a copy stream under the previous step, as fp32 "
                                                       "(what train.py:427 uploads) and as uint8 with the normalisation fused into the stem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration probes (copy GB/s, packed-FMA TFLOP/s, clocks)")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed window until this much timed work exists; "
@@ -199,6 +203,130 @@ def pmc_mfma_busy(kernel_class):
         return d["classes"][kernel_class]["mfma_busy_frac"], "profiles/" + os.path.basename(files[-1])
     except (KeyError, ValueError, OSError):
         return None, None
+
+
+# ---- box calibration ------------------------------------------------------------------------------------------------------
+# Boxes of this pool differ by up to 12 % in step rate at the same commit (round 4: builder 10.57 ms, driver 11.68 ms), and the
+# per-class pattern (pure streaming kernels unchanged, instruction-heavy ones 12-18 % slower) says shader clock / power state.
+# The "box" object records what THIS GPU sustains right before and right after the timed windows -- a float4 copy (HBM side)
+# and a pure v_pk_fma_f32 loop (shader-clock side), csrc/mnas_probe.hip -- plus what sysfs / rocm-smi say about clocks and
+# the power cap, so that two bench lines can be compared through their box ratios.
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _sysfs_dir(dev):
+    """/sys/bus/pci/devices/<bdf> of the torch device (None if it cannot be resolved: containers may hide sysfs)."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        d = "/sys/bus/pci/devices/" + bdf
+        if os.path.isdir(d):
+            return d
+    except Exception:
+        pass
+    cards = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if os.path.exists(c + "/pp_dpm_sclk")]
+    return cards[0] if len(cards) == 1 else None
+
+
+def sysfs_clocks(d):
+    """Current sclk / mclk level (the starred line of pp_dpm_*), hwmon power and cap -- read while a probe kernel runs."""
+    import glob
+    if not d:
+        return None
+    out = {}
+    for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk")):
+        txt = _read(os.path.join(d, fn))
+        if txt:
+            cur = [ln for ln in txt.splitlines() if ln.rstrip().endswith("*")]
+            out[key] = (cur[0] if cur else txt.splitlines()[-1]).split(":", 1)[-1].replace("*", "").strip()
+            out[key + "_levels"] = len(txt.splitlines())
+    for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+        for key, fn, scale in (("power_w", "power1_average", 1e-6), ("power_input_w", "power1_input", 1e-6),
+                               ("power_cap_w", "power1_cap", 1e-6), ("power_cap_max_w", "power1_cap_max", 1e-6),
+                               ("sclk_mhz_hwmon", "freq1_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+            v = _read(os.path.join(hw, fn))
+            if v and v.lstrip("-").isdigit():
+                out[key] = round(int(v) * scale, 1)
+    v = _read(os.path.join(d, "power_dpm_force_performance_level"))
+    if v:
+        out["perf_level"] = v
+    return out or None
+
+
+def smi_snapshot():
+    """rocm-smi / amd-smi clocks and power as a CHILD process.  Called only BEFORE this process touches the GPU (a process that
+    has initialised HIP must not fork+exec on this pool); None if neither tool is present or it does not answer in time."""
+    import shutil
+    import subprocess
+    for tool, argv in (("rocm-smi", ["--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"]),
+                       ("amd-smi", ["metric", "--clock", "--power", "--json"])):
+        exe = shutil.which(tool) or ("/opt/rocm/bin/" + tool if os.path.exists("/opt/rocm/bin/" + tool) else None)
+        if not exe:
+            continue
+        try:
+            r = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=30)
+            txt = r.stdout.strip()
+            try:
+                return {"tool": tool, "data": json.loads(txt[txt.index("{"):]) if "{" in txt else txt[:2000]}
+            except ValueError:
+                return {"tool": tool, "data": txt[:2000]}
+        except Exception as e:      # noqa: BLE001 -- measurement garnish, never fatal
+            return {"tool": tool, "error": repr(e)[:200]}
+    return None
+
+
+class BoxProbe:
+    """copy GB/s and packed-FMA TFLOP/s of this GPU (csrc/mnas_probe.hip through the C ABI), HIP-event timed on torch's current
+    stream; sysfs clocks are read from the host WHILE a long packed-FMA launch is running (idle clocks say nothing)."""
+    COPY_BYTES = 1 << 30
+    VALU_BLOCKS, VALU_ITERS = 2048, 20000          # ~2 ms at 2.4 GHz: 8 waves per SIMD, 8 independent chains each
+
+    def __init__(self, lib, dev):
+        self.lib, self.dev = lib, dev
+        self.src = torch.empty(self.COPY_BYTES // 4, dtype=torch.float32, device=dev).fill_(1.0)
+        self.dst = torch.empty_like(self.src)
+        self.out = torch.zeros(self.VALU_BLOCKS * 256, dtype=torch.float32, device=dev)
+        self.sysfs = _sysfs_dir(dev)
+
+    def _time(self, fn, reps):
+        best = None
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        return best
+
+    def measure(self):
+        from mnasnet_pytorch_amd._lib import check, cur_stream
+        lib = self.lib
+        copy = lambda: check(lib.mnas_probe_copy(self.src.data_ptr(), self.dst.data_ptr(), self.COPY_BYTES, cur_stream()), "probe_copy")
+        valu = lambda it=self.VALU_ITERS: check(lib.mnas_probe_valu(self.out.data_ptr(), self.VALU_BLOCKS, it, cur_stream()), "probe_valu")
+        copy(); valu()
+        torch.cuda.synchronize()
+        cms = self._time(copy, 5)
+        vms = self._time(valu, 5)
+        flop = self.VALU_BLOCKS * 256.0 * self.VALU_ITERS * 8 * 4
+        res = {"copy_GBps": round(2 * self.COPY_BYTES / cms / 1e6, 1), "valu_pk_fma_TFLOPps": round(flop / vms / 1e9, 2),
+               "valu_clock_GHz": round(flop / vms / 1e9 / 65.536, 3)}
+        if self.sysfs:
+            valu(self.VALU_ITERS * 25)              # ~50 ms of pure vector load: sample the clocks from the host meanwhile
+            time.sleep(0.02)
+            res["under_valu_load"] = sysfs_clocks(self.sysfs)
+            torch.cuda.synchronize()
+        return res
+
+    def free(self):
+        del self.src, self.dst, self.out
 
 
 def cpu_model():
@@ -440,6 +568,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    smi = smi_snapshot() if (rank == 0 and not args.no_box) else None     # child process: BEFORE anything touches the GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -455,7 +584,10 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         base = load_model("mnasnet")
-    if args.se:
+    if args.ccf:
+        from mnasnet_pytorch_amd import Mnasnet
+        base = Mnasnet(cut_channels_first=True)
+    elif args.se:
         from mnasnet_pytorch_amd import Mnasnet
         base = Mnasnet(False, kernel_size=5, se_ratio=0.25)
     elif args.k5:
@@ -520,6 +652,10 @@ def main():
     # ---- timed region: windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced with
     # MAX over ranks; windows are repeated until >= --min-seconds of timed work exist (a 20-step window is 0.2 s: too short for
     # an external GPU-busy sampler to see) and the MEDIAN window is reported
+    box, probe = None, None
+    if rank == 0 and not args.no_box:
+        probe = BoxProbe(L.load(), dev)
+        box = {"before": probe.measure()}
     windows, host_dts = [], []
     while True:
         barrier()
@@ -538,6 +674,16 @@ def main():
         host_dts.append(host_dt)
         if sum(windows) >= args.min_seconds or len(windows) >= 200:     # same decision on every rank (dt is the all-reduced MAX)
             break
+    if probe is not None:
+        box["after"] = probe.measure()
+        probe.free()
+        pr = torch.cuda.get_device_properties(dev)
+        box.update({"device": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count,
+                    "hbm_GiB": round(pr.total_memory / 2 ** 30, 1), "torch_clock_rate_khz": getattr(pr, "clock_rate", None),
+                    "smi_before_gpu_init": smi,
+                    "note": "copy_GBps = 2 x 1 GiB / float4-copy time; valu_pk_fma_TFLOPps = pure v_pk_fma_f32 loop, "
+                            "valu_clock_GHz = that / 65.536 flop per clock (256 CUs x 4 SIMDs x 16 lanes x 2 x 2); best of 5, HIP "
+                            "events, taken right before and right after the timed windows (csrc/mnas_probe.hip)"})
     order = sorted(range(len(windows)), key=lambda i: windows[i])
     mid = order[(len(order) - 1) // 2]
     dt, host_dt = windows[mid], host_dts[mid]
@@ -557,8 +703,8 @@ def main():
         "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in windows[:16]],
         "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic", "overrides": overrides,
-        "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=False)+head '512', 1000 classes%s) fwd+bwd+Adam, "
-                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (", all depthwise convs 5x5 + squeeze-excite (build-defined)" if args.se else (", all depthwise convs 5x5" if args.k5 else ""), B, Hh, Ww),
+        "config": {"workload": "MNASNet-1.0 (Mnasnet(cut_channels_first=%s)+head '512', 1000 classes%s) fwd+bwd+Adam, "
+                               "bs=%d/GPU, %dx%d, per-rank BatchNorm" % (bool(args.ccf), ", all depthwise convs 5x5 + squeeze-excite (build-defined)" if args.se else (", all depthwise convs 5x5" if args.k5 else ""), B, Hh, Ww),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss": round(lossv, 4)},
     }
     # ---- roofline of the dominant kernel class: events recorded inside the timed region (last timed step) -----------
@@ -608,6 +754,8 @@ def main():
             for key, ints, msv, nb_ in calib["detail"]:
                 sys.stderr.write("%-18s %-48s %8.1f us %8.1f GB/s\n" % (key, ",".join(map(str, ints)), msv * 1e3,
                                                                       nb_ / max(msv, 1e-9) / 1e6))
+    if box is not None:
+        res["box"] = box
     if args.h2d and world == 1:
         res["pcie_inclusive"] = h2d_mode(trainer, model, x, target, args.steps, dev)
     if world == 1 and not args.no_cpu_baseline:

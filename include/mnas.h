@@ -629,6 +629,14 @@ int mnas_event_destroy(void* event);
 int mnas_event_record(void* event, void* stream);
 int mnas_event_elapsed_ms(void* start, void* stop, float* ms);   /* non-zero if either is not complete */
 
+/* ---- box calibration (measurement only, csrc/mnas_probe.hip): what THIS GPU sustains, taken by bench.py right before and after
+ * its timed windows -- boxes of one pool differ in shader clock / power state, and a step rate means nothing without them.
+ * mnas_probe_copy: dst = src as 16-byte-per-lane loads and stores (bytes % 16 == 0); rate = 2*bytes / time.
+ * mnas_probe_valu: blocks x 256 threads, iters x 8 independent v_pk_fma_f32 per lane, nothing else:
+ *                  flop = blocks*256*iters*8*4;  TFLOP/s / 65.536 = sustained shader clock in GHz (256 CUs x 4 SIMDs x 16 lanes). */
+int mnas_probe_copy(const void* src, void* dst, int64_t bytes, void* stream);
+int mnas_probe_valu(float* out, int blocks, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

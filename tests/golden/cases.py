@@ -37,6 +37,14 @@ STAGES = {
     "stage_16_24_ccfT": (16, 24, 3, 3, 3, True, True, 2, 16, 16),
     "stage_16_24_ccfF": (16, 24, 3, 3, 3, True, False, 2, 16, 16),
 }
+# name: (cin, cout, k, reduce, repeat, N, H, W)   -- SepConv (mnasnet.py:64-103) as its own parity row.
+# repeat = r puts the SAME (depthwise, pointwise) pair r times in front of the final pair (list-multiply, mnasnet.py:76-85):
+# repeat >= 2 is the case in which weights, BatchNorm parameters and running statistics are shared between applications.
+SEPCONVS = {
+    "sep_32_16": (32, 16, 3, False, 0, 2, 12, 12),           # the network's own SepConv (mnasnet.py:180)
+    "sep_16_16_rep1": (16, 16, 3, False, 1, 2, 12, 12),
+    "sep_24_32_rep2_k5": (24, 32, 5, False, 2, 2, 10, 12),
+}
 # name: (ccf, N, H, W, train, proj_gamma)   -- SURVEY 8(c)(4); proj_gamma: see oracle.init_state
 NETS = {
     "net_ccfT_64_train": (True, 2, 64, 64, True, 1.0),
@@ -50,6 +58,44 @@ NETS = {
     "net_ccfT_224_eval": (True, 1, 224, 224, False, 1.0),    # BASELINE.json configs[0]
     "net_ccfF_224_eval": (False, 1, 224, 224, False, 1.0),
 }
+
+
+def sepconv_specs(name, prefix="sep"):
+    """(program, unique specs) of one stand-alone SepConv: module index j of `sequence` -> ConvSpec with prefix
+    '<prefix>.sequence.<j>'; the repeated pair is ONE spec pair applied `repeat` times (aliases = its other module indices)."""
+    cin, cout, k, reduce, repeat, N, H, W = SEPCONVS[name]
+    stride = 2 if reduce else 1
+    prog, uniq = [], []
+    if repeat > 0:
+        dwa = O.ConvSpec("%s.sequence.0" % prefix, cin, cin, k, stride, k // 2, cin)
+        pwa = O.ConvSpec("%s.sequence.1" % prefix, cin, cin, 1, 1, 0, 1)
+        uniq += [dwa, pwa]
+        for r in range(repeat):
+            if r > 0:
+                dwa.aliases.append("%s.sequence.%d" % (prefix, 2 * r))
+                pwa.aliases.append("%s.sequence.%d" % (prefix, 2 * r + 1))
+            prog += [("conv", dwa), ("conv", pwa)]
+    dwb = O.ConvSpec("%s.sequence.%d" % (prefix, 2 * repeat), cin, cin, k, stride, k // 2, cin)
+    pwb = O.ConvSpec("%s.sequence.%d" % (prefix, 2 * repeat + 1), cin, cout, 1, 1, 0, 1)
+    uniq += [dwb, pwb]
+    prog += [("conv", dwb), ("conv", pwb)]
+    return prog, uniq
+
+
+def sepconv_state(name, uniq, prefix="sep"):
+    """Closed-form state of a stand-alone SepConv keyed like the generator's load_det: '<name>.sequence.<j>.<suffix>' of the
+    FIRST alias."""
+    import torch
+    st = {}
+    for s_ in uniq:
+        tail = s_.prefix[len(prefix) + 1:]
+        for suf, shp in (("conv.weight", s_.weight_shape()), ("conv.bias", (s_.cout,)), ("bn.weight", (s_.cout,)),
+                         ("bn.bias", (s_.cout,)), ("bn.running_mean", (s_.cout,)), ("bn.running_var", (s_.cout,))):
+            st[s_.prefix + "." + suf] = O.det_param("%s.%s.%s" % (name, tail, suf), shp, STATE_SEED)
+        st[s_.prefix + ".bn.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    return st
+
+
 HEADS = ("256", "512_256", "320", "512")
 STATE_SEED = 1
 INPUT_SEED = 7

@@ -110,6 +110,28 @@ def gen_stages():
     np.savez_compressed(os.path.join(HERE, "stages.npz"), **out)
 
 
+def gen_sepconvs():
+    """SepConv (mnasnet.py:64-103) on its own: the network's instance, and repeat = 1 / 2 (the list-multiplied pair)."""
+    out = {}
+    for name, (cin, cout, k, reduce, repeat, N, H, W) in C.SEPCONVS.items():
+        for train in (True, False):
+            m = R.SepConv(cin, cout, kernel_size=k, reduce=reduce, repeat=repeat)
+            load_det(m, name)
+            m.train(train)
+            x = C.det_input((N, cin, H, W)).requires_grad_(True)
+            y = m(x)
+            (y * C.cotangent(tuple(y.shape))).sum().backward()
+            tag = name + ("/train" if train else "/eval")
+            out[tag + "/y"] = npy(y)
+            out[tag + "/dx"] = npy(x.grad)
+            for kk, gv in grads_of(m).items():      # named_parameters dedups the shared pair -> first alias only
+                out[tag + "/d_" + kk] = gv
+            for kk, v in m.state_dict().items():
+                if "running" in kk or "tracked" in kk:
+                    out[tag + "/" + kk] = npy(v)
+    np.savez_compressed(os.path.join(HERE, "sepconvs.npz"), **out)
+
+
 def gen_nets():
     out = {}
     for name, (ccf, N, H, W, train, pg) in C.NETS.items():
@@ -197,6 +219,7 @@ if __name__ == "__main__":
     gen_primitives()
     gen_blocks()
     gen_stages()
+    gen_sepconvs()
     gen_nets()
     gen_heads()
     for f in sorted(os.listdir(HERE)):

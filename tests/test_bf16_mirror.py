@@ -57,6 +57,29 @@ def test_block(name):
             assert rl2(r["grads"]["blk.sequence.%d.%s" % (j, suf)], g["%s/d_sequence.%d.%s" % (name, j, suf)]) < 0.2
 
 
+@pytest.mark.parametrize("name", sorted(C.SEPCONVS))
+def test_sepconv(name):
+    g = load("sepconvs")
+    cin, cout, k, reduce, repeat, N, H, W = C.SEPCONVS[name]
+    prog, uniq = C.sepconv_specs(name)
+    x = C.det_input((N, cin, H, W))
+    for train in (True, False):
+        st = C.sepconv_state(name, uniq)
+        tag = name + ("/train" if train else "/eval")
+        yshape = tuple(g[tag + "/y"].shape)
+        r = M.run(prog, st, x, train=train, cot=C.cotangent(yshape) if train else None, need_dx=True)
+        assert rl2(r["y"], g[tag + "/y"]) < 3e-2
+        if not train:
+            continue
+        assert rl2(r["dx"], g[tag + "/dx"]) < 0.2
+        for s_ in uniq:
+            tail = s_.prefix[len("sep."):]
+            for suf in ("conv.weight", "bn.weight", "bn.bias"):
+                assert rl2(r["grads"][s_.prefix + "." + suf], g["%s/d_%s.%s" % (tag, tail, suf)]) < 0.2, (s_.prefix, suf)
+            assert rl2(st[s_.prefix + ".bn.running_mean"], g["%s/%s.bn.running_mean" % (tag, tail)]) < 2e-2
+            assert rl2(st[s_.prefix + ".bn.running_var"], g["%s/%s.bn.running_var" % (tag, tail)]) < 2e-2
+
+
 @pytest.mark.parametrize("name", ["net_ccfF_b8_96_wc_train", "net_ccfT_b8_96_wc_train"])
 def test_net_forward_and_grad_norms(name):
     g = load("nets")

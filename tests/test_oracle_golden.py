@@ -104,6 +104,37 @@ def test_block(name):
             close(st["blk.sequence.%d.%s" % (j, suf)].detach(), g["%s/sequence.%d.%s" % (name, j, suf)])
 
 
+@pytest.mark.parametrize("name", sorted(C.SEPCONVS))
+@pytest.mark.parametrize("train", [True, False])
+def test_sepconv(name, train):
+    """SepConv (mnasnet.py:64-103) on its own, incl. the list-multiplied pair (repeat >= 1): shared weights accumulate the
+    gradients of their applications, shared BatchNorm buffers are updated once per application."""
+    g = load("sepconvs")
+    cin, cout, k, reduce, repeat, N, H, W = C.SEPCONVS[name]
+    prog, uniq = C.sepconv_specs(name)
+    st = C.sepconv_state(name, uniq)
+    req_grad(st)
+    x = C.det_input((N, cin, H, W)).requires_grad_(True)
+    h = x
+    for _, spec in prog:
+        h = O.convblock(h, st, spec, train)
+    (h * C.cotangent(tuple(h.shape))).sum().backward()
+    tag = name + ("/train" if train else "/eval")
+    close(h.detach(), g[tag + "/y"])
+    close(x.grad, g[tag + "/dx"])
+    for s_ in uniq:
+        tail = s_.prefix[len("sep."):]
+        for suf in ("conv.weight", "bn.weight", "bn.bias"):
+            close(st[s_.prefix + "." + suf].grad, g["%s/d_%s.%s" % (tag, tail, suf)])
+        for al in s_.aliases:                      # every alias of a shared ConvBlock shows the same buffers
+            t2 = al[len("sep."):]
+            close(st[s_.prefix + ".bn.running_mean"].detach(), g["%s/%s.bn.running_mean" % (tag, t2)])
+            close(st[s_.prefix + ".bn.running_var"].detach(), g["%s/%s.bn.running_var" % (tag, t2)])
+            assert int(st[s_.prefix + ".bn.num_batches_tracked"]) == int(g["%s/%s.bn.num_batches_tracked" % (tag, t2)])
+    if train and repeat >= 2:
+        assert int(st["sep.sequence.0.bn.num_batches_tracked"]) == repeat
+
+
 def stage_forward(name, x, train=True):
     """Restates MBConv (mnasnet.py:139-173) for one stand-alone stage with the oracle's primitives."""
     cin, cout, t, layers, k, reduce, ccf, N, H, W = C.STAGES[name]
