@@ -91,12 +91,10 @@ def class_key(opc, ints, L):
     """Kernel-class name of one launch record (opcode + its integer fields)."""
     names = {L.OP_CONV_GEMM: "k_igemm", L.OP_CONV_WGRAD: "k_wgrad", L.OP_DW_FWD: "k_dw_conv<fwd>", L.OP_DW_BWD: "k_dw_bwd",
              L.OP_BN_BWD_REDUCE: "k_bn_bwd_reduce", L.OP_STEM_FWD: "k_igemm<stem>", L.OP_STEM_WGRAD: "k_wgrad<stem>",
-             L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd", L.OP_GRAM: "k_gram", L.OP_DW_EXP_FWD: "k_dw_fwd_exp",
+             L.OP_ADD_ACT: "k_add_act", L.OP_PW_BWD: "k_pw_bwd",
              L.OP_POOL_ACT: "k_pool", L.OP_POOL_BWD: "k_pool", L.OP_DY_MAT: "k_dy_mat",
-             L.OP_TCONV_DGRAD: "k_igemm<dgrad>", L.OP_IRB_FWD: "k_irb_fwd", L.OP_SE_SCALE: "k_se", L.OP_SE_BWD_REDUCE: "k_se",
+             L.OP_TCONV_DGRAD: "k_igemm<dgrad>", L.OP_SE_SCALE: "k_se", L.OP_SE_BWD_REDUCE: "k_se",
              L.OP_SE_BWD_APPLY: "k_se"}
-    if opc == L.OP_IRB_BWD:         # i: N,H,W,C,E,k,nparts,which
-        return ("k_irb_bwd_proj", "k_irb_bwd_dw", "k_irb_bwd_exp")[ints[7]]
     if opc == L.OP_CONV_GEMM:
         return "k_igemm<dgrad>" if ints[0] == 1 else "k_igemm<fwd>"
     if opc == L.OP_DW_BWD:          # i: N,H,W,C,k,nparts,phase (1 = input gradient, 2 = weight gradient launch)
@@ -133,26 +131,7 @@ def launch_work(opc, ints, L):
         N_, Ho, Wo, Co, Ci = ints[:5]
         nbytes = 2 * (2 * N_ * Ho * Wo * Co + N_ * 4 * Ho * Wo * Ci)
         flops = 2.0 * N_ * Ho * Wo * Co * Ci * 9
-    elif opc == L.OP_DW_EXP_FWD:    # i: N,H,W,C,k,Cin: the expand ConvBlock (in + out once) AND the depthwise ConvBlock (in + out once)
-        N_, H_, W_, C_, k_, Ci = ints[:6]
-        px = N_ * H_ * W_
-        nbytes = 2 * (px * Ci + px * C_) + 2 * 2 * px * C_
-        flops = 2.0 * px * C_ * Ci + 2.0 * px * C_ * k_ * k_
-    elif opc == L.OP_IRB_FWD:       # fused expand + depthwise forward of a block: both ConvBlocks' tensors once (SURVEY 8(d) accounting)
-        N_, H_, W_, C_, E_, k_ = ints[:6]
-        px = N_ * H_ * W_
-        nbytes = 2 * (px * C_ + px * E_) + 2 * 2 * px * E_
-        flops = 2.0 * px * E_ * C_ + 2.0 * px * E_ * k_ * k_
-    elif opc == L.OP_IRB_BWD:       # the three backward launches of a fused block: the unfused accounting of what each replaces
-        N_, H_, W_, C_, E_, k_ = ints[:6]
-        px = N_ * H_ * W_
-        if ints[7] == 0:            # project conv backward (k_pw_bwd accounting: g, y of C; x and gin of E), dgrad + wgrad flops
-            nbytes, flops = 2 * px * (2 * C_ + 2 * E_), 2 * 2.0 * px * C_ * E_
-        elif ints[7] == 1:          # depthwise backward (fused accounting: 4 tensors of E) + the recomputed 1x1 GEMMs (y1, da2, P)
-            nbytes, flops = 2 * 4 * px * E_, 4.0 * px * E_ * k_ * k_ + 3 * 2.0 * px * C_ * E_
-        else:                       # expand conv input gradient (reads g, y of E; writes C) -- y1 recomputed: 2 GEMMs
-            nbytes, flops = 2 * (2 * px * E_ + px * C_), 2 * 2.0 * px * C_ * E_
-    elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT, L.OP_GRAM, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_SE_SCALE,
+    elif opc in (L.OP_BN_BWD_REDUCE, L.OP_ADD_ACT, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_SE_SCALE,
                  L.OP_SE_BWD_REDUCE, L.OP_SE_BWD_APPLY):
         nbytes, flops = 0, 0.0      # pure overhead in SURVEY 8(d)'s accounting
     else:                           # stem fwd / wgrad: fp32 image + bf16 output
@@ -516,19 +495,13 @@ OVERRIDES = [
      lambda e: [setattr(e, n, int(v)) for n, v in zip(("pw_bwd_parts_large", "pw_bwd_parts_mid", "pw_bwd_parts_small"),
                                                       os.environ["MNAS_PWB"].split(","))]),
     ("MNAS_NO_DYMAT", "dense 3x3 backward forms dy on load", lambda e: setattr(e, "materialize_dy", False)),
-    ("MNAS_IRB", "fused-block mode on the 14x14 / 7x7 stages: full | fwd | off",
-     lambda e: setattr(e, "fuse_irb", {"full": "full", "fwd": "fwd", "off": False}[os.environ["MNAS_IRB"]])),
-    ("MNAS_IRB_WGS", "workgroups per fused-block launch", lambda e: setattr(e, "irb_workgroups", _ov_int("MNAS_IRB_WGS"))),
     ("MNAS_WGRAD_WGS", "workgroups per k_wgrad launch", lambda e: setattr(e, "wgrad_wgs", _ov_int("MNAS_WGRAD_WGS"))),
     ("MNAS_NO_RECOMP", "expand convs' fused backward reads the stored y1 instead of recomputing it", lambda e: setattr(e, "pw_recompute_y", False)),
     ("MNAS_NO_MASKED_G", "project convs store the unmasked input gradient, the depthwise backward derives the ReLU mask per window column",
      lambda e: setattr(e, "dw_masked_g", False)),
-    ("MNAS_FUSE", "fused expand + depthwise forward kernels that also store y1 (measured slower)",
-     lambda e: setattr(e, "fuse_expand", True)),
     ("MNAS_DW5_SPLIT", "two-launch backward for the 5x5 depthwise layers", lambda e: setattr(e, "dw_fused_k", (3,))),
     ("MNAS_NO_SE_ONLOAD", "squeeze-excite through the materialised a*s tensor (k_se_scale) instead of on load", lambda e: setattr(e, "se_on_load", not _ov_int("MNAS_NO_SE_ONLOAD"))),
     ("MNAS_PWB_SEGMENTS", "fused 1x1 backward over contiguous pixel segments with at most this many workgroups", lambda e: setattr(e, "pw_bwd_segments", _ov_int("MNAS_PWB_SEGMENTS"))),
-    ("MNAS_SE_AFFINE", "squeeze-excite backward: dL/da2 formed on read in the depthwise backward instead of k_se_bwd_apply (opt-in, slower)", lambda e: setattr(e, "se_affine_on_read", bool(_ov_int("MNAS_SE_AFFINE")))),
     ("MNAS_DWB_PARTS", "upper bound on the persistent workgroups of a depthwise backward launch", lambda e: setattr(e, "dw_bwd_parts", _ov_int("MNAS_DWB_PARTS"))),
     ("MNAS_LIB_PATH", "alternative build of libmnas_hip.so (tools/build_alt.sh)", lambda e: None),
 ]
@@ -604,8 +577,8 @@ def main():
     overrides = apply_overrides(eng)          # diagnosis switches (environment); every honoured one is echoed in the JSON line
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
-               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_GRAM, L.OP_DW_EXP_FWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD,
-               L.OP_IRB_FWD, L.OP_IRB_BWD, L.OP_SE_SCALE, L.OP_SE_BWD_REDUCE, L.OP_SE_BWD_APPLY}
+               L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD,
+               L.OP_SE_SCALE, L.OP_SE_BWD_REDUCE, L.OP_SE_BWD_APPLY}
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B, S = args.batch, args.size

@@ -55,8 +55,10 @@ typedef struct MnasGradIn {
     const float* coef;    /* float[5][C] */
 } MnasGradIn;
 
-int mnas_version(void);                 /* ABI version: 5 (struct layouts changed in rounds 2, 3 and twice in round 4: 4 = the tiled-block forms,
-                                         * 5 = squeeze-excite on load: MnasConvGemm.gate, MnasPwBwd.seg_px / red4, MnasDwBwd.g_gate / g_bias) */
+int mnas_version(void);                 /* ABI version: 6 (struct layouts changed in rounds 2, 3, twice in round 4 -- 4 = the tiled-block forms,
+                                         * 5 = squeeze-excite on load: MnasConvGemm.gate, MnasPwBwd.seg_px -- and in round 5: 6 = the opt-in
+                                         * forms that lost their A/B are gone (MnasPwBwd.dy_out / red4, MnasDwBwd.src_* / g_gate / g_bias,
+                                         * mnas_dw_exp_*, mnas_irb_*, mnas_gram*, mnas_se_bn_assemble); their opcode numbers stay retired) */
 const char* mnas_arch(void);            /* "gfx950" */
 
 /* ---- 1x1 / dense kxk convolution as an implicit GEMM on MFMA (bf16 in, fp32 accumulate) -------------
@@ -171,15 +173,9 @@ typedef struct MnasPwBwd {
     float* red_partial;
     const void*  red_y;
     const float* red_bn;
-    /* round 4: the forms the spatially tiled fused inverted-residual block uses (mnasnet.py:105-137 with the expanded tensors
-     * y1 / g2 kept off HBM).  All three default to NULL = the plain form above.
-     *   gin == NULL ("NOGIN", the PROJECT conv's backward): the input gradient g2 = dy . W is formed on the matrix cores only
-     *       to be reduced into red_partial (required then) -- it is never written.  dy_out (optional) receives the staged
-     *       dy tile, bf16 (M,Co): the project conv's dy, materialised for mnas_dw_bwd's SRC form.
-     *   dy.y == NULL && w_fwd != NULL ("RECOMP", the EXPAND conv's backward): the raw forward output y of dy-on-load is not
-     *       read but recomputed per tile as bf16(W act(x) + b_fwd) from the staged x tile -- bit-identical to what
-     *       mnas_conv_gemm(mode 0) stored (same MFMA, same k order).  w_fwd: MNAS_PACK_FWD [Co_pad16][Ci_pad32]; Ci <= 32. */
-    void*  dy_out;
+    /* round 4, "RECOMP" (the EXPAND conv's backward; mnas_pw_bwd_forms bit 1): dy.y == NULL && w_fwd != NULL -- the raw forward
+     * output y of dy-on-load is not read but recomputed per tile as bf16(W act(x) + b_fwd) from the staged x tile, bit-identical
+     * to what mnas_conv_gemm(mode 0) stored (same MFMA, same k order).  w_fwd: MNAS_PACK_FWD [Co_pad16][Ci_pad32]; Ci <= 32. */
     const void*  w_fwd;
     const float* b_fwd;
     /* round 4: store gin MASKED, dz = gin*[s*x+t>0] under red_bn (the mask its fused reduce computes anyway), for a consumer
@@ -190,11 +186,6 @@ typedef struct MnasPwBwd {
      * (nparts-1)*seg_px) instead of striding over the tiles of the whole tensor, so that wpartial[b] is the weight-gradient sum
      * over a KNOWN pixel range -- with seg_px dividing H*W, a fraction of one image: what mnas_se_proj_finalize needs. */
     int32_t seg_px;
-    /* ABI 5, out-stage forms (mnas_pw_bwd_forms bit 2) with red_partial: FOUR reduce sums per channel, red_partial
-     * float[4][Ci][nparts] = (sum g*m, sum g*m*xhat, sum m, sum m*xhat), m = [s*x+t > 0] under red_bn -- with segment mode, the
-     * per-image ingredients of the BatchNorm-backward sums of (g*e[n][c] + z[n][c])*m for any per-(image, channel) e, z known
-     * only later (mnas_se_bn_assemble).  gin is stored unmasked; no resid. */
-    int32_t red4, reserved;
 } MnasPwBwd;
 int mnas_pw_bwd(const MnasPwBwd* a, void* stream);
 int mnas_pw_bwd_supported(int Ci, int Co);
@@ -202,7 +193,7 @@ int mnas_pw_bwd_supported(int Ci, int Co);
  * wastes ceil(seg_px / tile) * tile - seg_px pixel slots per workgroup, a caller picks seg_px with that in view. */
 int mnas_pw_bwd_tile_pixels(int Ci, int Co);
 int mnas_pw_bwd_slices(int Ci, int Co);
-int mnas_pw_bwd_forms(int Ci, int Co);      /* bit 0: NOGIN available for this channel pair, bit 1: RECOMP, bit 2: gin_masked */
+int mnas_pw_bwd_forms(int Ci, int Co);      /* bit 1: RECOMP available for this channel pair, bit 2: out-stage form (gin_masked) */
 
 /* ---- depthwise kxk (k in {3,5}, stride 1, pad k/2), LDS-tiled direct conv on the vector ALU ----------
  * Replaces ATen conv2d fwd/bwd for ConvBlock's groups==C convs (mnasnet.py:122-125, 76-81). */
@@ -226,103 +217,6 @@ int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
 int mnas_dw_geometry(int N, int H, int W, int C, int k, int which, int* out);
 int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which);
 
-/* ---- fused expand (1x1, Cin -> C) + depthwise forward: the first two ConvBlocks of MBConv_block (mnasnet.py:116-125) in
- * one kernel; the t-times expanded tensor is computed into the LDS row rings on the matrix cores and is only written to HBM
- * when y1 != NULL.  The expand conv's BatchNorm (scale, shift) must be known BEFORE the launch: mnas_gram +
- * mnas_gram_bn_finalize derive them from the covariance of the block input (y = W a + b is linear in a = act(x)).
- * Supported: Cin <= 96, C/2-channel-pair blocks of at most 128 channels; otherwise MNAS_EINVAL (use mnas_conv_gemm +
- * mnas_dw_fwd).  stats: float[2][C][rows], rows = mnas_dw_exp_rows(N,H,W,C,k,Cin,nparts). */
-typedef struct MnasDwExpFwd {
-    int32_t N, H, W, C, k;   /* C = expanded channels (depthwise width) */
-    int32_t Cin, nparts, reserved;
-    MnasActIn x;             /* block input (N,H,W,Cin), act-on-load */
-    const void*  w1;         /* expand weights, MNAS_PACK_FWD [C_pad16][Cin_pad32] */
-    const float* b1;         /* expand bias [C] or NULL */
-    const float* bn1_scale;  /* [C]: BatchNorm of the expand conv (bnbuf rows 0, 1) */
-    const float* bn1_shift;
-    const float* w;          /* depthwise weights fp32 [k*k][C] */
-    const float* bias;       /* depthwise bias [C] or NULL */
-    void*  y1;               /* bf16 (N,H,W,C) raw expand output, or NULL */
-    void*  out;              /* bf16 (N,H,W,C) raw depthwise output */
-    float* stats;
-} MnasDwExpFwd;
-int mnas_dw_exp_fwd(const MnasDwExpFwd* a, void* stream);
-int mnas_dw_exp_rows(int N, int H, int W, int C, int k, int Cin, int nparts);
-
-/* ---- fused inverted-residual block on the small feature maps (csrc/mnas_irb.hip, mnas_irb_bwd.hip): MBConv_block
- * (mnasnet.py:105-137) of the 14x14 / 7x7 stages with the t-times EXPANDED tensor kept off HBM.  Supported shapes
- * (mnas_irb_supported): W in {14, 7}, H <= W, C <= 192, C % 8 == 0, E % 32 == 0, k in {3, 5}; otherwise MNAS_EINVAL
- * (use the per-layer entry points).
- * Forward: y1 = W1 act(x) + b1 (matrix cores, never stored unless y1 != NULL) -> a1 = relu(bn1(y1)) -> y2 = depthwise(a1) +
- * bias (raw, stored) + BatchNorm partial statistics of y2 (float[2][E][nparts]).  bn1 = bnbuf of the expand conv with rows 0,1
- * (scale, shift) valid BEFORE the launch: mnas_gram + mnas_gram_bn_finalize.  nparts must be mnas_irb_fwd_parts(..., want). */
-typedef struct MnasIrbFwd {
-    int32_t N, H, W, C, E, k;
-    int32_t nparts, reserved;
-    MnasActIn x;             /* block input (N,H,W,C), act-on-load */
-    const void*  w1;         /* expand weights, MNAS_PACK_FWD [E_pad16][C_pad32] */
-    const float* b1;         /* expand bias [E] or NULL */
-    const float* bn1;        /* bnbuf float[8][E] of the expand conv */
-    const float* wdw;        /* depthwise weights fp32 [k*k][E] (MNAS_PACK_DW) */
-    const float* bdw;        /* depthwise bias [E] or NULL */
-    void*  y1;               /* bf16 (N,H,W,E) or NULL */
-    void*  y2;               /* bf16 (N,H,W,E) raw depthwise output */
-    float* stats;            /* float[2][E][nparts] or NULL */
-} MnasIrbFwd;
-int mnas_irb_fwd(const MnasIrbFwd* a, void* stream);
-int mnas_irb_supported(int N, int H, int W, int C, int E, int k);
-int mnas_irb_fwd_parts(int N, int H, int W, int C, int E, int k, int want);
-
-/* Backward of the same block (csrc/mnas_irb_bwd.hip), three launches separated by the BatchNorm-backward finalizes
- * (mnas_bwd_post / mnas_bn_bwd_finalize) whose coefficients the next launch needs; all take the same descriptor and read the
- * fields listed (unused ones may be NULL).  nparts = the forward's mnas_irb_fwd_parts value (image groups).
- *   mnas_irb_bwd_proj : gout = (G, y3, bnbuf3 rows 0..4), y2, bn2 (rows 0,1,5,6), w3t -> dy3 (bf16 (N,H,W,C), the project conv's
- *                       dy, materialised), w3partial float[nparts][C][E] (-> mnas_wgrad_finalize(.., nparts, C, E, 1, ..)),
- *                       red2 float[2][E][nparts] (BatchNorm2-backward sums of the never-written g2 = dy3 . W3).
- *   mnas_irb_bwd_dw   : x, dy3, y2, w1, w3t, b1, bn1 (rows 0,1,5,6), bn2 (rows 0..4, finalized), wdw -> g1 (bf16 (N,H,W,E): the
- *                       MASKED gradient dz1 of the expand conv's activated output), dwpartial float[nparts][k*k][E]
- *                       (-> mnas_dw_wgrad_finalize), ppartial float[nparts][E][C] (P = dz1^T act(x)), red1 float[2][E][nparts].
- *   mnas_irb_bwd_exp  : x, g1, w1, b1, bn1 (rows 2..4, finalized), gout.g (the skip gradient G, or NULL) -> dx (bf16 (N,H,W,C)).
- *   mnas_irb_w1_finalize: the expand conv's weight gradient from P, the forward's Gram sums (double[C*C + C]: G, Sx -- the
- *                       scratch of mnas_gram_bn_finalize) and bn1 rows 2..4; w1 = fp32 reference-layout weights [E][C]. */
-typedef struct MnasIrbBwd {
-    int32_t N, H, W, C, E, k;
-    int32_t nparts, reserved;
-    MnasActIn  x;            /* block input */
-    MnasGradIn gout;         /* G, y3, bnbuf of the project conv */
-    const void*  y2;
-    const void*  w1;         /* MNAS_PACK_FWD  of the expand conv  [E_pad16][C_pad32] */
-    const void*  w3t;        /* MNAS_PACK_DGRAD of the project conv [E_pad16][C_pad32] */
-    const float* b1;
-    const float* bn1;
-    const float* bn2;
-    const float* wdw;
-    void*  dy3;
-    void*  g1;
-    void*  dx;
-    float* w3partial;
-    float* red2;
-    float* dwpartial;
-    float* ppartial;
-    float* red1;
-} MnasIrbBwd;
-int mnas_irb_bwd_proj(const MnasIrbBwd* a, void* stream);
-int mnas_irb_bwd_dw(const MnasIrbBwd* a, void* stream);
-int mnas_irb_bwd_exp(const MnasIrbBwd* a, void* stream);
-int mnas_irb_w1_finalize(const float* ppartial, int nparts, int E, int C, const double* gsum, const float* w1,
-                         const float* b1, const float* bn1, float* grad, int accumulate, void* stream);
-
-/* ---- BatchNorm statistics of a 1x1 conv from the second moments of its INPUT (csrc/mnas_gram.hip) ----
- * mnas_gram: gpart[s][C][C] = sum over the pixels of split s of a a^T, spart[s][C] = sum a, a = act(x) (M pixels, C channels).
- * mnas_gram_bn_finalize: for y = W a + b (W: fp32 [Co][C], used bf16-rounded like the conv kernels do): batch mean / variance
- * of y -> bnbuf rows 0,1,5,6, running statistics and num_batches_tracked, exactly as mnas_bn_fwd_finalize(training=1).
- * scratch: double[C*C + C]. */
-int mnas_gram(const MnasActIn* x, int64_t M, int C, int nsplit, float* gpart, float* spart, void* stream);
-int mnas_gram_bn_finalize(const float* gpart, const float* spart, int nsplit, int C, int Co, double count,
-                          const float* w, const float* bias, const float* gamma, const float* beta,
-                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                          float eps, double* scratch, float* bnbuf, void* stream);
-
 typedef struct MnasDwBwd {
     int32_t N, H, W, C, k;
     int32_t nparts;
@@ -338,32 +232,12 @@ typedef struct MnasDwBwd {
     float* red_partial;
     int32_t phase;           /* 0: one fused sweep (input gradient + weight gradient + reduce); 1: input gradient (+reduce)
                                 only; 2: weight gradient only (lets the caller put the two on different streams) */
-    int32_t src_cin;         /* SRC form: channels of the block (src_x / src_dy), 8..32; 0 otherwise */
-    /* round 4, "SRC" form (src_dy != NULL; the depthwise conv of an MBConv_block, mnasnet.py:116-129, whose neighbours' wide
-     * tensors were never written): dy.g (= g2, the project conv's input gradient) and x.data (= y1, the expand conv's raw
-     * output) are NULL; their rows are recomputed on the matrix cores from the block's narrow tensors:
-     *     g2 = src_dy . W3   (src_dy: the project conv's dy, bf16 (N,H,W,src_cin), from mnas_pw_bwd's dy_out;
-     *                         src_w3t: MNAS_PACK_DGRAD weights of the project conv)
-     *     y1 = W1 act(src_x) + src_b1   (src_x: the block input; src_w1: MNAS_PACK_FWD weights of the expand conv)
-     * rounded to bf16 exactly as the kernels that would have stored them do.  x.scale / x.shift (BatchNorm of the expand conv),
-     * dy.y / dy.coef (depthwise conv), red_bn / red_partial (required) and phase = 0 as in the plain form; the partial tables
-     * have mnas_dw_src_rows(N,H,W,C,k,src_cin,nparts) rows. */
-    MnasActIn src_x;
-    const void*  src_w1;
-    const float* src_b1;
-    const void*  src_dy;
-    const void*  src_w3t;
+    int32_t reserved0;
     /* round 4: dy.g already holds dz = g*[s*y+t>0] (written by mnas_pw_bwd with gin_masked): dy-on-read skips the mask.
      * Phase 0 with the fused reduce only; results are bit-identical to the plain form on the unmasked g. */
     int32_t g_masked, reserved;
-    /* ABI 5: dy.g is read as g*g_gate[n][c] + g_bias[n][c] (fp32 [N][C] tables, both or neither) -- the squeeze-excite backward
-     * dL/da2 = gs*sigmoid(u) + dz/HW formed on read instead of materialised by mnas_se_bwd_apply.  Phase 0 with the fused reduce
-     * only, not with g_masked / SRC. */
-    const float* g_gate;
-    const float* g_bias;
 } MnasDwBwd;
 int mnas_dw_bwd(const MnasDwBwd* a, void* stream);
-int mnas_dw_src_rows(int N, int H, int W, int C, int k, int cin, int nparts);
 /* grad[c][0][kh][kw] (+)= sum_{p<nparts} wpartial[p][tap][c]   (pass nparts = rows1); wpartial is scratch like above */
 int mnas_dw_wgrad_finalize(float* wpartial, int nparts, int C, int k, float* grad, int accumulate,
                            void* stream);
@@ -520,13 +394,6 @@ int mnas_se_bwd_apply_cols(int N, int HW, int C);
  *                           weight gradient dW[o][c] (+)= sum_n s[n][c] * P_n[o][c].  W: the conv's fp32 weight [Co][Ci].
  *                           wpartial is overwritten (scratch).  Deterministic (fixed summation order). */
 int mnas_se_gate(const float* u, int N, int C, float* gate, void* stream);
-/* After mnas_pw_bwd(seg_px = HW/kseg, red4 = 1) of the project conv (part4 = its red_partial, float[4][C][N*kseg]) and the excite
- * MLP's backward (dz = dL/d(pooled a), fp32 [N][C]): g_bias[n][c] = dz/HW, and red float[2][C][N] = the BatchNorm-backward sums
- * (sum dz2, sum dz2*xhat) of dz2 = (gs*gate + g_bias)*[a > 0] per image -- what mnas_se_bwd_apply's fused reduce produced from a
- * pass over (gs, y2), here from the four per-image sums.  mnas_bn_bwd_finalize(red, nparts = N, ...) follows; mnas_dw_bwd reads gs
- * with g_gate = gate, g_bias. */
-int mnas_se_bn_assemble(const float* part4, int N, int kseg, int C, const float* gate, const float* dz, int HW, float* g_bias,
-                        float* red, void* stream);
 int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, int Ci, const float* u, const float* W, float* dW,
                           int accumulate, float* du, void* stream);
 
@@ -579,24 +446,18 @@ int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 #define MNAS_OP_EVENT_WAIT 16      /* p[0] = event handle: hipStreamWaitEvent(op's stream, event) */
 #define MNAS_OP_PW_BWD 17
 #define MNAS_OP_PACK_BATCH 18
-#define MNAS_OP_GRAM 19
-#define MNAS_OP_GRAM_BN 20
-#define MNAS_OP_DW_EXP_FWD 21
 #define MNAS_OP_POOL_ACT 22
 #define MNAS_OP_POOL_BWD 23
 #define MNAS_OP_DY_MAT 24
 #define MNAS_OP_BWD_POST 25
 #define MNAS_OP_TCONV_DGRAD 26
-#define MNAS_OP_IRB_FWD 27
-#define MNAS_OP_IRB_BWD 28     /* i[7] selects the launch (0 proj, 1 dw, 2 exp) and with it the pointer list: csrc/mnas_abi.hip */
-#define MNAS_OP_IRB_W1_FIN 29
+/* 19-21, 27-29, 36: retired in ABI 6 (Gram-statistics / fused-block / affine-on-read forms; DESIGN_HISTORY.md) */
 #define MNAS_OP_HEAD_LINEAR 30  /* i[5]: 0 forward, 1 weight gradient, 2 input gradient */
 #define MNAS_OP_SE_SCALE 31
 #define MNAS_OP_SE_BWD_REDUCE 32
 #define MNAS_OP_SE_BWD_APPLY 33
 #define MNAS_OP_SE_GATE 34          /* ABI 5 */
 #define MNAS_OP_SE_PROJ_FIN 35      /* ABI 5 */
-#define MNAS_OP_SE_BN_ASSEMBLE 36   /* ABI 5 */
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

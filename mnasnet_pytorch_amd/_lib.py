@@ -8,7 +8,7 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 5          # include/mnas.h: mnas_version()
+ABI_VERSION = 6          # include/mnas.h: mnas_version()
 LIB_PATH = os.environ.get("MNAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmnas_hip.so")      # override: A/B builds (tools/)
 
 c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
@@ -46,22 +46,14 @@ class MnasDwBwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
                 ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p), ("phase", C.c_int32),
-                ("src_cin", C.c_int32), ("src_x", MnasActIn), ("src_w1", c_void_p), ("src_b1", c_void_p), ("src_dy", c_void_p),
-                ("src_w3t", c_void_p), ("g_masked", C.c_int32), ("reserved", C.c_int32), ("g_gate", c_void_p), ("g_bias", c_void_p)]
-
-
-class MnasDwExpFwd(C.Structure):
-    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
-                ("Cin", C.c_int32), ("nparts", C.c_int32), ("reserved", C.c_int32), ("x", MnasActIn), ("w1", c_void_p),
-                ("b1", c_void_p), ("bn1_scale", c_void_p), ("bn1_shift", c_void_p), ("w", c_void_p), ("bias", c_void_p),
-                ("y1", c_void_p), ("out", c_void_p), ("stats", c_void_p)]
+                ("reserved0", C.c_int32), ("g_masked", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasPwBwd(C.Structure):
     _fields_ = [("M", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32), ("nparts", C.c_int32), ("x", MnasActIn),
                 ("dy", MnasGradIn), ("w", c_void_p), ("resid", c_void_p), ("gin", c_void_p), ("wpartial", c_void_p),
-                ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p), ("dy_out", c_void_p), ("w_fwd", c_void_p),
-                ("b_fwd", c_void_p), ("gin_masked", C.c_int32), ("seg_px", C.c_int32), ("red4", C.c_int32), ("reserved", C.c_int32)]
+                ("red_partial", c_void_p), ("red_y", c_void_p), ("red_bn", c_void_p), ("w_fwd", c_void_p),
+                ("b_fwd", c_void_p), ("gin_masked", C.c_int32), ("seg_px", C.c_int32)]
 
 
 class MnasPostWgrad(C.Structure):
@@ -97,21 +89,6 @@ class MnasStemWgrad(C.Structure):
                 ("in_affine", c_void_p), ("in_u8", C.c_int32), ("reserved", C.c_int32)]
 
 
-class MnasIrbFwd(C.Structure):
-    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("E", C.c_int32), ("k", C.c_int32),
-                ("nparts", C.c_int32), ("reserved", C.c_int32), ("x", MnasActIn), ("w1", c_void_p), ("b1", c_void_p),
-                ("bn1", c_void_p), ("wdw", c_void_p), ("bdw", c_void_p), ("y1", c_void_p), ("y2", c_void_p),
-                ("stats", c_void_p)]
-
-
-class MnasIrbBwd(C.Structure):
-    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("E", C.c_int32), ("k", C.c_int32),
-                ("nparts", C.c_int32), ("reserved", C.c_int32), ("x", MnasActIn), ("gout", MnasGradIn), ("y2", c_void_p),
-                ("w1", c_void_p), ("w3t", c_void_p), ("b1", c_void_p), ("bn1", c_void_p), ("bn2", c_void_p), ("wdw", c_void_p),
-                ("dy3", c_void_p), ("g1", c_void_p), ("dx", c_void_p), ("w3partial", c_void_p), ("red2", c_void_p),
-                ("dwpartial", c_void_p), ("ppartial", c_void_p), ("red1", c_void_p)]
-
-
 class MnasOp(C.Structure):
     _fields_ = [("opcode", C.c_int32), ("i", C.c_int32 * 15), ("d", C.c_double * 4), ("p", c_void_p * 16)]
 
@@ -119,10 +96,10 @@ class MnasOp(C.Structure):
 OP_CONV_GEMM, OP_CONV_WGRAD, OP_WGRAD_FINALIZE, OP_DW_FWD, OP_DW_BWD, OP_DW_WGRAD_FINALIZE = 1, 2, 3, 4, 5, 6
 OP_STEM_FWD, OP_STEM_WGRAD, OP_BN_FWD_FINALIZE, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE = 7, 8, 9, 10, 11
 OP_ADD_ACT, OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_PW_BWD, OP_PACK_BATCH = 12, 13, 14, 15, 16, 17, 18
-OP_GRAM, OP_GRAM_BN, OP_DW_EXP_FWD, OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 19, 20, 21, 22, 23, 24
-OP_BWD_POST, OP_TCONV_DGRAD, OP_IRB_FWD, OP_IRB_BWD, OP_IRB_W1_FIN = 25, 26, 27, 28, 29
+OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 22, 23, 24          # 19-21, 27-29, 36: retired in ABI 6 (include/mnas.h)
+OP_BWD_POST, OP_TCONV_DGRAD = 25, 26
 OP_HEAD_LINEAR, OP_SE_SCALE, OP_SE_BWD_REDUCE, OP_SE_BWD_APPLY = 30, 31, 32, 33
-OP_SE_GATE, OP_SE_PROJ_FIN, OP_SE_BN_ASSEMBLE = 34, 35, 36
+OP_SE_GATE, OP_SE_PROJ_FIN = 34, 35
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 EINVAL = 10001      # MNAS_EINVAL
 
@@ -143,13 +120,6 @@ SYMBOLS = {
     "mnas_head_dropout_mask": (c_int, [c_void_p, c_int64, c_float, C.c_uint64, c_void_p]),
     "mnas_head_cross_entropy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
-    "mnas_irb_fwd": (c_int, [C.POINTER(MnasIrbFwd), c_void_p]),
-    "mnas_irb_supported": (c_int, [c_int] * 6),
-    "mnas_irb_bwd_proj": (c_int, [C.POINTER(MnasIrbBwd), c_void_p]),
-    "mnas_irb_bwd_dw": (c_int, [C.POINTER(MnasIrbBwd), c_void_p]),
-    "mnas_irb_bwd_exp": (c_int, [C.POINTER(MnasIrbBwd), c_void_p]),
-    "mnas_irb_w1_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "mnas_irb_fwd_parts": (c_int, [c_int] * 7),
     "mnas_se_scale": (c_int, [C.POINTER(MnasActIn), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mnas_se_bwd_reduce": (c_int, [c_void_p, C.POINTER(MnasActIn), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mnas_se_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
@@ -157,7 +127,6 @@ SYMBOLS = {
     "mnas_se_bwd_apply_cols": (c_int, [c_int, c_int, c_int]),
     "mnas_se_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mnas_se_proj_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "mnas_se_bn_assemble": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mnas_conv_gemm_gate_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),
@@ -175,13 +144,7 @@ SYMBOLS = {
     "mnas_pw_bwd_slices": (c_int, [c_int, c_int]),
     "mnas_dw_fwd": (c_int, [C.POINTER(MnasDwFwd), c_void_p]),
     "mnas_dw_bwd": (c_int, [C.POINTER(MnasDwBwd), c_void_p]),
-    "mnas_dw_exp_fwd": (c_int, [C.POINTER(MnasDwExpFwd), c_void_p]),
-    "mnas_dw_exp_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "mnas_gram": (c_int, [C.POINTER(MnasActIn), c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "mnas_gram_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "mnas_dw_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "mnas_dw_src_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mnas_dw_geometry": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_int)]),
     "mnas_dw_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mnas_stem_fwd": (c_int, [C.POINTER(MnasStemFwd), c_void_p]),

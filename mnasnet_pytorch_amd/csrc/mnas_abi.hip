@@ -34,7 +34,7 @@ int mnas_pws_enabled() {
     return on;
 }
 
-extern "C" int mnas_version(void) { return 5; }
+extern "C" int mnas_version(void) { return 6; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 
 extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
@@ -65,18 +65,12 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //  NCHW_TO_NHWC     i: N,C,HW                                     p: src,dst
 //  PACK_WEIGHTS     i: kind,Co,Ci,kh,kw                           p: w,dst
 //  PACK_BATCH       i: n                                          p: descs (device array of MnasPackDesc)
-//  GRAM             i: C,nsplit           d: M                    p: x.data,x.scale,x.shift, gpart,spart
-//  GRAM_BN          i: nsplit,C,Co        d: count,momentum,eps   p: gpart,spart,w,bias,gamma,beta,rmean,rvar,nbt,scratch,bnbuf
-//  DW_EXP_FWD       i: N,H,W,C,k,Cin,nparts  p: x.data,x.scale,x.shift, w1,b1,bn1_scale,bn1_shift, w,bias,y1,out,stats
 //  POOL_ACT         i: N,HW,C                                     p: a.data,a.scale,a.shift, out
 //  POOL_BWD         i: N,HW,C                                     p: gpool, g
 //  DY_MAT           i: C                  d: rows                 p: g,y,coef,out
 //  BWD_POST         i: bn_nparts,bn_C, w1{nsplit,Co,Ci,taps,dw,level}, w2{...}   d: count
 //                   p: bn_partial,bnbuf,dgamma,dbeta, w1.partial,w1.grad, w2.partial,w2.grad
 //  TCONV_DGRAD      i: N,Ho,Wo,Co,Ci,nparts                       p: dy,w,out,stats,red_y,red_bn
-//  IRB_FWD          i: N,H,W,C,E,k,nparts          p: x.data,x.scale,x.shift, w1,b1,bn1,wdw,bdw,y1,y2,stats
-//  IRB_BWD          i: N,H,W,C,E,k,nparts,which    p: per launch (which = 0 proj, 1 dw, 2 exp): listed at the case below
-//  IRB_W1_FIN       i: nparts,E,C,accumulate       p: ppartial,gsum,w1,b1,bn1,grad
 //  HEAD_LINEAR      i: N,I,O,relu,accumulate,which   p: x,w,b,y,dz,dw,db,dx,relu_mask        (no dropout in launch lists)
 //  SE_SCALE         i: N,HW,C                      p: a.data,a.scale,a.shift, u, out
 //  SE_BWD_REDUCE    i: N,HW,C                      p: gs, a.data,a.scale,a.shift, u, du, scratch
@@ -122,25 +116,9 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = p[6]; a.resid = p[7]; a.gin = p[8]; a.wpartial = (float*)p[9];
             a.red_partial = (float*)p[10]; a.red_y = p[11]; a.red_bn = (const float*)p[12];
-            a.dy_out = p[13]; a.w_fwd = p[14]; a.b_fwd = (const float*)p[15];
-            a.gin_masked = i[4]; a.seg_px = i[5]; a.red4 = i[6];
+            a.w_fwd = p[14]; a.b_fwd = (const float*)p[15];        // (p[13], i[6]: the retired NOGIN / RED4 forms' slots)
+            a.gin_masked = i[4]; a.seg_px = i[5];
             return mnas_pw_bwd(&a, stream);
-        }
-        case MNAS_OP_GRAM: {
-            MnasActIn x = {p[0], (const float*)p[1], (const float*)p[2]};
-            return mnas_gram(&x, (int64_t)o.d[0], i[0], i[1], (float*)p[3], (float*)p[4], stream);
-        }
-        case MNAS_OP_GRAM_BN:
-            return mnas_gram_bn_finalize((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], o.d[0], (const float*)p[2],
-                                         (const float*)p[3], (const float*)p[4], (const float*)p[5], (float*)p[6], (float*)p[7],
-                                         (int64_t*)p[8], (float)o.d[1], (float)o.d[2], (double*)p[9], (float*)p[10], stream);
-        case MNAS_OP_DW_EXP_FWD: {
-            MnasDwExpFwd a = {};
-            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.k = i[4]; a.Cin = i[5]; a.nparts = i[6];
-            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
-            a.w1 = p[3]; a.b1 = (const float*)p[4]; a.bn1_scale = (const float*)p[5]; a.bn1_shift = (const float*)p[6];
-            a.w = (const float*)p[7]; a.bias = (const float*)p[8]; a.y1 = p[9]; a.out = p[10]; a.stats = (float*)p[11];
-            return mnas_dw_exp_fwd(&a, stream);
         }
         case MNAS_OP_WGRAD_FINALIZE:
             return mnas_wgrad_finalize((float*)p[0], i[0], i[1], i[2], i[3], (float*)p[1], i[4], stream);
@@ -158,15 +136,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = (const float*)p[6]; a.gin = p[7]; a.wpartial = (float*)p[8];
             a.red_bn = (const float*)p[9]; a.red_partial = (float*)p[10]; a.phase = i[6];
-            a.g_masked = i[8];
-            a.src_cin = i[7];      // SRC form (i[7] > 0): x.data / dy.g do not exist -- their slots carry the weight blocks
-            if (a.src_cin > 0) {
-                a.src_w1 = p[0]; a.src_w3t = p[3]; a.x.data = nullptr; a.dy.g = nullptr;
-                a.src_x.data = p[11]; a.src_x.scale = (const float*)p[12]; a.src_x.shift = (const float*)p[13];
-                a.src_dy = p[14]; a.src_b1 = (const float*)p[15];
-            } else {
-                a.g_gate = (const float*)p[11]; a.g_bias = (const float*)p[12];
-            }
+            a.g_masked = i[8];     // (i[7], p[11..15]: the retired SRC / g-affine forms' slots)
             return mnas_dw_bwd(&a, stream);
         }
         case MNAS_OP_DW_WGRAD_FINALIZE:
@@ -219,40 +189,6 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy = p[0]; a.w = p[1]; a.out = p[2]; a.stats = (float*)p[3]; a.red_y = p[4]; a.red_bn = (const float*)p[5];
             return mnas_tconv_dgrad(&a, stream);
         }
-        case MNAS_OP_IRB_FWD: {
-            MnasIrbFwd a = {};
-            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.E = i[4]; a.k = i[5]; a.nparts = i[6];
-            a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
-            a.w1 = p[3]; a.b1 = (const float*)p[4]; a.bn1 = (const float*)p[5]; a.wdw = (const float*)p[6];
-            a.bdw = (const float*)p[7]; a.y1 = p[8]; a.y2 = p[9]; a.stats = (float*)p[10];
-            return mnas_irb_fwd(&a, stream);
-        }
-        case MNAS_OP_IRB_BWD: {
-            MnasIrbBwd a = {};
-            a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.E = i[4]; a.k = i[5]; a.nparts = i[6];
-            if (i[7] == 0) {            // p: G, y3, bnbuf3, y2, bn2, w3t, dy3, w3partial, red2
-                a.gout.g = p[0]; a.gout.y = p[1]; a.gout.coef = (const float*)p[2];
-                a.y2 = p[3]; a.bn2 = (const float*)p[4]; a.w3t = p[5];
-                a.dy3 = p[6]; a.w3partial = (float*)p[7]; a.red2 = (float*)p[8];
-                return mnas_irb_bwd_proj(&a, stream);
-            }
-            if (i[7] == 1) {            // p: x.data,x.scale,x.shift, dy3, y2, w1, w3t, b1, bn1, bn2, wdw, g1, dwpartial, ppartial, red1
-                a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
-                a.dy3 = p[3]; a.y2 = p[4]; a.w1 = p[5]; a.w3t = p[6]; a.b1 = (const float*)p[7]; a.bn1 = (const float*)p[8];
-                a.bn2 = (const float*)p[9]; a.wdw = (const float*)p[10];
-                a.g1 = p[11]; a.dwpartial = (float*)p[12]; a.ppartial = (float*)p[13]; a.red1 = (float*)p[14];
-                return mnas_irb_bwd_dw(&a, stream);
-            }
-            if (i[7] == 2) {            // p: x.data,x.scale,x.shift, g1, w1, b1, bn1, G (skip gradient or NULL), dx
-                a.x.data = p[0]; a.x.scale = (const float*)p[1]; a.x.shift = (const float*)p[2];
-                a.g1 = p[3]; a.w1 = p[4]; a.b1 = (const float*)p[5]; a.bn1 = (const float*)p[6]; a.gout.g = p[7]; a.dx = p[8];
-                return mnas_irb_bwd_exp(&a, stream);
-            }
-            return MNAS_EINVAL;
-        }
-        case MNAS_OP_IRB_W1_FIN:
-            return mnas_irb_w1_finalize((const float*)p[0], i[0], i[1], i[2], (const double*)p[1], (const float*)p[2], (const float*)p[3],
-                                        (const float*)p[4], (float*)p[5], i[3], stream);
         case MNAS_OP_HEAD_LINEAR: {
             MnasHeadLinear a = {};
             a.N = i[0]; a.I = i[1]; a.O = i[2]; a.relu = i[3]; a.accumulate = i[4]; a.drop_p = 0.f; a.seed = 0;
@@ -275,9 +211,6 @@ static int run_one(const MnasOp& o, void* stream) {
         case MNAS_OP_SE_PROJ_FIN:
             return mnas_se_proj_finalize((float*)p[0], i[0], i[1], i[2], i[3], (const float*)p[1], (const float*)p[2], (float*)p[3],
                                          i[4], (float*)p[4], stream);
-        case MNAS_OP_SE_BN_ASSEMBLE:
-            return mnas_se_bn_assemble((const float*)p[0], i[0], i[1], i[2], (const float*)p[1], (const float*)p[2], i[3], (float*)p[3],
-                                       (float*)p[4], stream);
         case MNAS_OP_SE_BWD_APPLY:
             return mnas_se_bwd_apply(p[0], (const float*)p[1], (const float*)p[2], i[0], i[1], i[2], p[3], p[4], (const float*)p[5],
                                      (float*)p[6], stream);

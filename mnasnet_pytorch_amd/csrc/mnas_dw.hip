@@ -33,6 +33,7 @@
 #define DW_G 4          // rows per sweep step (default; the 5x5 weight-gradient sweep uses 2, see mnas_dw_bwd)
 #define DW_BW 4         // output columns per thread
 #define DW_RR 8         // ring rows = 2 * G (two buffers of G rows)
+#define DW_WSTRIDE 200  // bytes per channel pair in the LDS filter-tap table of the 5x5 forms: 25 taps x float2 (see dw_wld5)
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
@@ -46,23 +47,9 @@ struct DwArgs {
     int nt;                                 // nontemporal output stores
 };
 
-// exp_kpad > 0: geometry for the fused expand+depthwise forms (the workgroup also holds the expand conv's weight block
-// [2*cpw rounded to 16][exp_kpad+8] bf16, bias and input coefficients in LDS; channel blocks of at most 128 channels = 8 MFMA
-// tiles; at most DW_EXP_MAXPG 16-pixel groups of the G x iw ring patch per wave)
-#define DW_EXP_MAXPG 4
-#ifndef DW_SRC_LDS_CAP
-#define DW_SRC_LDS_CAP (52 * 1024)      // SRC backward: three workgroups per CU
-#endif
-static size_t dw_exp_lds(int cpw, int exp_kpad) {
-    const int rows = (2 * cpw + 15) / 16 * 16;
-    return (size_t)rows * (exp_kpad + 8) * 2 + (size_t)rows * 4 + (size_t)2 * exp_kpad * 4;
-}
-// src_cin > 0: geometry for the SRC backward (k_dw_bwd<.., SRC>): two weight blocks (expand conv, project conv^T) + two staging
-// rings of the narrow tensors (block input x, project-conv dy: src_cin channels) next to the three row rings
-static size_t dw_src_lds(int cpw, int kpad, int rr, int iw, int src_cin) {
-    return 2 * dw_exp_lds(cpw, kpad) + (size_t)2 * rr * iw * src_cin * 2;
-}
-static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a, int exp_kpad = 0, int src_cin = 0) {
+// wl: the launch form keeps its filter taps in LDS (DW_WSTRIDE bytes per channel pair of the block) and wants `wl_cap` bytes of LDS
+// per workgroup at most (four workgroups per CU instead of two)
+static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a, bool wl = false, size_t wl_cap = 0) {
     const int cps = C / 2;
     // Search (channel pairs per workgroup, column strips).  Whole pixel when it fits (cps <= 72), otherwise channel
     // blocks of >= 32 pairs (>= 128-byte runs per pixel).  Score = lane utilisation x occupancy / halo.
@@ -75,18 +62,10 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArg
         const int cgn = cpw / 4;
         for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
             const int tw = sx * DW_BW, iw = tw + k - 1;
-            size_t lds = (size_t)nrings * rr * iw * cpw * 4;
-            if (exp_kpad > 0) {
-                if (cpw > 64) continue;
-                lds += src_cin > 0 ? dw_src_lds(cpw, exp_kpad, rr, iw, src_cin) : dw_exp_lds(cpw, exp_kpad);
-                const int nth_ = ((sx * cpw + 63) / 64) * 64;
-                const int npg = ((rr / 2) * iw + 15) / 16;
-                if (src_cin == 0 && (npg + nth_ / 64 - 1) / (nth_ / 64) > DW_EXP_MAXPG) continue;
-                if (src_cin > 0 && nth_ > 192) continue;                       // + one producer wave = 256 threads
-            }
+            size_t lds = (size_t)nrings * rr * iw * cpw * 4 + (wl ? (size_t)cpw * DW_WSTRIDE : 0);
             // two workgroups per CU either way (160 KB LDS): wide strips (78 KB) measured 8-10 % faster than 60 KB for
             // every launch form except the 5x5 weight-gradient sweep (3 rings), which is 14 % slower with them
-            const size_t cap = src_cin > 0 ? (size_t)DW_SRC_LDS_CAP : ((k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024);
+            const size_t cap = wl ? wl_cap : ((k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024);
             if (lds > cap) continue;
             const int nth = ((sx * cpw + 63) / 64) * 64;
             const int rc = iw * cgn;
@@ -178,6 +157,49 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 f2bf(uint32_t u) { f2 r; r.x = bf_lo(u); r.y = bf_hi(u); return r; }   // bf16 pair -> f32 pair
 
+// ---- filter taps streamed from LDS (5x5 kernels, round 5) ---------------------------------------------------------------------
+// The 25 taps of a channel pair are 50 VGPRs -- a fifth of the register file of a kernel whose occupancy is what hides its LDS and
+// DMA latencies.  They are loop-invariant, so the compiler keeps them in registers whatever the source says (it hoists plain LDS
+// loads out of the row loop; `volatile` loads each get a full s_waitcnt).  Hence inline asm: the workgroup parks the taps of its
+// channel block in LDS once, lane-major ([channel pair][25 taps] float2: a tap is the lane's base address + an IMMEDIATE offset,
+// stride 50 dwords -> conflict-free b64 reads), and the row body fetches one tap ROW (5 float2) at a time into two alternating
+// 5-pair buffers, the fetch of tap row i+1 in flight under the 20 packed FMAs of tap row i.  LDS returns in order, so
+// `s_waitcnt lgkmcnt(5)` after issuing the next five guarantees everything older has landed; the waits carry the buffer as an
+// in/out operand so that no use can be scheduled above them.  (Loads the compiler issues itself in between only make a wait
+// more conservative: its own counters assume fewer loads in flight than there are.)
+__device__ __forceinline__ uint32_t dw_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void dw_wld5(f2 (&w)[5], uint32_t addr) {      // taps OFF .. OFF+4 of this lane's channel pair
+    asm volatile("ds_read_b64 %0, %5 offset:%6\n\tds_read_b64 %1, %5 offset:%7\n\tds_read_b64 %2, %5 offset:%8\n\t"
+                 "ds_read_b64 %3, %5 offset:%9\n\tds_read_b64 %4, %5 offset:%10"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4])
+                 : "v"(addr), "n"(OFF * 8), "n"(OFF * 8 + 8), "n"(OFF * 8 + 16), "n"(OFF * 8 + 24), "n"(OFF * 8 + 32)
+                 : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void dw_wwait(f2 (&w)[5]) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : "n"(CNT));
+}
+// A[i][ox] += tap(row KS-1-i, kx) * xr[ox+kx] for the five tap rows of a 5x5 filter, taps streamed as described above
+__device__ __forceinline__ void dw_scatter5_lds(f2 (&A)[5][DW_BW], const f2 (&xr)[DW_BW + 4], uint32_t waddr) {
+    f2 wa[5], wb[5];
+#define DW_ROWFMA(I_, W_) _Pragma("unroll") for (int ox = 0; ox < DW_BW; ++ox) _Pragma("unroll") for (int kx = 0; kx < 5; ++kx) \
+        A[I_][ox] = f2fma(W_[kx], xr[ox + kx], A[I_][ox])
+    dw_wld5<20>(wa, waddr);
+    dw_wld5<15>(wb, waddr);
+    dw_wwait<5>(wa); DW_ROWFMA(0, wa);
+    dw_wld5<10>(wa, waddr);
+    dw_wwait<5>(wb); DW_ROWFMA(1, wb);
+    dw_wld5<5>(wb, waddr);
+    dw_wwait<5>(wa); DW_ROWFMA(2, wa);
+    dw_wld5<0>(wa, waddr);
+    dw_wwait<5>(wb); DW_ROWFMA(3, wb);
+    dw_wwait<0>(wa); DW_ROWFMA(4, wa);
+#undef DW_ROWFMA
+}
+
 // window row of activations: relu(s*x+t) (or x), zero outside the image columns (mz[xx] = 1.0 inside, 0.0 outside)
 template <int WIN_W>
 __device__ __forceinline__ void dw_read_act(const uint32_t* rowp, int ps, bool has_coef, f2 s, f2 t, unsigned colmask,
@@ -232,34 +254,20 @@ __device__ __forceinline__ void dw_fill_edges(const DwArgs& a, const DwDma& p, u
 // GM ("g is masked", round 4): the producer of g -- mnas_pw_bwd's out-stage forms with gin_masked, which compute the mask for
 // their fused reduce anyway -- stored dz = g*[s*y+t>0] instead of g: the window read drops the mask (one packed FMA, two
 // compares, two selects per channel pair and column: 40 of the 5x5 row body's ~530 vector instructions)
-// GA ("g affine", round 4): the stored gradient is read as g*ge + gz with per-(image, channel) ge, gz (the squeeze-excite backward
-// g*sigmoid(u) + dz/HW formed on read instead of materialised by k_se_bwd_apply: csrc/mnas_se.hip)
-template <int WIN_W, bool GM = false, bool GA = false>
+template <int WIN_W, bool GM = false>
 __device__ __forceinline__ void dw_read_dy(const uint32_t* growp, const uint32_t* yrowp, int ps, const f2 (&cf)[5],
-                                           unsigned colmask, f2 (&xr)[WIN_W], f2 ge = {1.f, 1.f}, f2 gz = {0.f, 0.f}) {
+                                           unsigned colmask, f2 (&xr)[WIN_W]) {
 #pragma unroll
     for (int xx = 0; xx < WIN_W; ++xx) {
         const f2 g = f2bf(growp[xx * ps]), y = f2bf(yrowp[xx * ps]);
         f2 d;
-        if constexpr (GA) {
-            // ge / gz arrive pre-multiplied by c1 (the caller folds them once per item: one register pair more than the plain form
-            // instead of two -- this kernel sits at 256 VGPRs and every further live value is reloaded from scratch inside the row
-            // loop, each reload draining the ring DMA with it): dy = [s*y+t>0] * (g*c1*e + c1*z) + c2*y + c3
+        f2 dz = g;
+        if constexpr (!GM) {
             const f2 z = f2fma(y, cf[0], cf[1]);
-            const f2 t1 = f2fma(g, ge, gz);
-            f2 dz;
-            dz.x = (z.x > 0.f) ? t1.x : 0.f;
-            dz.y = (z.y > 0.f) ? t1.y : 0.f;
-            d = dz + f2fma(cf[3], y, cf[4]);
-        } else {
-            f2 dz = g;
-            if constexpr (!GM) {
-                const f2 z = f2fma(y, cf[0], cf[1]);
-                dz.x = (z.x > 0.f) ? g.x : 0.f;
-                dz.y = (z.y > 0.f) ? g.y : 0.f;
-            }
-            d = f2fma(cf[2], dz, f2fma(cf[3], y, cf[4]));
+            dz.x = (z.x > 0.f) ? g.x : 0.f;
+            dz.y = (z.y > 0.f) ? g.y : 0.f;
         }
+        d = f2fma(cf[2], dz, f2fma(cf[3], y, cf[4]));
         const bool in = (colmask >> xx) & 1u;
         xr[xx].x = in ? d.x : 0.f;
         xr[xx].y = in ? d.y : 0.f;
@@ -290,14 +298,16 @@ __device__ __forceinline__ void dw_block_reduce(float* scratch, const f2 (&v)[NV
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------
-template <int KS, int G>
-__global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, MnasActIn in, const float* __restrict__ w,
+template <int KS, int G, bool WL = false>
+__global__ __launch_bounds__(256, ((KS == 3 || WL) ? 4 : 3)) void k_dw_fwd(DwArgs a, MnasActIn in, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, uint32_t* __restrict__ out,
                                                                    float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
     const int cblk = 2 * a.cpw;
+    static_assert(!WL || KS == 5, "tap streaming is the 5x5 form");
     uint32_t* ring = (uint32_t*)smem;                    // [RR][rc*4 dwords]; reused as reduction scratch at the end
+    float* lds_w = (float*)(ring + (size_t)(2 * G) * a.rc * 4);      // WL: [cpw][25] float2 filter taps of the channel block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
@@ -306,7 +316,8 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     const f2 zero2 = {0.f, 0.f};
     f2 s1 = zero2, s2 = zero2;
     int cur_c0 = -1;
-    f2 wt[KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
+    f2 wt[WL ? 1 : KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
+    const uint32_t waddr = dw_lds_addr(lds_w) + (uint32_t)cp * DW_WSTRIDE;
     const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
@@ -317,10 +328,21 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         const bool ch_ok = ch < a.C;
         if (c0 != cur_c0) {       // first item: a workgroup only ever sees ONE channel block (see dw_setup)
             cur_c0 = c0;
+            if constexpr (WL) {
+                if (sxi == 0) {                  // (published by the barrier below, before anybody's first row)
+                    for (int t = 0; t < KS * KS; ++t) {
+                        f2 v;
+                        v.x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
+                        v.y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
+                        *(f2*)(lds_w + (size_t)cp * (DW_WSTRIDE / 4) + 2 * t) = v;
+                    }
+                }
+            } else {
 #pragma unroll
-            for (int t = 0; t < KS * KS; ++t) {
-                wt[t].x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
-                wt[t].y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
+                for (int t = 0; t < KS * KS; ++t) {
+                    wt[t].x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
+                    wt[t].y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
+                }
             }
             b2.x = (bias && ch_ok) ? bias[ch] : 0.f;
             b2.y = (bias && ch_ok) ? bias[ch + 1] : 0.f;
@@ -359,13 +381,17 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
                 if (iy >= 0 && iy < a.H) {           // uniform: rows outside the image contribute nothing
                     f2 xr[WIN_W];
                     dw_read_act_nm<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, xr);
+                    if constexpr (WL) {
+                        dw_scatter5_lds(A, xr, waddr);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < KS; ++i)
+                        for (int i = 0; i < KS; ++i)
 #pragma unroll
-                        for (int ox = 0; ox < DW_BW; ++ox)
+                            for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
-                            for (int kx = 0; kx < KS; ++kx)
-                                A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
+                                for (int kx = 0; kx < KS; ++kx)
+                                    A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
+                    }
                 }
                 if (oy >= 0 && oy < a.H && ch_ok) {
 #pragma unroll
@@ -402,255 +428,16 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
 }
 
 
-// ---- forward, fused with the preceding 1x1 expand conv (MBConv_block, mnasnet.py:116-125) ------------------------------
-// The ring rows are not copied from HBM: they are COMPUTED from the block input x (Cin channels, the small tensor) on the
-// matrix cores: y1[pixel][c0..c0+cblk) = W1 act(x)[pixel] + b1 for the G x iw patch of the next row group, written to the
-// ring as the same bf16 image the DMA would have delivered.  The expand conv's BatchNorm coefficients (`in.scale/shift`,
-// applied when the depthwise window is read) are known before this kernel runs: mnas_gram + mnas_gram_bn_finalize derive
-// them from the covariance of x.  The x fragments (8 consecutive input channels of one pixel = 16 contiguous bytes in
-// NHWC) go straight from global memory to registers one row group ahead; W1's block is LDS-resident.  With e.y1 == NULL the
-// expanded tensor never reaches HBM; otherwise the workgroup also stores the rows it owns (backward of the unfused form).
-struct DwExp {
-    const uint16_t* x;       // block input (N,H,W,Cin) bf16
-    const float* xs;         // act-on-load coefficients of x ([Cin]) or NULL
-    const float* xt;
-    const uint16_t* w1;      // MNAS_PACK_FWD weights of the expand conv: [C rounded to 16][Kpad]
-    const float* b1;         // [C] or NULL
-    uint32_t* y1;            // raw expand output (N,H,W,C) or NULL
-    int Cin, Kpad;
-};
-
-template <int KS, int G, int KST>
-__global__ __launch_bounds__(256, 2) void k_dw_fwd_exp(DwArgs a, DwExp e, MnasActIn in, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, uint32_t* __restrict__ out,
-                                                       float* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
-    const int cblk = 2 * a.cpw;
-    const int ntb = (cblk + 15) >> 4;                     // MFMA cout tiles of the channel block
-    const int ldw = e.Kpad + 8;
-    uint32_t* ring = (uint32_t*)smem;                     // [2G][rc*4 dwords]
-    uint16_t* lds_w1 = (uint16_t*)(ring + (size_t)(2 * G) * a.rc * 4);      // [ntb*16][ldw]
-    float* lds_b1 = (float*)(lds_w1 + (size_t)ntb * 16 * ldw);             // [ntb*16]
-    float* lds_xc = lds_b1 + ntb * 16;                                      // [2][Kpad]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int cp = tid % a.cpw, sxi = tid / a.cpw;
-    const bool active = sxi < a.sx;
-    const bool has_coef = in.scale != nullptr, has_xc = e.xs != nullptr;
-    const f2 zero2 = {0.f, 0.f};
-    f2 s1 = zero2, s2 = zero2;
-    f2 wt[KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
-    const int nsteps = (a.H + 2 * PAD + G - 1) / G;
-    const int ps = a.cpw;
-    const int npg = (G * a.iw + 15) >> 4;                 // 16-pixel groups of the G x iw patch
-
-    // ---- per-workgroup constants: its channel block never changes (geff is a multiple of cblocks)
-    const int c0 = ((int)blockIdx.x % a.cblocks) * cblk;
-    {
-        const int ch = c0 + 2 * cp;
-        const bool ch_ok = ch < a.C;
-#pragma unroll
-        for (int t = 0; t < KS * KS; ++t) {
-            wt[t].x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
-            wt[t].y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
-        }
-        b2.x = (bias && ch_ok) ? bias[ch] : 0.f;
-        b2.y = (bias && ch_ok) ? bias[ch + 1] : 0.f;
-        if (has_coef && ch_ok) { cs.x = in.scale[ch]; cs.y = in.scale[ch + 1]; ct.x = in.shift[ch]; ct.y = in.shift[ch + 1]; }
-        const int kc8n = e.Kpad >> 3, cpad16 = (a.C + 15) / 16 * 16;
-        for (int q = tid; q < ntb * 16 * kc8n; q += blockDim.x) {
-            const int r = q / kc8n, k8 = q - r * kc8n;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < cblk && c0 + r < cpad16) v = *(const uint4*)(e.w1 + (size_t)(c0 + r) * e.Kpad + k8 * 8);
-            *(uint4*)(lds_w1 + r * ldw + k8 * 8) = v;
-        }
-        for (int i = tid; i < ntb * 16; i += blockDim.x) lds_b1[i] = (e.b1 && i < cblk && c0 + i < a.C) ? e.b1[c0 + i] : 0.f;
-        for (int i = tid; i < 2 * e.Kpad; i += blockDim.x) {
-            const int r = i / e.Kpad, c = i - r * e.Kpad;
-            lds_xc[i] = (has_xc && c < e.Cin) ? (r == 0 ? e.xs[c] : e.xt[c]) : 0.f;
-        }
-    }
-    // ---- expand plan: this wave's pixel groups pg = wave + nwaves*i; lane l15 <-> patch pixel pi = pg*16 + l15 = (r, xx)
-    int pr_[DW_EXP_MAXPG], px_[DW_EXP_MAXPG];
-#pragma unroll
-    for (int i = 0; i < DW_EXP_MAXPG; ++i) {
-        const int pi = (wave + nwaves * i) * 16 + l15;
-        pr_[i] = pi / a.iw; px_[i] = pi - pr_[i] * a.iw;
-        if (wave + nwaves * i >= npg || pi >= G * a.iw) pr_[i] = -1;
-    }
-    uint4 xf[DW_EXP_MAXPG][KST];
-    __syncthreads();
-
-    for (int item = blockIdx.x; item < a.items; item += a.geff) {
-        int n, x0, c0i;
-        dw_item(a, item, n, x0, c0i);
-        const int ch = c0 + 2 * cp;
-        const bool ch_ok = ch < a.C;
-        const int gx0 = x0 + sxi * DW_BW;
-        unsigned colmask = 0;
-#pragma unroll
-        for (int xx = 0; xx < WIN_W; ++xx) { const int gx = gx0 - PAD + xx; colmask |= (gx >= 0 && gx < a.W) ? (1u << xx) : 0u; }
-        f2 A[KS][DW_BW];
-#pragma unroll
-        for (int i = 0; i < KS; ++i)
-#pragma unroll
-            for (int j = 0; j < DW_BW; ++j) A[i][j] = b2;
-        uint32_t* outp = out + (((size_t)n * a.H * a.W + gx0) * a.C + ch) / 2;
-        const uint32_t* colp = ring + (size_t)sxi * DW_BW * ps + cp;
-
-        // x fragments of the row group starting at image row r0 (registers; consumed by expand_rows one step later)
-        auto load_x = [&](int r0) {
-#pragma unroll
-            for (int i = 0; i < DW_EXP_MAXPG; ++i) {
-                const int gy = r0 + pr_[i], gx = x0 - PAD + px_[i];
-                const bool ok = pr_[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                const uint16_t* src = e.x + (((size_t)n * a.H + gy) * a.W + gx) * e.Cin + lg * 8;
-#pragma unroll
-                for (int ks = 0; ks < KST; ++ks)
-                    xf[i][ks] = (ok && ks * 32 + lg * 8 < e.Cin) ? *(const uint4*)(src + ks * 32) : make_uint4(0, 0, 0, 0);
-            }
-        };
-        // y1 rows [r0, r0+G) of the patch -> ring (and, for the pixels this workgroup owns, HBM)
-        auto expand_rows = [&](int r0) {
-#pragma unroll
-            for (int i = 0; i < DW_EXP_MAXPG; ++i) {
-                if (wave + nwaves * i >= npg) break;                      // uniform per wave
-                const int gy = r0 + pr_[i], gx = x0 - PAD + px_[i];
-                const bool ok = pr_[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                bf16x8_t bfrag[KST];
-#pragma unroll
-                for (int ks = 0; ks < KST; ++ks) {
-                    uint4 v = xf[i][ks];
-                    if (has_xc && ok) {
-                        const int k = ks * 32 + lg * 8;
-                        float sc[8], sh[8];
-                        *(float4*)&sc[0] = *(const float4*)(lds_xc + k);
-                        *(float4*)&sc[4] = *(const float4*)(lds_xc + k + 4);
-                        *(float4*)&sh[0] = *(const float4*)(lds_xc + e.Kpad + k);
-                        *(float4*)&sh[4] = *(const float4*)(lds_xc + e.Kpad + k + 4);
-                        v = act8(v, sc, sh);
-                        if (k >= e.Cin) v = make_uint4(0, 0, 0, 0);
-                    }
-                    bfrag[ks] = *(const bf16x8_t*)&v;
-                }
-                const bool own = ok && px_[i] >= PAD && px_[i] < PAD + a.sx * DW_BW;
-                uint32_t* ringp = ring + (size_t)dw_slot<2 * G>(gy) * a.rc * 4 + (size_t)px_[i] * a.cgn * 4 + (lg >> 1) * 4 + (lg & 1) * 2;
-                for (int nt = 0; nt < ntb; ++nt) {
-                    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < KST; ++ks) {
-                        const bf16x8_t afrag = *(const bf16x8_t*)(lds_w1 + (nt * 16 + l15) * ldw + ks * 32 + lg * 8);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[ks], acc, 0, 0, 0);
-                    }
-                    const int cl = nt * 16 + lg * 4;                      // first of this lane's 4 channels inside the block
-                    const float4 bb = *(const float4*)(lds_b1 + cl);
-                    uint2 pk;
-                    pk.x = pack_bf16(acc[0] + bb.x, acc[1] + bb.y);
-                    pk.y = pack_bf16(acc[2] + bb.z, acc[3] + bb.w);
-                    if (ok && cl < cblk) {
-                        *(uint2*)(ringp + nt * 8) = pk;
-                        if (e.y1 && own && c0 + cl < a.C)
-                            st_u2(e.y1 + (((size_t)n * a.H + gy) * a.W + gx) * a.C / 2 + (c0 + cl) / 2, pk, a.nt);
-                    }
-                }
-            }
-        };
-
-        __syncthreads();                             // previous item's last group consumed
-        load_x(-PAD);
-        expand_rows(-PAD);
-        if (nsteps > 1) load_x(-PAD + G);
-        for (int s = 0; s < nsteps; ++s) {
-            const int r0 = -PAD + s * G;
-            __syncthreads();                         // group s is in the ring; readers of group s-1 are done with the other buffer
-            if (s + 1 < nsteps) {
-                expand_rows(r0 + G);
-                if (s + 2 < nsteps) load_x(r0 + 2 * G);
-            }
-            if (!active) continue;
-#pragma unroll 1
-            for (int j = 0; j < G; ++j) {
-                const int iy = r0 + j;
-                const int oy = iy - PAD;
-                if (iy >= 0 && iy < a.H) {
-                    f2 xr[WIN_W];
-                    dw_read_act<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, colmask, xr);
-#pragma unroll
-                    for (int i = 0; i < KS; ++i)
-#pragma unroll
-                        for (int ox = 0; ox < DW_BW; ++ox)
-#pragma unroll
-                            for (int kx = 0; kx < KS; ++kx)
-                                A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
-                }
-                if (oy >= 0 && oy < a.H && ch_ok) {
-#pragma unroll
-                    for (int ox = 0; ox < DW_BW; ++ox) {
-                        if (gx0 + ox < a.W) {
-                            const f2 v = A[0][ox];
-                            s1 += v;
-                            s2 = f2fma(v, v, s2);
-                            st_u1(outp + ((size_t)oy * a.W + ox) * a.C / 2, pack_bf16(v.x, v.y), a.nt);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i + 1 < KS; ++i)
-#pragma unroll
-                    for (int ox = 0; ox < DW_BW; ++ox) A[i][ox] = A[i + 1][ox];
-#pragma unroll
-                for (int ox = 0; ox < DW_BW; ++ox) A[KS - 1][ox] = b2;
-            }
-        }
-    }
-    if (stats) {
-        const int rows = a.geff / a.cblocks, col = blockIdx.x / a.cblocks;
-        const f2 sv[2] = {s1, s2};
-        const bool any = (int)blockIdx.x < a.items;
-        dw_block_reduce<2>((float*)ring, sv, cp, sxi, a.sx, cblk, active, [&](int r, int cl, float v) {
-            const int c = c0 + cl;
-            if (c < a.C) stats[((size_t)r * a.C + c) * rows + col] = any ? v : 0.f;
-        });
-    }
-}
-
 // ---- backward: input gradient (DG), weight gradient (WG), fused BN-backward reduce of the producer of x (RED) ----
 // Per image row iy (rows iy of g,y and iy-PAD.. of x are in the rings):
 //   xr = dy row iy, k+3 columns  -> DG: scattered into the register ring A of KS partial gin rows (flipped filter);
 //                                   its centre 4 columns become D[0] of the dy ring (D[q] = dy row iy-q)
 //   xa = act(x) row r = iy-PAD   -> WG: wacc[ky][kx] += D[ky][ox] * xa[ox+kx]      (dy rows r-ky+PAD = iy-ky)
 //   RED: the raw x centre values of row iy-PAD are in the x ring too: sum dz, sum dz*xhat for the emitted gin row.
-// SRC (round 4, the spatially tiled fused inverted-residual block): the g ring and the x ring are not copied from HBM -- the
-// tensors they would be copied from (g2 = dy3 . W3, the project conv's input gradient, and y1 = W1 act(x) + b1, the expand
-// conv's raw output: both t times wider than the block) were never written.  Their rows are COMPUTED on the matrix cores, one
-// row group ahead of the sweep, from the two NARROW tensors of the block (dy3 and the block input x, Cin channels), whose row
-// segments are staged in LDS by DMA one further group ahead.  The epilogues round exactly as the kernels that used to store
-// the tensors did (same MFMA, same k order), so everything downstream is bit-identical to the per-layer path.
-// WAVE SPECIALISATION: the workgroup carries ONE extra wave (the last one) that does nothing but this: it issues the staging
-// DMA and runs the MFMAs + epilogues of the next group while the sweep waves work the current group on the vector ALUs -- the
-// matrix pipe and the vector pipe of a CU are busy at the same time, from different waves, and the producer's dependent
-// LDS -> MFMA -> pack -> LDS chains sit on nobody's critical path (folded into the sweep waves, the same work made the launch
-// 2x slower: 614 vs 315 us at 112x112, 43 spilled VGPRs).  The sweep waves are exactly those of the plain kernel.
-struct DwSrc {
-    const uint16_t* x;       // block input (N,H,W,Cin) bf16
-    const float* xs;         // its act-on-load coefficients ([Cin]) or NULL
-    const float* xt;
-    const uint16_t* w1;      // MNAS_PACK_FWD weights of the expand conv [C rounded to 16][Kpad]
-    const float* b1;         // [C] or NULL
-    const uint16_t* dy;      // materialised dy of the project conv (N,H,W,Cin) bf16
-    const uint16_t* w3t;     // MNAS_PACK_DGRAD weights of the project conv [C rounded to 16][Kpad]
-    int Cin, Kpad;
-};
-
-template <int KS, bool DG, bool WG, bool RED, int G, bool SRC = false, int NTB = 1, bool GM = false, bool GA = false>
+template <int KS, bool DG, bool WG, bool RED, int G, bool GM = false>
 __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
-    float* __restrict__ red_partial, const float* __restrict__ red_bn, DwSrc e, const float* __restrict__ g_gate = nullptr,
-    const float* __restrict__ g_bias = nullptr) {
-    static_assert(!SRC || (DG && WG), "the SRC form is the fused sweep");
-    static_assert(!GA || (!SRC && !GM), "g affine: plain fused sweep");
+    float* __restrict__ red_partial, const float* __restrict__ red_bn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
     constexpr bool NEEDX = WG;                 // x ring only when the weight gradient is computed here
@@ -660,45 +447,11 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     uint32_t* ring_y = ring_g + (size_t)(2 * G) * a.rc * 4;
     uint32_t* ring_x = ring_y + (size_t)(2 * G) * a.rc * 4;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (blockDim.x >> 6) - (SRC ? 1 : 0);   // sweep waves
-    const bool is_prod = SRC && wave == nwaves;           // SRC: the extra (last) wave produces the g / x ring rows
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
-    const bool active = sxi < a.sx;                       // (false for the producer wave: tid >= sx * cpw)
+    const bool active = sxi < a.sx;
     const bool has_coef = x.scale != nullptr;
     const uint32_t* xglob = (const uint32_t*)x.data;
-    // ---- SRC: weight blocks, coefficient tables and the staging rings of the two narrow tensors
-    const int ntb = (cblk + 15) >> 4;                     // MFMA cout tiles of the channel block
-    const int ldw = e.Kpad + 8;
-    const int cgs = e.Cin >> 3, rcs = a.iw * cgs;         // staging: 16-byte chunks per pixel / per ring row
-    float* lds_ga = (float*)(ring_x + (size_t)(2 * G) * a.rc * 4);            // GA: [2][cblk] (c1*gate, c1*bias) of the current item
-    uint16_t* lds_w1 = (uint16_t*)(ring_x + (size_t)(2 * G) * a.rc * 4);      // [ntb*16][ldw]
-    uint16_t* lds_w3 = lds_w1 + (size_t)ntb * 16 * ldw;                       // [ntb*16][ldw]
-    float* lds_b1 = (float*)(lds_w3 + (size_t)ntb * 16 * ldw);               // [ntb*16]
-    float* lds_xc = lds_b1 + ntb * 16;                                        // [2][Kpad]
-    uint16_t* stage_d = (uint16_t*)(lds_xc + 2 * e.Kpad);                     // [2G][rcs*8]
-    uint16_t* stage_x = stage_d + (size_t)(2 * G) * rcs * 8;                  // [2G][rcs*8]
-    const int l15 = lane & 15, lg = lane >> 4;
-    const bool has_xc = SRC && e.xs != nullptr;
-    const int npg = (G * a.iw + 15) >> 4;                 // 16-pixel groups of the G x iw patch
-    if constexpr (SRC) {
-        const int c0w = ((int)blockIdx.x % a.cblocks) * cblk;          // a workgroup only ever sees one channel block
-        const int kc8n = e.Kpad >> 3, cpad16 = (a.C + 15) / 16 * 16;
-        for (int q = tid; q < ntb * 16 * kc8n; q += blockDim.x) {
-            const int r = q / kc8n, k8 = q - r * kc8n;
-            uint4 v1 = make_uint4(0, 0, 0, 0), v3 = make_uint4(0, 0, 0, 0);
-            if (r < cblk && c0w + r < cpad16) {
-                v1 = *(const uint4*)(e.w1 + (size_t)(c0w + r) * e.Kpad + k8 * 8);
-                v3 = *(const uint4*)(e.w3t + (size_t)(c0w + r) * e.Kpad + k8 * 8);
-            }
-            *(uint4*)(lds_w1 + r * ldw + k8 * 8) = v1;
-            *(uint4*)(lds_w3 + r * ldw + k8 * 8) = v3;
-        }
-        for (int i = tid; i < ntb * 16; i += blockDim.x) lds_b1[i] = (e.b1 && i < cblk && c0w + i < a.C) ? e.b1[c0w + i] : 0.f;
-        for (int i = tid; i < 2 * e.Kpad; i += blockDim.x) {
-            const int r = i / e.Kpad, c = i - r * e.Kpad;
-            lds_xc[i] = (has_xc && c < e.Cin) ? (r == 0 ? e.xs[c] : e.xt[c]) : 0.f;
-        }
-    }
     const f2 zero2 = {0.f, 0.f};
     int cur_c0 = -1;
     f2 wt[DG ? KS * KS : 1], wacc[WG ? KS * KS : 1];
@@ -710,105 +463,6 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
-    if (SRC && is_prod) {
-      if constexpr (SRC) {
-        // ================= producer wave: its own loop nest (disjoint live ranges: the kernel's register count is the larger of
-        // the two roles, not their sum), meeting the sweep waves at the same barriers =================
-        __syncthreads();                                  // weight blocks / tables are in LDS
-        bf16x8_t af1[NTB], af3[NTB];                      // expand / project^T weight fragments, bias: registers for the whole kernel
-        float4 bb1[NTB];
-        float xsc[8], xsh[8];
-#pragma unroll
-        for (int nt = 0; nt < NTB; ++nt) {
-            af1[nt] = *(const bf16x8_t*)(lds_w1 + (nt * 16 + l15) * ldw + lg * 8);
-            af3[nt] = *(const bf16x8_t*)(lds_w3 + (nt * 16 + l15) * ldw + lg * 8);
-            bb1[nt] = *(const float4*)(lds_b1 + nt * 16 + lg * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { xsc[j] = lds_xc[(lg * 8 + j) & (e.Kpad - 1)]; xsh[j] = lds_xc[e.Kpad + ((lg * 8 + j) & (e.Kpad - 1))]; }
-        for (int item = blockIdx.x; item < a.items; item += a.geff) {
-            int n, x0, c0;
-            dw_item(a, item, n, x0, c0);
-            cur_c0 = c0;
-            // ---- staging: staging DMA of the narrow tensors' row segments (chunk q of a staging row = chunk q of the HBM
-            // row segment: all Cin channels of iw pixels, contiguous)
-            auto stage_rows = [&](uint16_t* stage, const uint16_t* src, int row0) {
-#pragma unroll
-                for (int r = 0; r < G; ++r) {
-                    const int gy = row0 + r;
-                    if (gy < 0 || gy >= a.H) continue;                                   // uniform
-                    const uint4* rowsrc = (const uint4*)src + (((size_t)n * a.H + gy) * a.W + (ptrdiff_t)(x0 - PAD)) * cgs;
-                    uint32_t* rowdst = (uint32_t*)stage + (size_t)dw_slot<2 * G>(gy) * rcs * 4;
-                    for (int b = 0; b * 64 < rcs; ++b) {
-                        const int q = b * 64 + lane, gx = x0 - PAD + q / cgs;
-                        if (q < rcs && gx >= 0 && gx < a.W)
-                            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rowsrc + q), (lds_void_ptr)(rowdst + b * 256), 16, 0, 0);
-                    }
-                }
-            };
-            auto stage_group = [&](int r0) {          // group r0: dy rows [r0, r0+G) (-> ring_g), x rows [r0-PAD, r0-PAD+G) (-> ring_x)
-                stage_rows(stage_d, e.dy, r0);
-                stage_rows(stage_x, e.x, r0 - PAD);
-            };
-            // Ring rows of group r0 computed from the staged rows: D[c][pixel] = W[c][:] . in[pixel][:] (+ bias), rounded to bf16.
-            // Lane l15 <-> pixel pg*16 + l15 of the G x iw patch; a lane's 4 accumulators are 4 consecutive channels of that pixel.
-            // Both producers of a pixel group run together: 2 LDS reads, 2*NTB independent MFMAs back to back (weight fragments and
-            // bias live in registers for the whole kernel), then the 2*NTB pack + store epilogues.
-            auto produce_group = [&](int r0) {
-                for (int pg = 0; pg < npg; ++pg) {
-                    const int pi = pg * 16 + l15;
-                    const int pr = pi / a.iw, px = pi - pr * a.iw;
-                    const int gx = x0 - PAD + px;
-                    const bool cok = pi < G * a.iw && gx >= 0 && gx < a.W;
-                    const int gyd = r0 + pr, gyx = r0 - PAD + pr;
-                    const bool okd = cok && gyd >= 0 && gyd < a.H, okx = cok && gyx >= 0 && gyx < a.H;
-                    const int sd = dw_slot<2 * G>(okd ? gyd : 0), sx_ = dw_slot<2 * G>(okx ? gyx : 0);
-                    uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-                    if (lg * 8 < e.Cin) {
-                        if (okd) vd = *(const uint4*)(stage_d + (size_t)sd * rcs * 8 + px * e.Cin + lg * 8);
-                        if (okx) vx = *(const uint4*)(stage_x + (size_t)sx_ * rcs * 8 + px * e.Cin + lg * 8);
-                        if (has_xc && okx) vx = act8(vx, xsc, xsh);
-                    }
-                    const bf16x8_t bd = *(const bf16x8_t*)&vd, bx = *(const bf16x8_t*)&vx;
-                    f32x4_t accd[NTB], accx[NTB];
-#pragma unroll
-                    for (int nt = 0; nt < NTB; ++nt) {
-                        accd[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[nt], bd, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[nt], bx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    }
-                    uint32_t* rpd = ring_g + (size_t)sd * a.rc * 4 + (size_t)px * a.cgn * 4 + lg * 2;
-                    uint32_t* rpx = ring_x + (size_t)sx_ * a.rc * 4 + (size_t)px * a.cgn * 4 + lg * 2;
-#pragma unroll
-                    for (int nt = 0; nt < NTB; ++nt) {
-                        const bool cin_blk = nt * 16 + lg * 4 < cblk;
-                        uint2 pk;
-                        pk.x = pack_bf16(accd[nt][0], accd[nt][1]);
-                        pk.y = pack_bf16(accd[nt][2], accd[nt][3]);
-                        if (okd && cin_blk) *(uint2*)(rpd + nt * 8) = pk;
-                        pk.x = pack_bf16(accx[nt][0] + bb1[nt].x, accx[nt][1] + bb1[nt].y);
-                        pk.y = pack_bf16(accx[nt][2] + bb1[nt].z, accx[nt][3] + bb1[nt].w);
-                        if (okx && cin_blk) *(uint2*)(rpx + nt * 8) = pk;
-                    }
-                }
-            };
-
-            __syncthreads();                             // (sweep waves: previous item's last group consumed)
-            stage_group(-PAD);
-            dma_barrier();                               // staging of group 0 landed
-            if (nsteps > 1) stage_group(-PAD + G);
-            produce_group(-PAD);
-            for (int s = 0; s < nsteps; ++s) {
-                const int r0 = -PAD + s * G;
-                dma_barrier();                           // staging of group s+1 landed; readers of ring buffer (s+1)%2 retired
-                if (s + 1 < nsteps) {
-                    if (s + 2 < nsteps) stage_group(r0 + 2 * G);
-                    produce_group(r0 + G);
-                }
-            }
-        }
-      }
-    } else {
-    if constexpr (SRC) __syncthreads();                   // (producer wave: weight blocks visible)
     for (int item = blockIdx.x; item < a.items; item += a.geff) {
         int n, x0, c0;
         dw_item(a, item, n, x0, c0);
@@ -834,8 +488,6 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 rmu.x = -red_bn[5 * a.C + ch] * ris.x; rmu.y = -red_bn[5 * a.C + ch + 1] * ris.y;
             }
         }
-        f2 ge = {1.f, 1.f}, gz = zero2;
-
         DwDma plan;
         dw_dma_plan<KS>(a, plan, wave, nwaves, lane, x0, c0);
         const int gx0 = x0 + sxi * DW_BW;
@@ -857,9 +509,9 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
         // double-buffered groups of G rows (see k_dw_fwd); the x ring runs PAD rows behind g/y: row iy of dy meets row
         // oy = iy - PAD of x, and each row of either is read from LDS exactly once
         auto dma_group = [&](int r0) {
-            if constexpr (!SRC) dw_dma_rows<KS, G>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
+            dw_dma_rows<KS, G>(a, plan, ring_g, (const uint4*)d.g, n, r0, x0, c0, wave, nwaves);
             dw_dma_rows<KS, G>(a, plan, ring_y, (const uint4*)d.y, n, r0, x0, c0, wave, nwaves);
-            if constexpr (!SRC) { if (NEEDX) dw_dma_rows<KS, G>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves); }
+            if (NEEDX) dw_dma_rows<KS, G>(a, plan, ring_x, (const uint4*)x.data, n, r0 - PAD, x0, c0, wave, nwaves);
         };
         // input-gradient-only launch with the fused reduce: the raw x values of the rows it emits come from global memory,
         // fetched one group AHEAD (with the DMA, before the barrier that drains vmcnt) so that no load issued inside the
@@ -878,31 +530,14 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             }
         };
         __syncthreads();                             // previous item's last group consumed
-        if constexpr (GA) {
-            // per-item table (c1*gate, c1*bias) of this image's channel block, in LDS: the row loop fetches the pair it needs with
-            // the window reads.  As registers the two pairs pushed this 256-VGPR kernel's spill reloads (scratch = vector memory)
-            // behind the DMA issue of every row group -- a reload waits for everything older, so each group's DMA was drained
-            // before its predecessor was computed: 1.9x slower at 112x112
-            if (sxi == 0) {
-                const size_t o = (size_t)n * a.C + (ch_ok ? ch : 0);
-                const float e0 = g_gate[o], e1 = g_gate[o + 1], z0 = g_bias[o], z1 = g_bias[o + 1];
-                f2 ce, cz;
-                ce.x = ch_ok ? e0 : 1.f; ce.y = ch_ok ? e1 : 1.f;
-                cz.x = ch_ok ? z0 : 0.f; cz.y = ch_ok ? z1 : 0.f;
-                *(f2*)(lds_ga + 2 * cp) = ce * cf[2];
-                *(f2*)(lds_ga + cblk + 2 * cp) = cz * cf[2];
-            }
-        }
 #if MNAS_DW_XFILL
         if (NEEDX) dw_fill_edges<2 * G>(a, plan, ring_x, wave, nwaves, lane, has_coef);   // out-of-image columns of x act to 0
 #endif
         dma_group(-PAD);
-        if constexpr (SRC) dma_barrier();            // (producer wave: staging of group 0 landed -> it produces the rings of group 0)
         load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
             dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
-            // (SRC: the rings of group s are complete -- y by DMA, g / x produced by the producer wave during step s-1)
             if constexpr (REDG) {
 #pragma unroll
                 for (int j = 0; j < G; ++j)
@@ -930,12 +565,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 f2 xr[WIN_W];
                 if (row_in) {
                     const size_t ro = (size_t)dw_slot<2 * G>(iy) * a.rc * 4 + coloff;
-                    if constexpr (GA) {
-                        const f2 ge = *(const f2*)(lds_ga + 2 * cp), gz = *(const f2*)(lds_ga + cblk + 2 * cp);
-                        dw_read_dy<WIN_W, GM, GA>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr, ge, gz);
-                    } else {
-                        dw_read_dy<WIN_W, GM, GA>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
-                    }
+                    dw_read_dy<WIN_W, GM>(ring_g + ro, ring_y + ro, ps, cf, colmask, xr);
                 } else {
 #pragma unroll
                     for (int xx = 0; xx < WIN_W; ++xx) xr[xx] = zero2;
@@ -1011,7 +641,6 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             }
         }
     }
-    }       // sweep waves
     const int row = blockIdx.x / a.cblocks, rows = a.geff / a.cblocks;
     const int cb0 = (blockIdx.x % a.cblocks) * cblk;
     const bool any = cur_c0 >= 0;
@@ -1038,10 +667,17 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 static int dw_rings(int form) { return form < 0 ? 1 : (form == 1 ? 2 : 3); }      // form: -1 forward, else phase
 // Pick rows-per-group G in {4, 2} and the strip geometry for a launch form: 2-row groups halve the ring footprint (wider
 // strips / more channels per workgroup) at the price of a barrier every 2 rows instead of 4 (priced at 7 %).
-static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g, int exp_kpad = 0, int src_cin = 0) {
+// 5x5 forward: filter taps streamed from LDS (<= 128 VGPRs, four waves per SIMD), with at most dw5f_cap() bytes of LDS per
+// workgroup (ring + tap table): four workgroups per CU.  (Constants in the shipped build; environment switches exist only in the
+// -DMNAS_DIAG build, tools/build_alt.sh.)
+static int dw5f_wl() { static int v = -1; if (v < 0) v = mnas_diag_env("MNAS_DW5F_WL", 1); return v; }
+static size_t dw5f_cap() { static int v = -1; if (v < 0) v = mnas_diag_env("MNAS_DW5F_CAP_KB", 40); return (size_t)v * 1024; }
+static bool dw_form_wl(int k, int form) { return dw5f_wl() && k == 5 && form < 0; }
+static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g) {
     DwArgs a4, a2;
     const int nrings = dw_rings(form);
-    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4, exp_kpad, src_cin), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2, exp_kpad, src_cin);
+    const bool wl = dw_form_wl(k, form);
+    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4, wl, dw5f_cap()), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2, wl, dw5f_cap());
     if (!ok4 && !ok2) return false;
     if (ok2 && (!ok4 || 0.93f * a2.score > a4.score)) { *a = a2; *g = 2; }
     else { *a = a4; *g = 4; }
@@ -1086,89 +722,15 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     size_t lds = (size_t)2 * g * a.rc * 16;
     const size_t red_need = (size_t)a.sx * 2 * 2 * a.cpw * sizeof(float);          // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
+    const bool wl = dw_form_wl(c->k, -1);
+    if (wl) lds = (size_t)2 * g * a.rc * 16 + (size_t)a.cpw * DW_WSTRIDE;         // (the ring alone always covers red_need)
     hipStream_t s = (hipStream_t)stream;
-#define MNAS_DWF(K_, G_) hipLaunchKernelGGL((k_dw_fwd<K_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
-                                            (uint32_t*)c->out, c->stats)
-    if (c->k == 3) { if (g == 4) MNAS_DWF(3, 4); else MNAS_DWF(3, 2); }
-    else { if (g == 4) MNAS_DWF(5, 4); else MNAS_DWF(5, 2); }
+#define MNAS_DWF(K_, G_, WL_) hipLaunchKernelGGL((k_dw_fwd<K_, G_, WL_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
+                                                 (uint32_t*)c->out, c->stats)
+    if (c->k == 3) { if (g == 4) MNAS_DWF(3, 4, false); else MNAS_DWF(3, 2, false); }
+    else if (wl) { if (g == 4) MNAS_DWF(5, 4, true); else MNAS_DWF(5, 2, true); }
+    else { if (g == 4) MNAS_DWF(5, 4, false); else MNAS_DWF(5, 2, false); }
 #undef MNAS_DWF
-    MNAS_CHECK_LAUNCH();
-    return MNAS_OK;
-}
-
-// Fused expand (1x1, Cin -> C) + depthwise forward.  Geometry differs from the plain forward (LDS also holds the expand
-// weights): rows of the statistics table = mnas_dw_exp_rows(...).  Supported: Cin <= 96 (three MFMA k-steps); returns
-// MNAS_EINVAL otherwise (callers fall back to mnas_conv_gemm + mnas_dw_fwd).
-extern "C" int mnas_dw_exp_rows(int N, int H, int W, int C, int k, int Cin, int nparts) {
-    if (Cin < 8 || (Cin & 7) || Cin > 96) return -1;
-    DwArgs a;
-    int g;
-    if (!dw_choose(N, H, W, C, k, -1, &a, &g, (Cin + 31) / 32 * 32) || !dw_finish(&a, nparts)) return -1;
-    return a.geff / a.cblocks;
-}
-
-extern "C" int mnas_dw_exp_fwd(const MnasDwExpFwd* c, void* stream) {
-    if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1 || c->Cin < 8 || (c->Cin & 7) || c->Cin > 96) return MNAS_EINVAL;
-    if (!c->x.data || !c->w1 || !c->w || !c->out) return MNAS_EINVAL;
-    DwArgs a;
-    int g;
-    const int kpad = (c->Cin + 31) / 32 * 32;
-    if (!dw_choose(c->N, c->H, c->W, c->C, c->k, -1, &a, &g, kpad) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
-    a.nt = (mnas_nt_mask() & MNAS_NT_DW_FWD) ? 1 : 0;
-    DwExp e;
-    e.x = (const uint16_t*)c->x.data; e.xs = c->x.scale; e.xt = c->x.shift;
-    e.w1 = (const uint16_t*)c->w1; e.b1 = c->b1; e.y1 = (uint32_t*)c->y1; e.Cin = c->Cin; e.Kpad = kpad;
-    MnasActIn in = {nullptr, c->bn1_scale, c->bn1_shift};
-    size_t lds = (size_t)2 * g * a.rc * 16 + dw_exp_lds(a.cpw, kpad);
-    const size_t red_need = (size_t)a.sx * 2 * 2 * a.cpw * sizeof(float);
-    if (lds < red_need) lds = red_need;
-    hipStream_t s = (hipStream_t)stream;
-    const int kst = kpad / 32;
-#define MNAS_DWE(K_, G_, T_) hipLaunchKernelGGL((k_dw_fwd_exp<K_, G_, T_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, e, in, c->w, \
-                                               c->bias, (uint32_t*)c->out, c->stats)
-#define MNAS_DWE_T(K_, G_) do { if (kst == 1) MNAS_DWE(K_, G_, 1); else if (kst == 2) MNAS_DWE(K_, G_, 2); else MNAS_DWE(K_, G_, 3); } while (0)
-    if (c->k == 3) { if (g == 4) MNAS_DWE_T(3, 4); else MNAS_DWE_T(3, 2); }
-    else { if (g == 4) MNAS_DWE_T(5, 4); else MNAS_DWE_T(5, 2); }
-#undef MNAS_DWE_T
-#undef MNAS_DWE
-    MNAS_CHECK_LAUNCH();
-    return MNAS_OK;
-}
-
-// SRC form: geometry / partial-table rows (both tables of the launch, like which = 1 of mnas_dw_rows)
-static bool dw_src_ok(int C, int cin) { return cin >= 8 && !(cin & 7) && cin <= 32 && !(C & 7); }
-extern "C" int mnas_dw_src_rows(int N, int H, int W, int C, int k, int cin, int nparts) {
-    if (!dw_src_ok(C, cin) || (k != 3 && k != 5)) return -1;
-    DwArgs a;
-    int g;
-    if (!dw_choose(N, H, W, C, k, 0, &a, &g, 32, cin) || !dw_finish(&a, nparts)) return -1;
-    const int ntb = (2 * a.cpw + 15) / 16;
-    if (ntb != 3 && ntb != 5) return -1;
-    return a.geff / a.cblocks;
-}
-static int dw_bwd_src(const MnasDwBwd* c, hipStream_t s) {
-    if (c->phase != 0 || !c->red_bn || !c->red_partial || !dw_src_ok(c->C, c->src_cin)) return MNAS_EINVAL;
-    if (!c->src_x.data || !c->src_w1 || !c->src_w3t || !c->dy.y || !c->dy.coef || !c->w || !c->gin || !c->wpartial) return MNAS_EINVAL;
-    DwArgs a;
-    int g;
-    if (!dw_choose(c->N, c->H, c->W, c->C, c->k, 0, &a, &g, 32, c->src_cin) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
-    a.nt = (mnas_nt_mask() & MNAS_NT_DW_BWD) ? 1 : 0;
-    DwSrc e;
-    e.x = (const uint16_t*)c->src_x.data; e.xs = c->src_x.scale; e.xt = c->src_x.shift;
-    e.w1 = (const uint16_t*)c->src_w1; e.b1 = c->src_b1; e.dy = (const uint16_t*)c->src_dy; e.w3t = (const uint16_t*)c->src_w3t;
-    e.Cin = c->src_cin; e.Kpad = 32;
-    size_t lds = (size_t)3 * 2 * g * a.rc * 16 + dw_src_lds(a.cpw, 32, 2 * g, a.iw, c->src_cin);
-    const size_t red_need = (size_t)a.sx * c->k * c->k * 2 * a.cpw * sizeof(float);
-    if (lds < red_need) lds = red_need;
-    const int ntb = (2 * a.cpw + 15) / 16;
-    if (ntb != 3 && ntb != 5) return MNAS_EINVAL;          // 48- and 72-channel blocks (the 112x112 / 56x56 stages)
-#define MNAS_DWS(K_, G_, T_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, true, T_>), dim3(a.geff), dim3(a.nthreads + 64), lds, s, a, \
-                                                c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, e)
-#define MNAS_DWS_T(K_, G_) do { if (ntb == 3) MNAS_DWS(K_, G_, 3); else MNAS_DWS(K_, G_, 5); } while (0)
-    if (c->k == 3) { if (g == 4) MNAS_DWS_T(3, 4); else MNAS_DWS_T(3, 2); }
-    else { if (g == 4) MNAS_DWS_T(5, 4); else MNAS_DWS_T(5, 2); }
-#undef MNAS_DWS_T
-#undef MNAS_DWS
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
@@ -1176,7 +738,6 @@ static int dw_bwd_src(const MnasDwBwd* c, hipStream_t s) {
 extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1 || c->phase < 0 || c->phase > 2) return MNAS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (c->src_dy) return dw_bwd_src(c, s);
     if (!c->x.data || !c->dy.g) return MNAS_EINVAL;
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;
     // phase 0: everything in one fused sweep.  phase 1: input gradient (+reduce).  phase 2: weight gradient.
@@ -1190,24 +751,12 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     const size_t red_need = (size_t)a.sx * (want_wg ? c->k * c->k : 2) * 2 * a.cpw * sizeof(float);   // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
 #define MNAS_DWB(K_, DG_, WG_, R_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
-                                                         c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{})
+                                                         c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
 #define MNAS_DWB_G(K_, DG_, WG_, R_) do { if (g == 4) MNAS_DWB(K_, DG_, WG_, R_, 4); else MNAS_DWB(K_, DG_, WG_, R_, 2); } while (0)
-    if (c->g_gate) {                         // g read as g*g_gate[n][c] + g_bias[n][c]: fused sweep only
-        if (!(want_dg && want_wg && red) || c->g_masked || !c->g_bias) return MNAS_EINVAL;
-        lds = (size_t)nrings * 2 * g * a.rc * 16 + (size_t)4 * a.cpw * sizeof(float);      // + the per-item (gate, bias) table
-        if (lds < red_need) lds = red_need;
-#define MNAS_DWA(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, false, 1, false, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
-                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{}, c->g_gate, c->g_bias)
-        if (c->k == 3) { if (g == 4) MNAS_DWA(3, 4); else MNAS_DWA(3, 2); }
-        else { if (g == 4) MNAS_DWA(5, 4); else MNAS_DWA(5, 2); }
-#undef MNAS_DWA
-        MNAS_CHECK_LAUNCH();
-        return MNAS_OK;
-    }
     if (c->g_masked) {                       // fused sweep only (what the engine runs behind a project conv's masked gradient)
         if (!(want_dg && want_wg && red)) return MNAS_EINVAL;
-#define MNAS_DWM(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, false, 1, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
-                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn, DwSrc{})
+#define MNAS_DWM(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
+                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
         if (c->k == 3) { if (g == 4) MNAS_DWM(3, 4); else MNAS_DWM(3, 2); }
         else { if (g == 4) MNAS_DWM(5, 4); else MNAS_DWM(5, 2); }
 #undef MNAS_DWM

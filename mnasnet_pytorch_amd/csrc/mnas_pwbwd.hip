@@ -18,10 +18,7 @@
 //   reduce  per tile: 16-lane shuffle tree, then one LDS slot per (wave, channel) -- fixed order, no atomics.
 // Roofline: HBM.  MFMA work per tile is ~0.3 us against ~5 us of memory time.
 //
-// FORM (round 4, the spatially tiled fused inverted-residual block: the expanded tensors y1 / g2 never reach HBM):
-//   1 "NOGIN"  project conv: the input gradient g2 = dy3 . W3 is formed and bf16-rounded exactly as FORM 0 stores it, but only
-//              REDUCED (BatchNorm2-backward sums) -- the store is gone (a third of the launch's traffic); the staged dy tile
-//              can be written out (dy_out: dy3 materialised for k_dw_bwd's SRC form, which re-forms g2 row by row).
+// FORM (round 4; forms 1 "NOGIN" and 3 "RED4" lost their A/B and were removed in round 5 -- DESIGN_HISTORY.md):
 //   2 "RECOMP" expand conv: dy-on-load's raw forward output y1 is not read: after the x tile is staged, y1 = bf16(W1 act(x) + b1)
 //              is recomputed on the matrix cores (same MFMA, same k order as the forward -> the same bits) and dy is formed
 //              in place over the raw g tile.  One more barrier per tile; a third of the launch's reads gone.
@@ -42,13 +39,11 @@ struct PwBwdArgs {
     const void* red_y;
     const float* red_bn;
     int nt;                  // nontemporal gin stores
-    void* dy_out;            // FORM 1: materialised dy (M,Co) or NULL
     const uint16_t* w_fwd;   // FORM 2: MNAS_PACK_FWD [round16(Co)][Kf]
     const float* b_fwd;      // FORM 2: [Co] or NULL
     int Kf;                  // FORM 2: Ci rounded up to 32
     int gin_masked;          // out-stage forms: store dz = gin*[s*x+t>0] (the fused reduce's mask) instead of gin
     int seg_px;              // > 0: segment mode (see the tile walk)
-    int red4;                // FORM 3: four reduce sums (see below)
 };
 
 __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int row0, int col0, int lane) {
@@ -67,11 +62,7 @@ __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int
 // (partial lines) sustained 2-2.4 TB/s of writes; the same change took the widening forward convs from 2.4 to 4.7 TB/s.
 template <int NTO, int NTI, int PT, bool OS, int FORM>
 __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
-    // FORM 3 ("RED4", out-stage forms): the fused reduce keeps FOUR sums per channel under red_bn -- sum g*m, sum g*m*xhat, sum m,
-    // sum m*xhat with m = [s*x+t > 0] -- red_partial float[4][Ci][P].  With segment mode a workgroup is a fraction of one image, and
-    // the BatchNorm-backward sums of ANY per-(image, channel) affine map of g, (g*e[n][c] + z[n][c])*m, follow from the table
-    // without another pass over (g, x): sum dz = e*R0 + z*R2, sum dz*xhat = e*R1 + z*R3 (csrc/mnas_se.hip k_se_bn_assemble).
-    static_assert(FORM == 0 || (FORM == 1 && OS) || (FORM == 2 && !OS) || (FORM == 3 && OS), "NOGIN / RED4 ride on the out-stage path, RECOMP on the plain epilogue");
+    static_assert(FORM == 0 || (FORM == 2 && !OS), "RECOMP rides on the plain epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BP = 64 * PT;
     constexpr int COP = NTO * 16, CIP = NTI * 16;
@@ -182,11 +173,9 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     // OS copy-out role: thread -> fixed 16-byte channel column c8 of the out-stage rows orow0 + k*OROWS
     const int oc8 = tid % NCH8, orow0 = tid / NCH8;
     const bool ocol_ok = tid < TCOLS && oc8 * 8 < cis;
-    float r1[8], r2[8], r3[FORM == 3 ? 8 : 1], r4[FORM == 3 ? 8 : 1];
+    float r1[8], r2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < (FORM == 3 ? 8 : 1); ++j) { r3[j] = 0.f; r4[j] = 0.f; }
     constexpr bool REGSTAT = NTI <= 6;
     float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
 #pragma unroll
@@ -234,10 +223,6 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 float o[8];
                 dy8(vg[i], vy[i], cf[0], cf[1], cf[2], cf[3], cf[4], o);
                 v = pack8(o);
-                if constexpr (FORM == 1) {
-                    if (a.dy_out && blockIdx.y == 0)
-                        *(uint4*)((uint16_t*)a.dy_out + (size_t)(tile0 + pd[i]) * a.Co + cd8[i] * 8) = v;
-                }
             }
             *(uint4*)(tile_d + pd[i] * ldd + cd8[i] * 8) = v;
         }
@@ -399,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                 if (!(ocol_ok && p < BP && tile0 + p < mend)) continue;
                 const uint4 pk = *(const uint4*)(tile_a + p * lda + oc8 * 8);
                 uint16_t* gdst = (uint16_t*)a.gin + ((size_t)(tile0 + p) * a.Ci + ci0 + oc8 * 8);
-                if (FORM != 1 && !a.gin_masked) st_u4(gdst, pk, true);
+                if (!a.gin_masked) st_u4(gdst, pk, true);
                 if (do_red) {                                // channel pairs in float2 (v_pk_fma_f32); same operations as the scalar form
                     const uint32_t gu[4] = {pk.x, pk.y, pk.z, pk.w}, yu[4] = {vx[k].x, vx[k].y, vx[k].z, vx[k].w};
                     uint32_t mz[4];
@@ -415,16 +400,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
                         const mnas_f2 a1 = mnas_ld2(r1 + 2 * j) + dz, a2 = mnas_f2fma(dz, xh, mnas_ld2(r2 + 2 * j));
                         r1[2 * j] = a1.x; r1[2 * j + 1] = a1.y;
                         r2[2 * j] = a2.x; r2[2 * j + 1] = a2.y;
-                        if constexpr (FORM == 3) {
-                            mnas_f2 mk;
-                            mk.x = (z.x > 0.f) ? 1.f : 0.f;
-                            mk.y = (z.y > 0.f) ? 1.f : 0.f;
-                            const mnas_f2 a3 = mnas_ld2(r3 + 2 * j) + mk, a4 = mnas_f2fma(mk, xh, mnas_ld2(r4 + 2 * j));
-                            r3[2 * j] = a3.x; r3[2 * j + 1] = a3.y;
-                            r4[2 * j] = a4.x; r4[2 * j + 1] = a4.y;
-                        }
                     }
-                    if (FORM != 1 && a.gin_masked) st_u4(gdst, make_uint4(mz[0], mz[1], mz[2], mz[3]), true);
+                    if (a.gin_masked) st_u4(gdst, make_uint4(mz[0], mz[1], mz[2], mz[3]), true);
                 }
             }
             continue;
@@ -521,18 +498,6 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             for (int th = c >> 3; th < TCOLS; th += NCH8) v += fin[th * 16 + r * 8 + (c & 7)];
             if (c < cis) a.red_partial[((size_t)r * a.Ci + ci0 + c) * gridDim.x + blockIdx.x] = v;   // [2][Ci][P]
         }
-        if constexpr (FORM == 3) {                           // rows 2, 3 of float[4][Ci][P]: second pass through the same scratch
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { fin[tid * 16 + j] = r3[j]; fin[tid * 16 + 8 + j] = r4[j]; }
-            __syncthreads();
-            for (int i = tid; i < 2 * CIP; i += 256) {
-                const int r = i / CIP, c = i % CIP;
-                float v = 0.f;
-                for (int th = c >> 3; th < TCOLS; th += NCH8) v += fin[th * 16 + r * 8 + (c & 7)];
-                if (c < cis) a.red_partial[((size_t)(2 + r) * a.Ci + ci0 + c) * gridDim.x + blockIdx.x] = v;
-            }
-        }
     } else if (do_red) {
         if (REGSTAT) {
 #pragma unroll
@@ -566,7 +531,7 @@ static int pw_bwd_outstage() {
 template <int NTO, int NTI, int PT>
 static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int nslices = 1) {
     constexpr int BP = 64 * PT, COP = NTO * 16, CIP = NTI * 16;
-    const bool nogin = a.gin == nullptr, recomp = a.dy.y == nullptr;
+    const bool recomp = a.dy.y == nullptr;
     size_t lds = (size_t)(5 * COP + 14 * CIP) * sizeof(float) +
                  ((size_t)CIP * (a.Kd + 8) + (size_t)BP * (a.Kd + 8) + (size_t)BP * (CIP + 8)) * 2;
     if (recomp) lds += (size_t)COP * (a.Kf + 8) * 2 + (size_t)COP * sizeof(float);
@@ -578,28 +543,13 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
         // the out-stage forms reduce against the x chunks they staged: red_y must BE x.data (it is for a project conv: the
         // reduce target is the depthwise conv that produced x); anything else takes the plain epilogue below
         const bool redx = !a.red_partial || a.red_y == a.x.data;
-        if constexpr (NTI > NTO && NTO <= 3) {                // FORM 1 (project convs of the tiled fused block) rides on the out-stage path
-            if (nogin) {
-                if (a.resid || !a.red_partial || !redx) return MNAS_EINVAL;
-                hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 1>), dim3(nparts, nslices), dim3(256), lds, stream, a);
-                MNAS_CHECK_LAUNCH();
-                return MNAS_OK;
-            }
-        }
-        if (nogin) return MNAS_EINVAL;
-        if (a.red4) {
-            if (!a.red_partial || !redx || a.resid || a.gin_masked) return MNAS_EINVAL;
-            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 3>), dim3(nparts, nslices), dim3(256), lds, stream, a);
-            MNAS_CHECK_LAUNCH();
-            return MNAS_OK;
-        }
         if (pw_bwd_outstage() >= (NTI == NTO ? 2 : 1) && !a.resid && redx) {
             hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 0>), dim3(nparts, nslices), dim3(256), lds, stream, a);
             MNAS_CHECK_LAUNCH();
             return MNAS_OK;
         }
     }
-    if (nogin) return MNAS_EINVAL;
+    if (a.gin_masked) return MNAS_EINVAL;                     // only the out-stage kernel masks (a -DMNAS_DIAG build can switch it off)
     if constexpr (NTO > NTI && NTI <= 2) {                    // the expand convs of the 112x112 / 56x56 stages
         if (recomp) {
             hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false, 2>), dim3(nparts, nslices), dim3(256), lds, stream, a);
@@ -634,12 +584,12 @@ extern "C" int mnas_pw_bwd_supported(int Ci, int Co) { return pw_cfg(Ci, Co) ? 1
 // pixels per tile / channel slices (grid.y) of the launch for this channel pair: what a caller sizing MnasPwBwd.seg_px needs
 extern "C" int mnas_pw_bwd_tile_pixels(int Ci, int Co) { const PwCfg* c = pw_cfg(Ci, Co); return c ? 64 * c->pt : -1; }
 extern "C" int mnas_pw_bwd_slices(int Ci, int Co) { const PwCfg* c = pw_cfg(Ci, Co); return c ? c->nslices : -1; }
-// bit 0: NOGIN (gin == NULL) available, bit 1: RECOMP (dy.y == NULL + w_fwd) available -- mirrors launch_pw_bwd's dispatch
+// bit 1: RECOMP (dy.y == NULL + w_fwd) available, bit 2: out-stage form (gin_masked) -- mirrors launch_pw_bwd's dispatch (bit 0 was
+// the NOGIN form, removed in round 5)
 extern "C" int mnas_pw_bwd_forms(int Ci, int Co) {
     const PwCfg* c = pw_cfg(Ci, Co);
     if (!c) return 0;
     int f = 0;
-    if (c->nti_slice > c->nto && c->nti_slice >= 3 && c->nto <= 3) f |= 1;
     if (c->nto > c->nti_slice && c->nti_slice <= 2 && c->nslices == 1) f |= 2;
     if ((c->nti_slice > c->nto && c->nti_slice >= 3) || (c->nti_slice == c->nto && c->nti_slice >= 5)) f |= 4;     // out-stage form
     return f;
@@ -647,20 +597,17 @@ extern "C" int mnas_pw_bwd_forms(int Ci, int Co) {
 
 extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     if (!c || c->M < 1 || c->nparts < 1 || c->nparts > 65535 || !mnas_pw_bwd_supported(c->Ci, c->Co)) return MNAS_EINVAL;
-    if (!c->x.data || !c->dy.g || !c->dy.coef || !c->w || !c->wpartial) return MNAS_EINVAL;
+    if (!c->x.data || !c->dy.g || !c->dy.coef || !c->w || !c->wpartial || !c->gin) return MNAS_EINVAL;
     if (!c->dy.y && !c->w_fwd) return MNAS_EINVAL;           // RECOMP needs the forward weights
-    if (!c->gin && !c->red_partial) return MNAS_EINVAL;      // NOGIN: the input gradient is only reduced
     if (c->red_partial && (!c->red_bn || !c->red_y)) return MNAS_EINVAL;
     PwBwdArgs a;
     a.M = c->M; a.Ci = c->Ci; a.Co = c->Co; a.Kd = (c->Co + 31) / 32 * 32;
     a.x = c->x; a.dy = c->dy; a.w = (const uint16_t*)c->w; a.resid = c->resid; a.gin = c->gin;
     a.wpartial = c->wpartial; a.red_partial = c->red_partial; a.red_y = c->red_y; a.red_bn = c->red_bn;
     a.nt = (mnas_nt_mask() & MNAS_NT_PW_BWD) ? 1 : 0;
-    a.dy_out = c->dy_out; a.w_fwd = (const uint16_t*)c->w_fwd; a.b_fwd = c->b_fwd; a.Kf = (c->Ci + 31) / 32 * 32;
+    a.w_fwd = (const uint16_t*)c->w_fwd; a.b_fwd = c->b_fwd; a.Kf = (c->Ci + 31) / 32 * 32;
     a.gin_masked = c->gin_masked;
     a.seg_px = c->seg_px;
-    a.red4 = c->red4;
-    if (a.red4 && !(mnas_pw_bwd_forms(c->Ci, c->Co) & 4)) return MNAS_EINVAL;
     if (a.seg_px < 0 || (a.seg_px > 0 && ((int64_t)a.seg_px * c->nparts < c->M || (int64_t)a.seg_px * (c->nparts - 1) >= c->M))) return MNAS_EINVAL;
     if (a.gin_masked && (!c->red_partial || c->resid || c->red_y != c->x.data || !(mnas_pw_bwd_forms(c->Ci, c->Co) & 4))) return MNAS_EINVAL;
     const PwCfg* cfg = pw_cfg(c->Ci, c->Co);

@@ -219,37 +219,6 @@ extern "C" int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, i
     return MNAS_OK;
 }
 
-// BatchNorm2-backward sums of dz2 = (gs*e + z)*m per image from the project conv's four per-image sums (k_pw_bwd FORM 3):
-//     red[0][c][n] = e*R0 + z*R2,  red[1][c][n] = e*R1 + z*R3,  R_r = sum_j part4[r][c][n*kseg + j],  e = gate[n][c], z = dz[n][c]/HW
-__global__ __launch_bounds__(256) void k_se_bn_assemble(const float* __restrict__ part4, int N, int kseg, int C, const float* __restrict__ gate,
-                                                        const float* __restrict__ dz, float inv_hw, float* __restrict__ g_bias,
-                                                        float* __restrict__ red) {
-    const int i = blockIdx.x * 256 + threadIdx.x;            // i = c * N + n: consecutive threads read consecutive table columns
-    if (i >= N * C) return;
-    const int c = i / N, n = i - c * N;
-    const size_t P = (size_t)N * kseg;
-    float R[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float* src = part4 + ((size_t)r * C + c) * P + (size_t)n * kseg;
-        float v = src[0];
-        for (int j = 1; j < kseg; ++j) v += src[j];
-        R[r] = v;
-    }
-    const float e = gate[(size_t)n * C + c], z = dz[(size_t)n * C + c] * inv_hw;
-    g_bias[(size_t)n * C + c] = z;
-    red[((size_t)0 * C + c) * N + n] = fmaf(e, R[0], z * R[2]);
-    red[((size_t)1 * C + c) * N + n] = fmaf(e, R[1], z * R[3]);
-}
-extern "C" int mnas_se_bn_assemble(const float* part4, int N, int kseg, int C, const float* gate, const float* dz, int HW, float* g_bias,
-                                   float* red, void* stream) {
-    if (!part4 || !gate || !dz || !g_bias || !red || N < 1 || kseg < 1 || C < 1 || HW < 1) return MNAS_EINVAL;
-    hipLaunchKernelGGL(k_se_bn_assemble, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part4, N, kseg, C, gate, dz,
-                       1.f / (float)HW, g_bias, red);
-    MNAS_CHECK_LAUNCH();
-    return MNAS_OK;
-}
-
 // pixel splits per image: enough workgroups to fill the chip (>= ~2048), whole multiples of R pixels each
 static bool se_geom(int N, int HW, int C, SeGeom* g, int* splits) {
     if (N < 1 || HW < 1 || C < 8 || (C & 7) || C > 2048) return false;

@@ -252,7 +252,6 @@ class Program:
 
 
         self._se_records = {}    # record index of a project conv -> its block's squeeze-excite tensors
-        self._irb_blocks = {}    # index of the expand conv's record -> (Gram sums, image groups) of a fused block application
         step_records = []
         for op, m, stage in steps:
             start = len(records)
@@ -263,26 +262,13 @@ class Program:
                 step_records.append(("conv", stage, start, None, None))
             else:
                 a_in = cur
-                h = None
                 cis = [eng.info[id(cb)] for cb in m]
-                is_irb = len(cis) == 3 and cis[0].kind == "pw" and cis[1].kind == "dw" and cis[2].kind == "pw"
-                if eng.fuse_irb and is_irb and id(m[0]) not in eng.se_info:
-                    h = self._block_fwd_irb(cis[0], cis[1], a_in, Hc, Wc)
-                    if h is not None:
-                        h = self._conv_fwd(cis[2], h, Hc, Wc)
-                if h is None and eng.fuse_expand and is_irb and id(m[0]) not in eng.se_info:
-                    h = self._block_fwd_fused(cis[0], cis[1], a_in, Hc, Wc)
-                    if h is not None:
-                        h = self._conv_fwd(cis[2], h, Hc, Wc)
                 se = eng.se_info.get(id(m[0]))
-                if se is not None:
-                    h = None                                # SE blocks run per layer (the fused paths have no SE stage)
-                if h is None:
-                    h = cur
-                    for j_, ci_ in enumerate(cis):
-                        if j_ == 2 and se is not None:
-                            h = self._se_fwd(se, h, Hc, Wc, ci_)
-                        h = self._conv_fwd(ci_, h, Hc, Wc)
+                h = cur
+                for j_, ci_ in enumerate(cis):
+                    if j_ == 2 and se is not None:
+                        h = self._se_fwd(se, h, Hc, Wc, ci_)
+                    h = self._conv_fwd(ci_, h, Hc, Wc)
                 r = self._new((N, Hc, Wc, a_in.C))
                 fwd.add(L.OP_ADD_ACT, [a_in.C, Hc * Wc], [float(N * Hc * Wc)],
                         a_in.act_ptrs() + h.act_ptrs() + [r.data_ptr(), None])
@@ -343,7 +329,6 @@ class Program:
 
 
         self._masked_g = set()       # data_ptr of gradient tensors stored masked (dz) by their producer
-        self._g_affine = {}          # data_ptr of a gradient tensor -> (gate, bias) fp32 [N][C]: read as g*gate + bias (squeeze-excite)
         g = g_final
         g_red = 0            # number of fused-reduce partial columns already written for the layer g belongs to
         self.patch_x_bwd = None
@@ -365,22 +350,12 @@ class Program:
             else:
                 re_, rd, rp = records[start], records[start + 1], records[start + 2]
                 G = g                                   # grad wrt the block output (materialised sum)
-                if start in self._irb_blocks:
-                    if not merge:
-                        raise NotImplementedError("the fused block backward needs Engine.merge_post")
-                    g = self._block_bwd_irb(ops, start, G, g_red, (not first) or need_dx)
-                    g_red = 0
-                    continue
                 se_rec = self._se_records.get(start + 2)
                 if se_rec is not None and se_rec[5]:
                     # excitation on load: the project conv's backward runs on the UNGATED activation in segment mode; its
                     # weight-gradient slabs give du and (gated) dW3 without a pass over gs / a2 (csrc/mnas_se.hip)
-                    # ... and, with Engine.se_affine_on_read, four per-image reduce sums from which the BatchNorm2-backward sums
-                    # are assembled once the excite MLP's backward is through; the depthwise backward then reads gs*s + dz/HW on
-                    # the fly: no k_se_bwd_apply pass either
-                    r4 = bool(eng.se_affine_on_read and rd[1].kind == "dw" and rd[1].k in eng.dw_fused_k and N <= _STATS_PARTS)
-                    gs_, du_, part4 = self._conv_bwd_se_proj(ops, rp, G, g_red, se_rec, r4)
-                    g2, c2 = self._se_bwd(ops, start + 2, gs_, du_, part4)
+                    gs_, du_ = self._conv_bwd_se_proj(ops, rp, G, g_red, se_rec)
+                    g2, c2 = self._se_bwd(ops, start + 2, gs_, du_)
                 else:
                     g2, c2 = self._conv_bwd(ops, rp, G, None, True, g_red, self._target_of(rp[2]))
                     if se_rec is not None:
@@ -481,104 +456,6 @@ class Program:
         out = _Act(y, bn, Ho, Wo, ci.cout)
         records.append(("conv", ci, a_in, out, Hi, Wi))
         return out
-
-    def _block_fwd_fused(self, e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
-        """expand (1x1) + depthwise of an MBConv_block in ONE kernel (csrc/mnas_dw.hip, EXP forms): the expand conv's
-        BatchNorm statistics come from the covariance of the block input (csrc/mnas_gram.hip), so the expanded tensor
-        is produced straight into the depthwise kernel's LDS rings.  It is still written to HBM in training (backward
-        reads it); in eval mode it never leaves the chip.  Returns the depthwise output, or None if unsupported."""
-        eng, lib, dev, N, H, W, training = self.eng, self.eng.lib, self.eng.device, self.N, self.H, self.W, self.training
-        new, bnbuf, fwd, records = self._new, self._bnbuf, self._fwd, self._records
-        M = N * Hi * Wi
-        C_, k = d_ci.cout, d_ci.k
-        nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * C_, 256 * 16 * 2)))
-        rows = lib.mnas_dw_exp_rows(N, Hi, Wi, C_, k, e_ci.cin, nlaunch)
-        if rows < 1:
-            return None
-        econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
-        bn_e, bn_d = bnbuf(C_), bnbuf(C_)
-        if training:
-            nsplit = max(1, min(512, _cdiv(M, 2048)))
-            gsc = eng.gram_scratch(e_ci.cin, nsplit)
-            gd = torch.empty(e_ci.cin * e_ci.cin + e_ci.cin, dtype=torch.float64, device=dev)
-            self.keep.append(gd)
-            fwd.add(L.OP_GRAM, [e_ci.cin, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
-            fwd.add(L.OP_GRAM_BN, [nsplit, e_ci.cin, C_], [float(M), ebn.momentum, ebn.eps],
-                    [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
-                     econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
-                     ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
-                     gd.data_ptr(), bn_e.data_ptr()])
-        else:
-            fwd.add(L.OP_BN_FWD_FINALIZE, [1, C_, 0], [float(M), ebn.momentum, ebn.eps],
-                    [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
-                     ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
-        y1 = new((N, Hi, Wi, C_)) if training else None
-        y2 = new((N, Hi, Wi, C_))
-        stats = eng.scratch_stats.data_ptr() if training else None
-        fwd.add(L.OP_DW_EXP_FWD, [N, Hi, Wi, C_, k, e_ci.cin, nlaunch], [],
-                a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                                   bn_e.data_ptr(), bn_e.data_ptr() + 4 * C_, d_ci.w_fwd.data_ptr(),
-                                   dconv.bias.data_ptr() if dconv.bias is not None else None,
-                                   y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
-        fwd.add(L.OP_BN_FWD_FINALIZE, [rows, C_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
-                [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
-                 dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
-        h1 = _Act(y1, bn_e, Hi, Wi, C_)
-        h2 = _Act(y2, bn_d, Hi, Wi, C_)
-        records.append(("conv", e_ci, a_in, h1, Hi, Wi))
-        records.append(("conv", d_ci, h1, h2, Hi, Wi))
-        return h2
-
-    def _block_fwd_irb(self, e_ci: _ConvInfo, d_ci: _ConvInfo, a_in: _Act, Hi, Wi):
-        """expand + depthwise of an MBConv_block on the small maps (csrc/mnas_irb.hip): the expanded tensor y1 is NEVER written;
-        backward recomputes it (csrc/mnas_irb_bwd.hip).  BatchNorm1's statistics come from the covariance of the block input
-        (csrc/mnas_gram.hip); the Gram sums are kept for the expand conv's weight gradient.  Returns the depthwise output, or
-        None if the shape is not supported (then the per-layer kernels run)."""
-        eng, lib, dev, N, H, W, training = self.eng, self.eng.lib, self.eng.device, self.N, self.H, self.W, self.training
-        new, bnbuf, fwd, records = self._new, self._bnbuf, self._fwd, self._records
-        C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
-        if e_ci.cout != E_ or not lib.mnas_irb_supported(N, Hi, Wi, C_, E_, k):
-            return None
-        M = N * Hi * Wi
-        econv, ebn, dconv, dbn = e_ci.mod.conv, e_ci.mod.bn, d_ci.mod.conv, d_ci.mod.bn
-        bn_e, bn_d = bnbuf(E_), bnbuf(E_)
-        gd = None
-        if training:
-            nsplit = max(1, min(128, _cdiv(M, 1024)))
-            gsc = eng.gram_scratch(C_, nsplit)
-            gd = torch.empty(C_ * C_ + C_, dtype=torch.float64, device=dev)       # G = sum a a^T, Sx = sum a (kept for backward)
-            self.keep.append(gd)
-            fwd.add(L.OP_GRAM, [C_, nsplit], [float(M)], a_in.act_ptrs() + [gsc[0].data_ptr(), gsc[1].data_ptr()])
-            fwd.add(L.OP_GRAM_BN, [nsplit, C_, E_], [float(M), ebn.momentum, ebn.eps],
-                    [gsc[0].data_ptr(), gsc[1].data_ptr(), econv.weight.data_ptr(),
-                     econv.bias.data_ptr() if econv.bias is not None else None, ebn.weight.data_ptr(), ebn.bias.data_ptr(),
-                     ebn.running_mean.data_ptr(), ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(),
-                     gd.data_ptr(), bn_e.data_ptr()])
-        else:
-            fwd.add(L.OP_BN_FWD_FINALIZE, [1, E_, 0], [float(M), ebn.momentum, ebn.eps],
-                    [None, ebn.weight.data_ptr(), ebn.bias.data_ptr(), ebn.running_mean.data_ptr(),
-                     ebn.running_var.data_ptr(), ebn.num_batches_tracked.data_ptr(), bn_e.data_ptr()])
-        nparts = lib.mnas_irb_fwd_parts(N, Hi, Wi, C_, E_, k, max(1, eng.irb_workgroups // (E_ // 32)))
-        # "fwd" mode: the fused kernel also stores y1 and the per-layer backward kernels run (they read y1 and g2)
-        keep_y1 = training and eng.fuse_irb == "fwd"
-        y1 = new((N, Hi, Wi, E_)) if keep_y1 else None
-        y2 = new((N, Hi, Wi, E_))
-        stats = eng.scratch_stats.data_ptr() if training else None
-        fwd.add(L.OP_IRB_FWD, [N, Hi, Wi, C_, E_, k, nparts], [],
-                a_in.act_ptrs() + [e_ci.w_fwd.data_ptr(), econv.bias.data_ptr() if econv.bias is not None else None,
-                                   bn_e.data_ptr(), d_ci.w_fwd.data_ptr(),
-                                   dconv.bias.data_ptr() if dconv.bias is not None else None,
-                                   y1.data_ptr() if y1 is not None else None, y2.data_ptr(), stats])
-        fwd.add(L.OP_BN_FWD_FINALIZE, [nparts, E_, 1 if training else 0], [float(M), dbn.momentum, dbn.eps],
-                [stats, dbn.weight.data_ptr(), dbn.bias.data_ptr(), dbn.running_mean.data_ptr(),
-                 dbn.running_var.data_ptr(), dbn.num_batches_tracked.data_ptr(), bn_d.data_ptr()])
-        h1 = _Act(y1, bn_e, Hi, Wi, E_)                      # full mode: the expanded activation exists only on chip
-        h2 = _Act(y2, bn_d, Hi, Wi, E_)
-        records.append(("conv", e_ci, a_in, h1, Hi, Wi))
-        records.append(("conv", d_ci, h1, h2, Hi, Wi))
-        if training and not keep_y1:
-            self._irb_blocks[len(records) - 2] = (gd, nparts)
-        return h2
 
     def _se_onload_kseg(self, p_ci: _ConvInfo, h2: _Act, Hi, Wi):
         """Workgroups per image of the project conv's segment-mode backward when the excitation can be applied ON LOAD for this
@@ -726,19 +603,14 @@ class Program:
                 gm = 1 if g.data_ptr() in self._masked_g else 0
                 if gm and rt is None:
                     raise AssertionError("masked gradient handed to a depthwise backward without the fused reduce")
-                aff = self._g_affine.get(g.data_ptr())
-                if aff is not None:
-                    if rt is None or gm:
-                        raise AssertionError("gradient with an on-read affine map needs the plain fused sweep with its reduce")
-                    dwp = dwp + [aff[0].data_ptr(), aff[1].data_ptr()]
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 0, 0, gm], [], dwp, 0)
                 if merge:
                     self._queue_wgrad(ops, wsc.data_ptr(), wrows, Co, 1, ci.k * ci.k, True, eng.gptr(ci, 0))
                 else:
                     ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad2.data_ptr(), eng.gptr(ci, 0)], 0)
             else:
-                if g.data_ptr() in self._masked_g or g.data_ptr() in self._g_affine:
-                    raise AssertionError("masked / on-read-affine gradient handed to the two-launch depthwise backward")
+                if g.data_ptr() in self._masked_g:
+                    raise AssertionError("masked gradient handed to the two-launch depthwise backward")
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2], [], dwp, WS)          # weight gradient
                 ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
                 ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1], [], dwp, 0)           # input gradient
@@ -832,57 +704,6 @@ class Program:
             raise AssertionError("residual add into a depthwise dgrad does not occur")
         return gin, ncols
 
-    def _block_bwd_irb(self, ops: _OpList, start, G, g_reduced, need_gin):
-        """Backward of a fused block application (csrc/mnas_irb_bwd.hip): three launches separated by the BatchNorm-backward
-        finalizes; g2 and y1 never exist in HBM.  Returns the gradient of the block input (skip gradient included) or None."""
-        eng, lib, N, merge, pend, records = self.eng, self.eng.lib, self.N, self.eng.merge_post, self._pend, self._records
-        new = self._new
-        re_, rd, rp = records[start], records[start + 1], records[start + 2]
-        gd, nparts = self._irb_blocks[start]
-        e_ci, d_ci, p_ci = re_[1], rd[1], rp[1]
-        a_in, Hi, Wi = re_[2], re_[4], re_[5]
-        C_, E_, k = e_ci.cin, d_ci.cout, d_ci.k
-        M = N * Hi * Wi
-        y2, bn_d = rd[3].data, rd[3].bn
-        y3, bn_p = rp[3].data, rp[3].bn
-        bn_e = re_[3].bn
-        econv, dconv = e_ci.mod.conv, d_ci.mod.conv
-        # ---- BatchNorm3 backward: sums of (G, y3) -- fused into G's producer when it could -- then the finalize
-        if g_reduced:
-            nred, red_buf = g_reduced, eng.scratch_red
-        else:
-            nred = max(1, min(1024, _cdiv(M * C_, 256 * 8 * 8)))
-            red_buf = eng.scratch_stats
-            ops.add(L.OP_BN_BWD_REDUCE, [C_, nred], [float(M)], [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), red_buf.data_ptr()])
-        if pend["ops"] is not None and pend["ops"] is not ops:
-            self._flush_post()
-        self._emit_post(ops, (red_buf.data_ptr(), bn_p.data_ptr(), eng.gptr(p_ci, 2), eng.gptr(p_ci, 3), nred, C_, float(M)))
-        b1p = econv.bias.data_ptr() if econv.bias is not None else None
-        geo = [N, Hi, Wi, C_, E_, k, nparts]
-        dy3 = new((N, Hi, Wi, C_))
-        w3p = self._next_scratch()
-        ops.add(L.OP_IRB_BWD, geo + [0], [],
-                [G.data_ptr(), y3.data_ptr(), bn_p.data_ptr(), y2.data_ptr(), bn_d.data_ptr(), p_ci.w_dgrad.data_ptr(),
-                 dy3.data_ptr(), w3p.data_ptr(), eng.scratch_red.data_ptr()], 0)
-        self._queue_wgrad(ops, w3p.data_ptr(), nparts, C_, E_, 1, False, eng.gptr(p_ci, 0))
-        self._emit_post(ops, (eng.scratch_red.data_ptr(), bn_d.data_ptr(), eng.gptr(d_ci, 2), eng.gptr(d_ci, 3), nparts, E_, float(M)))
-        g1 = new((N, Hi, Wi, E_))
-        dwp, pp = self._next_scratch(), self._next_scratch()
-        ops.add(L.OP_IRB_BWD, geo + [1], [],
-                a_in.act_ptrs() + [dy3.data_ptr(), y2.data_ptr(), e_ci.w_fwd.data_ptr(), p_ci.w_dgrad.data_ptr(), b1p, bn_e.data_ptr(),
-                                   bn_d.data_ptr(), d_ci.w_fwd.data_ptr(), g1.data_ptr(), dwp.data_ptr(), pp.data_ptr(),
-                                   eng.scratch_red.data_ptr()], 0)
-        self._queue_wgrad(ops, dwp.data_ptr(), nparts, E_, 1, k * k, True, eng.gptr(d_ci, 0))
-        self._emit_post(ops, (eng.scratch_red.data_ptr(), bn_e.data_ptr(), eng.gptr(e_ci, 2), eng.gptr(e_ci, 3), nparts, E_, float(M)))
-        ops.add(L.OP_IRB_W1_FIN, [nparts, E_, C_, 1], [],
-                [pp.data_ptr(), gd.data_ptr(), econv.weight.data_ptr(), b1p, bn_e.data_ptr(), eng.gptr(e_ci, 0)], 0)
-        if not need_gin:
-            return None
-        gin = new((N, Hi, Wi, C_))
-        ops.add(L.OP_IRB_BWD, geo + [2], [],
-                a_in.act_ptrs() + [g1.data_ptr(), e_ci.w_fwd.data_ptr(), b1p, bn_e.data_ptr(), G.data_ptr(), gin.data_ptr()], 0)
-        return gin
-
     def _feeds_fused_dw(self, act: _Act):
         """True if the ConvBlock that produced the virtual activation `act` is a depthwise conv whose backward runs as the fused
         sweep (the only mnas_dw_bwd form that takes a masked gradient)."""
@@ -893,10 +714,9 @@ class Program:
                 return ci.kind == "dw" and ci.k in self.eng.dw_fused_k and rec[2] is not None and rec[2].bn is not None
         return False
 
-    def _conv_bwd_se_proj(self, ops: _OpList, rec, g, g_reduced, se_rec, red4=False):
-        """Backward of the project conv of a squeeze-excite block whose excitation is applied on load.  Returns (gs, du, part4):
-        the input gradient wrt the GATED activation, dL/du (fp32 [N][E]) and (red4) the table of the four per-image reduce sums
-        float[4][E][N*kseg] (else None)."""
+    def _conv_bwd_se_proj(self, ops: _OpList, rec, g, g_reduced, se_rec):
+        """Backward of the project conv of a squeeze-excite block whose excitation is applied on load.  Returns (gs, du): the input
+        gradient wrt the GATED activation and dL/du (fp32 [N][E])."""
         eng, lib, N, merge = self.eng, self.eng.lib, self.N, self.eng.merge_post
         new = self._new
         _, ci, a_in, out, Hi, Wi = rec
@@ -919,15 +739,13 @@ class Program:
         gs = new((N, Hi, Wi, ci.cin))
         du = new((N, ci.cin), torch.float32)
         wsc = self._next_scratch() if merge else eng.scratch_wgrad2
-        part4 = new((4 * ci.cin * N * kseg,), torch.float32) if red4 else None
-        red = [part4.data_ptr(), h2.data.data_ptr(), h2.bn.data_ptr()] if red4 else [None, None, None]
-        ops.add(L.OP_PW_BWD, [M, ci.cin, Co, N * kseg, 0, HW // kseg, 1 if red4 else 0], [],
-                h2.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), None, gs.data_ptr(), wsc.data_ptr()] + red + [None, None, None], 0)
+        ops.add(L.OP_PW_BWD, [M, ci.cin, Co, N * kseg, 0, HW // kseg], [],
+                h2.act_ptrs() + gy + [ci.w_dgrad.data_ptr(), None, gs.data_ptr(), wsc.data_ptr()] + [None] * 6, 0)
         ops.add(L.OP_SE_PROJ_FIN, [N, kseg, Co, ci.cin, 1], [],
                 [wsc.data_ptr(), u.data_ptr(), ci.mod.conv.weight.data_ptr(), eng.gptr(ci, 0), du.data_ptr()], 0)
-        return gs, du, part4
+        return gs, du
 
-    def _se_bwd(self, ops: _OpList, rec_index, gs, du=None, part4=None):
+    def _se_bwd(self, ops: _OpList, rec_index, gs, du=None):
         """Backward of the squeeze-excite stage: gs = dL/d(a2 * s) from the project conv's input gradient -> dL/d a2, and the
         SE parameters' gradients (accumulated into the flat buffer; shared blocks sum their applications).  du: dL/du when the
         project conv's backward already produced it (excitation on load), else it is reduced here from (gs, a2)."""
@@ -939,7 +757,7 @@ class Program:
         m_ = se.mod
         dh = new((N, R_), torch.float32)
         dzp = new((N, E_), torch.float32)
-        ga = new((N, h2.H, h2.W, E_)) if part4 is None else None
+        ga = new((N, h2.H, h2.W, E_))
         if du is None:
             du = new((N, E_), torch.float32)
             sb = lib.mnas_se_scratch_bytes(N, HWl, E_)
@@ -957,15 +775,6 @@ class Program:
                                                             eng.gptr(se, 0), eng.gptr(se, 1)], 0)
         ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 2], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
                                                             None, None, dzp.data_ptr(), None], 0)
-        if part4 is not None:
-            # dL/da2 = gs*s + dz/HW is never materialised: the depthwise backward forms it on read (g_gate, g_bias), and the
-            # BatchNorm2-backward sums of its masked value come from the project conv's four per-image sums
-            kseg, gate = self._se_records[rec_index][5], self._se_records[rec_index][6]
-            zs = new((N, E_), torch.float32)
-            ops.add(L.OP_SE_BN_ASSEMBLE, [N, kseg, E_, HWl], [],
-                    [part4.data_ptr(), gate.data_ptr(), dzp.data_ptr(), zs.data_ptr(), eng.scratch_red.data_ptr()], 0)
-            self._g_affine[gs.data_ptr()] = (gate, zs)
-            return gs, N
         # the BatchNorm2-backward reduce of the depthwise conv rides in the same pass (ga is its g; h2 = its raw output + bnbuf)
         ncols = lib.mnas_se_bwd_apply_cols(N, HWl, E_)
         fused = h2.bn is not None and 0 < ncols <= _STATS_PARTS
@@ -1140,22 +949,6 @@ class Engine:
         self.use_tconv = True            # stride-2 dense 3x3 input gradient as a transposed convolution (csrc/mnas_tconv.hip)
         self.merge_post = True           # BatchNorm-backward finalize + weight-gradient reductions of the main stream in one launch
         self.materialize_dy = True       # dense 3x3 convs: dy formed once (mnas_dy_materialize), gathered plain by dgrad / wgrad
-        # MBConv_block: expand + depthwise forward in ONE kernel (statistics from the input's covariance, csrc/mnas_gram.hip).
-        # Validated bit-identical to the unfused pair, but measured SLOWER at bs 256 (14.7 vs 13.05 ms/step): the depthwise
-        # sweeps are latency/issue-bound, not HBM-bound, so removing the expanded tensor's read does not pay for the MFMA stage
-        # and the halved occupancy (166-250 VGPRs); see DESIGN.md.  Kept as an opt-in (eval mode never writes the expanded tensor).
-        self.fuse_expand = False
-        # MBConv_block on the 14x14 / 7x7 maps as fused kernels with the expanded tensor kept off HBM (csrc/mnas_irb*.hip):
-        # forward expand+depthwise in one launch (y1 never written), backward in three launches that recompute y1 and the project
-        # conv's input gradient on the matrix cores instead of reading them
-        # Modes: "full" (True) = forward + backward fused; "fwd" = fused forward that also stores y1, per-layer backward kernels;
-        # False = per-layer kernels everywhere.  Validated against the mirror and against the per-layer path
-        # (tests/test_gpu_irb.py, test_gpu_model.py) -- and measured SLOWER at bs 256 (MI355X, round 3: 13.3 ms/step full,
-        # 12.1 fwd, 11.6 off): the depthwise sweep inside the fused backward is vector-ALU-bound (4700 VALU instructions per
-        # (image, 32-channel slice) against 2100 for the sweep itself), and the forward's saving is eaten by the Gram-matrix
-        # statistics pass.  Opt-in until the instruction count comes down; see DESIGN.md section 7.
-        self.fuse_irb = False
-        self.irb_workgroups = 512        # workgroups per fused-block launch ((E/32) channel slices x image groups)
         # depthwise kernel sizes whose backward runs as ONE fused sweep (input gradient + weight gradient + reduce).  5x5 too:
         # with 2-row DMA groups the fused form gets full-width strips and beats the two launches (155 vs 210 us at 56x56)
         # although it needs all 256 VGPRs; (3,) selects the split form (input gradient on main, weight gradient on side)
@@ -1179,10 +972,6 @@ class Engine:
         self.dw_masked_g = True
         self.se_on_load = True           # squeeze-excite excitation applied in the project conv's load (forward) / folded into its
                                          # weight-gradient slabs (backward) where the kernels support the shape; False: k_se_scale
-        self.se_affine_on_read = False   # with se_on_load: dL/da2 = gs*s + dz/HW formed on read in the depthwise backward, BatchNorm2
-                                         # sums assembled from per-image partials (no k_se_bwd_apply pass).  Correct and tested, but
-                                         # OFF: the 5x5 fused sweep sits at 256 VGPRs and the two extra per-item pairs move its spill
-                                         # reloads behind the ring DMA of every row group (1.5-1.9x slower: DESIGN.md section 7)
         self.pw_bwd_segments = 512       # > 0: the project convs' fused backward at >= 800 k pixels walks contiguous pixel segments,
                                          # at most this many workgroups (0: tiles strided over the grid everywhere)
         self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch
@@ -1247,7 +1036,6 @@ class Engine:
         self.scratch_wgrad3 = torch.empty(wmax, dtype=torch.float32, device=device)      # main-stream producers rotate over 2..4:
         self.scratch_wgrad4 = torch.empty(wmax, dtype=torch.float32, device=device)      # a table is reduced up to two launches later
         self.scratch_red = torch.empty(_STATS_PARTS * 2 * smax, dtype=torch.float32, device=device)   # fused BN-bwd partials
-        self._gram_scratch = None        # allocated on first use (fused expand paths only): see gram_scratch()
         if self._ext_grad is not None:
             self.flat_grad = self._ext_grad
         else:
@@ -1348,20 +1136,6 @@ class Engine:
             if self.lib.mnas_event_elapsed_ms(e0, e1, C.byref(ms)) == 0:
                 out.append((tag, ms.value))
         return out
-
-    def gram_scratch(self, cin, nsplit):
-        """(partials float[nsplit][cin][cin], sums float[nsplit][cin]) for mnas_gram: allocated lazily, grown on demand, shared by
-        all blocks (a block's Gram is reduced by the finalize launch right behind it on the same stream)."""
-        need = (nsplit * cin * cin, nsplit * cin)
-        cur = self._gram_scratch
-        if cur is None or cur[0].numel() < need[0] or cur[1].numel() < need[1]:
-            if cur is not None and any(p.busy for lst in self.programs.values() for p in lst):
-                raise RuntimeError("gram scratch would be re-allocated while a program is in flight")
-            n0 = max(need[0], cur[0].numel() if cur else 0)
-            n1 = max(need[1], cur[1].numel() if cur else 0)
-            self._gram_scratch = (torch.empty(n0, dtype=torch.float32, device=self.device),
-                                  torch.empty(n1, dtype=torch.float32, device=self.device))
-        return self._gram_scratch
 
     def gptr(self, ci: _ConvInfo, j: int):
         return self.flat_grad.data_ptr() + 4 * ci.gslice[j][0]

@@ -359,6 +359,16 @@ class Trainer:
         self.optimizer.zero_grad()                           # train.py:438
         if self.schedule is not None:
             self.schedule.begin_step()
+        loss = self.forward_backward(x, target)
+        if self.schedule is not None:
+            self.schedule.finish()
+        self.optimizer.step()                                # train.py:440
+        return loss
+
+    def forward_backward(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """train.py:427-439 without the optimizer: forward, loss, backward INTO the flat gradient buffer (accumulating into what is
+        already there: two calls between ``optimizer.zero_grad()`` and ``optimizer.step()`` sum their gradients, which is what
+        the world-2 test uses to emulate two data-parallel ranks in one process).  Fires the engine's stage-done callback."""
         head = self._native_head()
         if head is not None:
             # features -> pool -> head -> cross-entropy -> head backward -> features backward as plain launch lists: no
@@ -385,7 +395,4 @@ class Trainer:
             out = self.model(x.float())
             loss = self.criterion(out, target)
             loss.backward()
-        if self.schedule is not None:
-            self.schedule.finish()
-        self.optimizer.step()                                # train.py:440
         return loss.detach()

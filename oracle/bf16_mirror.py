@@ -42,22 +42,13 @@ def _kind(spec: ConvSpec):
     return spec.kind
 
 
-def irb_supported(N, H, W, C, E, k):
-    """Shapes the HIP engine runs as a FUSED inverted-residual block (csrc/mnas_irb.hip: mnas_irb_supported): the 14x14 / 7x7
-    stages.  There the depthwise conv reads its input from an LDS image staged as bf16 and its backward reads dy staged as
-    bf16 -- two rounding points the per-layer depthwise kernels (act-/dy-on-read in fp32) do not have."""
-    if N < 1 or k not in (3, 5) or C % 8 or C < 16 or C > 192 or E % 32 or E < 32:
-        return False
-    return (W == 14 and 1 <= H <= 14) or (W == 7 and 1 <= H <= 7)
-
-
-def conv_fwd(spec: ConvSpec, a_in, st, train, image=None, dw_staged=False):
+def conv_fwd(spec: ConvSpec, a_in, st, train, image=None):
     p = spec.prefix
     if image is not None:
         a = round_bf16(image)
     else:
-        # depthwise: act-on-read in fp32 -- except inside a fused block (dw_staged), where the activation is staged as bf16
-        a = a_in.f32() if (_kind(spec) == "dw" and not dw_staged) else a_in.staged()
+        # depthwise: act-on-read in fp32; the MFMA kernels stage the activation as bf16
+        a = a_in.f32() if _kind(spec) == "dw" else a_in.staged()
     W = st[p + ".conv.weight"].detach()
     w = W if _kind(spec) == "dw" else round_bf16(W)
     y32 = F.conv2d(a, w, st[p + ".conv.bias"].detach(), stride=spec.stride, padding=spec.pad, groups=spec.groups)
@@ -81,7 +72,7 @@ def conv_fwd(spec: ConvSpec, a_in, st, train, image=None, dw_staged=False):
     y = round_bf16(y32)
     out = MAct(y, s, t)
     saved = dict(spec=spec, a=a, w=w, w32=W, y=y, s=s, t=t, mean=mean.float(), invstd=invstd.float(), M=M,
-                 in_shape=tuple(a.shape), dw_staged=dw_staged)
+                 in_shape=tuple(a.shape))
     return out, saved
 
 
@@ -103,8 +94,8 @@ def conv_bwd(saved, g, grads, resid=None, need_gin=True, se=None):
     c2 = (-sd * isd * S2 / M).float()
     c3 = (sd * (md * isd * S2 / M - S1 / M)).float()
     dy = v(c1) * dz + (v(c2) * y + v(c3))
-    if _kind(spec) != "dw" or saved.get("dw_staged"):
-        dy = round_bf16(dy)                 # staged into LDS as bf16 for the MFMA kernels (and inside a fused block); the
+    if _kind(spec) != "dw":
+        dy = round_bf16(dy)                 # staged into LDS as bf16 for the MFMA kernels; the
                                             # per-layer depthwise kernels keep fp32
     p = spec.prefix
 
@@ -161,16 +152,13 @@ def se_bwd(saved, gs, grads):
     acc(p + ".fc1.weight", dh.t() @ z)
     acc(p + ".fc1.bias", dh.sum(0))
     ga = gs * sg[:, :, None, None] + dz[:, :, None, None] / HW
-    # Engine.se_affine_on_read: the depthwise backward forms this value on read in fp32 (never stored, never rounded)
-    return ga if saved.get("affine") else round_bf16(ga)
+    return round_bf16(ga)                   # k_se_bwd_apply stores it as bf16
 
 
-def run(program, st, x, train=True, cot=None, need_dx=False, irb=False, se_on_load=None, se_affine=True):
+def run(program, st, x, train=True, cot=None, need_dx=False, se_on_load=None):
     """program: list of ("conv", spec) / ("block", [e,d,p]) (oracle.build_program or hand-made).
-    irb: mirror the engine's fused-block rounding points (Engine.fuse_irb = "full" / "fwd") on the shapes irb_supported() names.
     se_on_load: None, or a predicate (N, H, W, E) -> bool naming the squeeze-excite blocks whose excitation the engine applies on
-    load (Engine.se_on_load; the forward values are the same, the project conv's backward rounds differently: conv_bwd);
-    se_affine: for those blocks, dL/da2 is formed on read by the depthwise backward (Engine.se_affine_on_read) instead of stored.
+    load (Engine.se_on_load; the forward values are the same, the project conv's backward rounds differently: conv_bwd).
     Returns dict(y=fp32 output, grads={name: tensor}, dx=fp32 or None)."""
     first = program[0][1] if program[0][0] == "conv" else program[0][1][0]
     is_image = first.kind == "dense" and first.cin == 3
@@ -185,14 +173,12 @@ def run(program, st, x, train=True, cot=None, need_dx=False, irb=False, se_on_lo
             h = cur
             svs = []
             N_, C_, H_, W_ = a_in.data.shape
-            fused = bool(irb) and len(arg) == 3 and arg[1].kind == "dw" and irb_supported(N_, H_, W_, C_, arg[1].cout, arg[1].k)
             sse = None
             for j, spec in enumerate(arg[:3]):
                 if j == 2 and len(arg) == 4:
                     h, sse = se_fwd(arg[3], h, st)
                     sse["on_load"] = bool(se_on_load and se_on_load(N_, H_, W_, h.data.shape[1]))
-                    sse["affine"] = sse["on_load"] and bool(se_affine)
-                h, sv = conv_fwd(spec, h, st, train, dw_staged=fused)
+                h, sv = conv_fwd(spec, h, st, train)
                 svs.append(sv)
             svs.append(sse)
             cur = MAct(round_bf16(a_in.f32() + h.f32()))

@@ -338,44 +338,6 @@ def test_stage_bs256_replication_property(name):
     print(name, "bs256 replication: worst parameter-gradient deviation %.5f" % worst)
 
 
-@pytest.mark.parametrize("name", ["features5_80_96_k3_14", "features6_96_192_k5_14", "features7_192_320_k3_7"])
-def test_fused_block_path_vs_per_layer_path(name):
-    """The 14x14 / 7x7 stages as fused inverted-residual-block kernels (Engine.fuse_irb = "full": y1 and g2 never reach HBM,
-    backward recomputes them; "fwd": fused forward only).  Same module, same inputs, fused vs per-layer kernels (HIP vs HIP, 32
-    images, well-conditioned state): the paths differ only by the bf16 staging of a1 / dy2 inside the fused block and by the
-    expand conv's weight gradient taking the Gram-matrix route: y <= 1e-2, dx <= 8e-2, parameter gradients <= 0.12 relative L2
-    (BatchNorm weights, a heavily cancelling sum, 0.2); measured 0.004 / 0.05 / 0.09 / 0.13 -- "fwd" mode (fused forward,
-    per-layer backward) shows the same numbers as "full", i.e. the gap is the forward's bf16 staging of a1.  This is a consistency check between
-    two differently rounded pipelines; the fused path is held to the mirror WITH ITS OWN rounding points below."""
-    spec = FULL_STAGES[name][:7] + (32,) + FULL_STAGES[name][8:]
-    outs = []
-    for fused in ("full", False, "fwd"):
-        m, _, _, shp = _stage_setup(name, 0.1, spec)
-        m._engine().fuse_irb = fused
-        x = C.det_input(shp).cuda().requires_grad_(True)
-        y = m(x)
-        cot = C.cotangent(tuple(y.shape)).cuda()
-        (y * cot).sum().backward()
-        outs.append((y.detach().cpu(), x.grad.cpu(), {kk: p.grad.cpu() for kk, p in m.named_parameters()},
-                     {kk: v.cpu() for kk, v in m.state_dict().items() if "running" in kk or "tracked" in kk}))
-    (y1, dx1, g1, b1), (y0, dx0, g0, b0), (y2, dx2, g2, b2) = outs
-    for tag, (ya, dxa, ga, ba) in (("full", outs[0]), ("fwd", outs[2])):
-        ey, edx = rl2(ya, y0), rl2(dxa, dx0)
-        worst = max(rl2(ga[kk], g0[kk]) for kk in g0 if not kk.endswith("conv.bias"))
-        print(name, tag, "fused vs per-layer: y %.4f dx %.4f worst grad %.4f" % (ey, edx, worst))
-        assert ey < 1e-2 and edx < 8e-2
-        for kk in g0:
-            if kk.endswith("conv.bias"):
-                continue
-            assert bool(torch.isfinite(ga[kk]).all()), (tag, kk)
-            assert rl2(ga[kk], g0[kk]) < (0.2 if kk.endswith("bn.weight") else 0.12), (tag, kk)
-        for kk in b0:                 # BatchNorm bookkeeping: counters equal, running statistics to 1e-3 (Gram-route statistics)
-            if kk.endswith("tracked"):
-                assert int(ba[kk]) == int(b0[kk]), kk
-            else:
-                assert rl2(ba[kk], b0[kk]) < 1e-3, kk
-
-
 @pytest.mark.parametrize("name", ["features3_24_40_k5_56", "features6_96_192_k5_14", "features7_192_320_k3_7"])
 def test_side_stream_path_is_bit_identical(name):
     """Engine.use_side_stream (weight-gradient kernels on a second HIP stream; the default until round 3, now opt-in) must not
@@ -399,34 +361,6 @@ def test_side_stream_path_is_bit_identical(name):
         assert torch.equal(g0[kk], g1[kk]), kk
     for kk in b0:
         assert torch.equal(b0[kk], b1[kk]), kk
-
-
-@pytest.mark.parametrize("name", ["features5_80_96_k3_14", "features6_96_192_k5_14", "features7_192_320_k3_7"])
-def test_fused_block_stage_vs_mirror(name):
-    """Engine.fuse_irb = "full" at the bench batch (256 images) against the bf16 mirror WITH the fused block's rounding points
-    (oracle.bf16_mirror.run(irb=True): a1 and dy2 staged as bf16): same tolerances as test_stage_full_size_vs_mirror."""
-    m, prog, st, shp = _stage_setup(name, 0.1, FULL_STAGES[name])
-    m._engine().fuse_irb = "full"
-    x0 = C.det_input(shp)
-    x = x0.cuda().requires_grad_(True)
-    y = m(x)
-    cot = C.cotangent(tuple(y.shape))
-    (y * cot.cuda()).sum().backward()
-    y_, dx_ = y.detach().cpu(), x.grad.cpu()
-    grads = {kk: p.grad.cpu() for kk, p in m.named_parameters()}
-    del y, x
-    torch.cuda.empty_cache()
-    r = M.run(prog, st, x0, True, cot, need_dx=True, irb=True)
-    ey, edx = rl2(y_, r["y"]), rl2(dx_, r["dx"])
-    worst = max(rl2(gv, r["grads"][kk]) for kk, gv in grads.items() if not kk.endswith("conv.bias"))
-    print(name, "fused vs irb mirror: y %.4f dx %.4f worst grad %.4f" % (ey, edx, worst))
-    tol = 5e-2 if FULL_STAGES[name][3] >= 4 else TIGHT_BLK
-    assert ey < 1e-2 and edx < tol
-    for kk, gv in grads.items():
-        if kk.endswith("conv.bias"):
-            assert float(gv.abs().max()) < 1e-3
-            continue
-        assert rl2(gv, r["grads"][kk]) < (0.1 if kk.endswith("bn.weight") else tol), (kk, rl2(gv, r["grads"][kk]))
 
 
 @pytest.mark.parametrize("name", sorted(C.STAGES))
@@ -540,9 +474,12 @@ def test_net_full_size_bit_reproducible():
 
 
 # Per-parameter relative L2 of the whole-network gradients against the mirror at 224x224, batch 32 (well-conditioned state):
-# MEASURED on MI355X (round 5, printed by the test): see the numbers next to NET_GRAD_RL2 below.  The bound is per parameter
-# tensor (not a median): a wrong sign or scale in ONE small tensor fails it, which a cosine median does not.
-NET_GRAD_RL2 = {False: None, True: None}      # filled in below once measured: {ccf: (bound for all, bound for bn.weight)}
+# MEASURED on MI355X (round 5, printed by the test): ccf=False per-stage medians 0.17-0.24, worst tensor 0.288 (a bn.weight) /
+# 0.273 (everything else); ccf=True medians 0.13-0.19, worst 0.280 / 0.267.  (The whole-network backward amplifies the 1-ulp bf16
+# rounding-order differences between the engine and the mirror ~100x; per stage the same quantities are held to 3-5e-2 by
+# test_stage_full_size_vs_mirror.)  The bound is PER PARAMETER TENSOR, 1.5x the worst measurement: a wrong sign (rel-L2 2), a
+# wrong scale (>= 0.5) or a dropped application of a shared block in ONE small tensor fails it -- a cosine median does not see that.
+NET_GRAD_RL2 = {False: (0.42, 0.45), True: (0.42, 0.45)}      # {ccf: (bound for all, bound for bn.weight)}
 
 
 @pytest.mark.parametrize("ccf", [False, True])

@@ -167,105 +167,6 @@ def test_se_project_backward_segments(shape, kseg):
     assert relerr(du_ref, du_pass) < 5e-3
 
 
-@pytest.mark.parametrize("shape,kseg", [((3, 112, 112, 48, 16), 2), ((4, 56, 56, 72, 24), 2), ((5, 28, 28, 240, 40), 2)])
-def test_se_four_sum_reduce_and_assemble(shape, kseg):
-    """mnas_pw_bwd with red4 (ABI 5) in segment mode + mnas_se_bn_assemble: the BatchNorm2-backward sums of
-    dz2 = (gs*e[n][c] + z[n][c]) * [s*y2+t > 0] from the project conv's four per-image sums, against the same sums taken directly
-    over the pixels (gs as stored, bf16); gin itself is the plain launch's, bit for bit."""
-    from gpu_util import dy_ref, grad_in, pack, rand_bn_coefs
-    import torch.nn.functional as F
-    N, H, W, Ci, Co = shape
-    lib = L.load()
-    HW, M = H * W, N * H * W
-    assert lib.mnas_pw_bwd_forms(Ci, Co) & 4
-    x = bf16r(O.det_uniform((N, Ci, H, W), 830))
-    bx = rand_bn_coefs(Ci, 831, O)
-    g, y = bf16r(O.det_uniform((N, Co, H, W), 832)), bf16r(O.det_uniform((N, Co, H, W), 833))
-    b = rand_bn_coefs(Co, 834, O)
-    w = bf16r(O.det_param("q.conv.weight", (Co, Ci, 1, 1), 5))
-    u, dz = 2.0 * O.det_uniform((N, Ci), 835), O.det_uniform((N, Ci), 836)
-    xd, gd, yd, bd, bxd = nhwc(x), nhwc(g), nhwc(y), b.cuda(), bx.cuda()
-    wpk = pack(w, L.PACK_DGRAD)
-    nparts = N * kseg
-
-    def run(red4):
-        gin = torch.full((N, H, W, Ci), float("nan"), dtype=torch.bfloat16, device="cuda")
-        wpart = torch.full((nparts, Co, Ci), float("nan"), device="cuda")
-        part = torch.full((4 if red4 else 2, Ci, nparts), float("nan"), device="cuda")
-        c = L.MnasPwBwd()
-        c.M, c.Ci, c.Co, c.nparts, c.seg_px, c.red4 = M, Ci, Co, nparts, HW // kseg, red4
-        c.x, c.dy = act_in(xd, bxd[0], bxd[1]), grad_in(gd, yd, bd)
-        c.w, c.gin, c.wpartial = L.ptr(wpk), L.ptr(gin), L.ptr(wpart)
-        c.red_partial, c.red_y, c.red_bn = L.ptr(part), L.ptr(xd), L.ptr(bxd)
-        L.check(lib.mnas_pw_bwd(C_.byref(c), L.cur_stream()), "pw_bwd")
-        return gin, part
-    gin4, part4 = run(1)
-    gin2, part2 = run(0)
-    torch.cuda.synchronize()
-    assert torch.equal(gin4, gin2) and torch.equal(part4[:2], part2)
-    gate = torch.empty((N, Ci), device="cuda")
-    L.check(lib.mnas_se_gate(u.cuda().data_ptr(), N, Ci, gate.data_ptr(), L.cur_stream()))
-    dzd = dz.cuda()
-    gbias = torch.full((N, Ci), float("nan"), device="cuda")
-    red = torch.full((2, Ci, N), float("nan"), device="cuda")
-    L.check(lib.mnas_se_bn_assemble(part4.data_ptr(), N, kseg, Ci, gate.data_ptr(), dzd.data_ptr(), HW, gbias.data_ptr(), red.data_ptr(),
-                                    L.cur_stream()), "se_bn_assemble")
-    gq = from_nhwc(gin4).double()
-    s_, t_, mu_, is_ = (bx[i].view(1, -1, 1, 1).double() for i in (0, 1, 5, 6))
-    m = ((s_ * x.double() + t_) > 0).double()
-    xhat = x.double() * is_ - mu_ * is_
-    e, z = torch.sigmoid(u).double()[:, :, None, None], (dz.double() / HW)[:, :, None, None]
-    dz2 = (gq * e + z) * m
-    assert relerr(gbias.cpu(), dz / HW) < 1e-6
-    assert relerr(red[0].cpu().t(), dz2.sum((2, 3))) < 1e-3
-    assert relerr(red[1].cpu().t(), (dz2 * xhat).sum((2, 3))) < 1e-3
-
-
-@pytest.mark.parametrize("shape", [(3, 28, 28, 64, 5), (2, 56, 56, 72, 5), (5, 14, 14, 96, 3)])
-def test_dw_bwd_affine_on_read(shape):
-    """MnasDwBwd.g_gate / g_bias (ABI 5): the fused depthwise backward on the stored gs, read as gs*gate[n][c] + bias[n][c], against
-    the same launch on the materialised fp32-formed value -- compared with fp32 math on the unrounded affine value (the point of
-    forming it on read: no bf16 rounding in between)."""
-    import torch.nn.functional as F
-    from gpu_util import dy_ref, grad_in, pack, rand_bn_coefs
-    N, H, W, Cc, k = shape
-    lib = L.load()
-    x = bf16r(O.det_uniform((N, Cc, H, W), 840))
-    w = O.det_param("d.conv.weight", (Cc, 1, k, k), 6)
-    sc, sh = 1 + 0.3 * O.det_uniform((Cc,), 841), 0.2 * O.det_uniform((Cc,), 842)
-    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    gs, y = bf16r(O.det_uniform((N, Cc, H, W), 843)), bf16r(O.det_uniform((N, Cc, H, W), 844))
-    e, z = torch.sigmoid(2.0 * O.det_uniform((N, Cc), 845)), 0.05 * O.det_uniform((N, Cc), 846)
-    b = rand_bn_coefs(Cc, 847, O)
-    g2 = gs * e[:, :, None, None] + z[:, :, None, None]
-    dy = dy_ref(g2, y, b, rounded=False)
-    ref_gin = torch.nn.grad.conv2d_input((N, Cc, H, W), w, dy, padding=k // 2, groups=Cc)
-    ref_dw = torch.nn.grad.conv2d_weight(a, (Cc, 1, k, k), dy, padding=k // 2, groups=Cc)
-    xd, gd, yd, bd, dsc, dsh, ed, zd = nhwc(x), nhwc(gs), nhwc(y), b.cuda(), sc.cuda(), sh.cuda(), e.cuda().contiguous(), z.cuda().contiguous()
-    wp = pack(w, L.PACK_DW)
-    nparts = 41
-    rows = lib.mnas_dw_rows(N, H, W, Cc, k, nparts, 1)
-    gin = torch.full((N, H, W, Cc), float("nan"), dtype=torch.bfloat16, device="cuda")
-    wpart = torch.full((rows, k * k, Cc), float("nan"), device="cuda")
-    b_in = rand_bn_coefs(Cc, 848, O)
-    b_in[0], b_in[1] = sc, sh
-    bid = b_in.cuda()
-    redp = torch.full((2, Cc, rows), float("nan"), device="cuda")
-    a_ = L.MnasDwBwd()
-    a_.N, a_.H, a_.W, a_.C, a_.k, a_.nparts, a_.phase = N, H, W, Cc, k, nparts, 0
-    a_.x, a_.dy = act_in(xd, dsc, dsh), grad_in(gd, yd, bd)
-    a_.w, a_.gin, a_.wpartial = wp.data_ptr(), gin.data_ptr(), wpart.data_ptr()
-    a_.red_bn, a_.red_partial = bid.data_ptr(), redp.data_ptr()
-    a_.g_gate, a_.g_bias = ed.data_ptr(), zd.data_ptr()
-    L.check(lib.mnas_dw_bwd(C_.byref(a_), L.cur_stream()), "dw_bwd affine")
-    assert relerr(from_nhwc(gin), ref_gin) < 6e-3
-    grad = torch.full((Cc, 1, k, k), float("nan"), device="cuda")
-    L.check(lib.mnas_dw_wgrad_finalize(wpart.data_ptr(), rows, Cc, k, grad.data_ptr(), 0, L.cur_stream()))
-    assert relerr(grad.cpu(), ref_dw) < 2e-3
-    a_.g_masked = 1                                             # not combinable with the masked hand-over
-    assert lib.mnas_dw_bwd(C_.byref(a_), L.cur_stream()) == 10001
-
-
 SE_STAGES = {
     # (cin, cout, t, layers, k, reduce, ccf, N, H, W): shared SE block applied `layers` times, then the dense 3x3
     "se_features2_16_24": (16, 24, 3, 3, 5, True, False, 4, 56, 56),
@@ -320,8 +221,7 @@ def test_se_stage_vs_mirror(name):
     on_load = [bool(r_[5]) for lst in m._engine().programs.values() for prog_ in lst for r_ in prog_._se_records.values()]
     assert on_load and all(v == on_load[0] for v in on_load)
     assert on_load[0] == name.endswith(("_n16", "_n64")), "the stage did not take the expected squeeze-excite path"
-    r = M.run(prog, st, x0, True, cot, need_dx=True, se_on_load=(lambda *a: True) if on_load[0] else None,
-              se_affine=m._engine().se_affine_on_read)
+    r = M.run(prog, st, x0, True, cot, need_dx=True, se_on_load=(lambda *a: True) if on_load[0] else None)
     ey, edx = rl2(y.detach().cpu(), r["y"]), rl2(x.grad.cpu(), r["dx"])
     worst = 0.0
     layers = SE_STAGES[name][3]
@@ -349,24 +249,22 @@ def test_se_on_load_matches_materialised(name):
     through three applications of the shared block (the stage tests hold either path to its own mirror at 5e-2): the two paths
     agree within the same bounds."""
     res = {}
-    for on in (True, "no_affine", False):                # True: + the opt-in affine-on-read backward (Engine.se_affine_on_read)
+    for on in (True, False):
         m, prog, st, shp = _se_stage(name)
-        m._engine().se_on_load = bool(on)
-        m._engine().se_affine_on_read = on is True
+        m._engine().se_on_load = on
         x = C.det_input(shp).cuda().requires_grad_(True)
         y = m(x)
         (y * C.cotangent(tuple(y.shape)).cuda()).sum().backward()
         res[on] = (y.detach().cpu(), x.grad.cpu(), {k: v.grad.cpu() for k, v in m.named_parameters()})
         used = [r for lst in m._engine().programs.values() for prog_ in lst for r in prog_._se_records.values()]
         assert used and all(bool(r[5]) == bool(on) for r in used), "the stage did not take the expected squeeze-excite path"
-    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res["no_affine"][0], res[False][0])
-    for other in ("no_affine", False):
-        assert rl2(res[True][1], res[other][1]) < 5e-2
-        for k in res[True][2]:
-            if not k.endswith("conv.bias"):
-                e = rl2(res[True][2][k], res[other][2][k])
-                print(name, k, "on-load + affine-on-read vs %s %.4f" % ("on-load only" if other else "materialised", e))
-                assert e < (0.1 if k.endswith("bn.weight") else 5e-2), k
+    assert torch.equal(res[True][0], res[False][0])
+    assert rl2(res[True][1], res[False][1]) < 5e-2
+    for k in res[True][2]:
+        if not k.endswith("conv.bias"):
+            e = rl2(res[True][2][k], res[False][2][k])
+            print(name, k, "on-load vs materialised %.4f" % e)
+            assert e < (0.1 if k.endswith("bn.weight") else 5e-2), k
 
 
 def test_se_variant_network_step_vs_oracle():

@@ -19,6 +19,3 @@ for hw in 384x512 512x512 512x384; do
   python3 bench.py --hw $hw --batch 64 --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_bench_${hw}.json 2>/dev/null
 done
 python3 bench.py --clusters --no-cpu-baseline > gpurun_out/${TAG}_bench_clusters.json 2>/dev/null
-# round 4: the stand-alone chain benchmark of one inverted-residual block application (per-layer launches vs the tiled fused forms)
-python3 tools/kbench_irb112.py > gpurun_out/${TAG}_chain112.txt 2>&1
-python3 tools/kbench_irb112.py 56 24 72 5 > gpurun_out/${TAG}_chain56.txt 2>&1

@@ -33,10 +33,6 @@ def key(name):
         dg, wg = m.group(1) == "true", m.group(2) == "true"
         return "k_dw_bwd" if dg and wg else ("k_dw_conv<dgrad>" if dg else "k_dw_wgrad")
     if name.startswith("k_add_act"): return "k_add_act"
-    if name.startswith("void k_irb_fwd"): return "k_irb_fwd"
-    if name.startswith("void k_irb_bwd_proj"): return "k_irb_bwd_proj"
-    if name.startswith("void k_irb_bwd_dw"): return "k_irb_bwd_dw"
-    if name.startswith("void k_irb_bwd_exp"): return "k_irb_bwd_exp"
     if name.startswith("k_gram") or name.startswith("void k_gram"): return "k_gram"
     if name.startswith("k_se_") or name.startswith("void k_se_"): return "k_se"
     return "other"

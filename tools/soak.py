@@ -2,7 +2,7 @@
 on, 4 fixed batches cycling) executed twice from the same state; every step's loss and the final flat parameter / moment buffers
 must be bit-identical (no float atomics, fixed summation orders: a difference is a race or an uninitialised read -- the kind of
 bug that never shows in small tests, cf. dma_barrier in csrc/mnas_common.h), the loss finite throughout and lower at the end.
-usage (GPU box): python3 tools/soak.py [steps=150] [batch=256] [se|irb|HxW]      (se: the 5x5 + squeeze-excite variant of BASELINE config 4; irb: Engine.fuse_irb = "full")"""
+usage (GPU box): python3 tools/soak.py [steps=150] [batch=256] [se|HxW]      (se: the 5x5 + squeeze-excite variant of BASELINE config 4)"""
 import sys, os, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +16,6 @@ HW = (224, 224)
 for a_ in sys.argv[3:]:
     if "x" in a_ and a_.replace("x", "").isdigit():
         HW = tuple(int(v) for v in a_.split("x"))            # e.g. 384x512: a rectangular cluster of BASELINE config 5
-IRB = len(sys.argv) > 3 and sys.argv[3] == "irb"          # the opt-in fused inverted-residual block path (Engine.fuse_irb = "full")
 
 
 def run():
@@ -24,8 +23,6 @@ def run():
     base = Mnasnet(False, kernel_size=5, se_ratio=0.25) if SE else load_model("mnasnet")      # seeded default init
     m = FineTuneModelPool(base, "mnasnet", 1000, "512").cuda().train()
     tr = Trainer(m, lr=1e-3)
-    if IRB:
-        tr.engine.fuse_irb = "full"
     g = torch.Generator(device="cuda").manual_seed(7)
     xs = [torch.randn(B, 3, HW[0], HW[1], device="cuda", generator=g) for _ in range(4)]
     ts = [torch.randint(0, 1000, (B,), device="cuda", generator=g) for _ in range(4)]
