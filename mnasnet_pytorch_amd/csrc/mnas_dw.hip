@@ -33,7 +33,6 @@
 #define DW_G 4          // rows per sweep step (default; the 5x5 weight-gradient sweep uses 2, see mnas_dw_bwd)
 #define DW_BW 4         // output columns per thread
 #define DW_RR 8         // ring rows = 2 * G (two buffers of G rows)
-#define DW_WSTRIDE 200  // bytes per channel pair in the LDS filter-tap table of the 5x5 forms: 25 taps x float2 (see dw_wld5)
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
@@ -47,9 +46,7 @@ struct DwArgs {
     int nt;                                 // nontemporal output stores
 };
 
-// wl: the launch form keeps its filter taps in LDS (DW_WSTRIDE bytes per channel pair of the block) and wants `wl_cap` bytes of LDS
-// per workgroup at most (four workgroups per CU instead of two)
-static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a, bool wl = false, size_t wl_cap = 0) {
+static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArgs* a) {
     const int cps = C / 2;
     // Search (channel pairs per workgroup, column strips).  Whole pixel when it fits (cps <= 72), otherwise channel
     // blocks of >= 32 pairs (>= 128-byte runs per pixel).  Score = lane utilisation x occupancy / halo.
@@ -62,10 +59,10 @@ static bool dw_pick(int N, int H, int W, int C, int k, int nrings, int rr, DwArg
         const int cgn = cpw / 4;
         for (int sx = 1; sx <= maxsx && sx * cpw <= 256; ++sx) {
             const int tw = sx * DW_BW, iw = tw + k - 1;
-            size_t lds = (size_t)nrings * rr * iw * cpw * 4 + (wl ? (size_t)cpw * DW_WSTRIDE : 0);
+            size_t lds = (size_t)nrings * rr * iw * cpw * 4;
             // two workgroups per CU either way (160 KB LDS): wide strips (78 KB) measured 8-10 % faster than 60 KB for
             // every launch form except the 5x5 weight-gradient sweep (3 rings), which is 14 % slower with them
-            const size_t cap = wl ? wl_cap : ((k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024);
+            const size_t cap = (k == 5 && nrings == 3) ? 60 * 1024 : 78 * 1024;
             if (lds > cap) continue;
             const int nth = ((sx * cpw + 63) / 64) * 64;
             const int rc = iw * cgn;
@@ -156,49 +153,6 @@ __device__ __forceinline__ void dw_dma_rows(const DwArgs& a, const DwDma& p, uin
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 f2bf(uint32_t u) { f2 r; r.x = bf_lo(u); r.y = bf_hi(u); return r; }   // bf16 pair -> f32 pair
-
-// ---- filter taps streamed from LDS (5x5 kernels, round 5) ---------------------------------------------------------------------
-// The 25 taps of a channel pair are 50 VGPRs -- a fifth of the register file of a kernel whose occupancy is what hides its LDS and
-// DMA latencies.  They are loop-invariant, so the compiler keeps them in registers whatever the source says (it hoists plain LDS
-// loads out of the row loop; `volatile` loads each get a full s_waitcnt).  Hence inline asm: the workgroup parks the taps of its
-// channel block in LDS once, lane-major ([channel pair][25 taps] float2: a tap is the lane's base address + an IMMEDIATE offset,
-// stride 50 dwords -> conflict-free b64 reads), and the row body fetches one tap ROW (5 float2) at a time into two alternating
-// 5-pair buffers, the fetch of tap row i+1 in flight under the 20 packed FMAs of tap row i.  LDS returns in order, so
-// `s_waitcnt lgkmcnt(5)` after issuing the next five guarantees everything older has landed; the waits carry the buffer as an
-// in/out operand so that no use can be scheduled above them.  (Loads the compiler issues itself in between only make a wait
-// more conservative: its own counters assume fewer loads in flight than there are.)
-__device__ __forceinline__ uint32_t dw_lds_addr(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
-template <int OFF>
-__device__ __forceinline__ void dw_wld5(f2 (&w)[5], uint32_t addr) {      // taps OFF .. OFF+4 of this lane's channel pair
-    asm volatile("ds_read_b64 %0, %5 offset:%6\n\tds_read_b64 %1, %5 offset:%7\n\tds_read_b64 %2, %5 offset:%8\n\t"
-                 "ds_read_b64 %3, %5 offset:%9\n\tds_read_b64 %4, %5 offset:%10"
-                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4])
-                 : "v"(addr), "n"(OFF * 8), "n"(OFF * 8 + 8), "n"(OFF * 8 + 16), "n"(OFF * 8 + 24), "n"(OFF * 8 + 32)
-                 : "memory");
-}
-template <int CNT>
-__device__ __forceinline__ void dw_wwait(f2 (&w)[5]) {
-    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : "n"(CNT));
-}
-// A[i][ox] += tap(row KS-1-i, kx) * xr[ox+kx] for the five tap rows of a 5x5 filter, taps streamed as described above
-__device__ __forceinline__ void dw_scatter5_lds(f2 (&A)[5][DW_BW], const f2 (&xr)[DW_BW + 4], uint32_t waddr) {
-    f2 wa[5], wb[5];
-#define DW_ROWFMA(I_, W_) _Pragma("unroll") for (int ox = 0; ox < DW_BW; ++ox) _Pragma("unroll") for (int kx = 0; kx < 5; ++kx) \
-        A[I_][ox] = f2fma(W_[kx], xr[ox + kx], A[I_][ox])
-    dw_wld5<20>(wa, waddr);
-    dw_wld5<15>(wb, waddr);
-    dw_wwait<5>(wa); DW_ROWFMA(0, wa);
-    dw_wld5<10>(wa, waddr);
-    dw_wwait<5>(wb); DW_ROWFMA(1, wb);
-    dw_wld5<5>(wb, waddr);
-    dw_wwait<5>(wa); DW_ROWFMA(2, wa);
-    dw_wld5<0>(wa, waddr);
-    dw_wwait<5>(wb); DW_ROWFMA(3, wb);
-    dw_wwait<0>(wa); DW_ROWFMA(4, wa);
-#undef DW_ROWFMA
-}
 
 // window row of activations: relu(s*x+t) (or x), zero outside the image columns (mz[xx] = 1.0 inside, 0.0 outside)
 template <int WIN_W>
@@ -298,16 +252,14 @@ __device__ __forceinline__ void dw_block_reduce(float* scratch, const f2 (&v)[NV
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------
-template <int KS, int G, bool WL = false>
-__global__ __launch_bounds__(256, ((KS == 3 || WL) ? 4 : 3)) void k_dw_fwd(DwArgs a, MnasActIn in, const float* __restrict__ w,
+template <int KS, int G>
+__global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, MnasActIn in, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, uint32_t* __restrict__ out,
                                                                    float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
     const int cblk = 2 * a.cpw;
-    static_assert(!WL || KS == 5, "tap streaming is the 5x5 form");
     uint32_t* ring = (uint32_t*)smem;                    // [RR][rc*4 dwords]; reused as reduction scratch at the end
-    float* lds_w = (float*)(ring + (size_t)(2 * G) * a.rc * 4);      // WL: [cpw][25] float2 filter taps of the channel block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
@@ -316,8 +268,7 @@ __global__ __launch_bounds__(256, ((KS == 3 || WL) ? 4 : 3)) void k_dw_fwd(DwArg
     const f2 zero2 = {0.f, 0.f};
     f2 s1 = zero2, s2 = zero2;
     int cur_c0 = -1;
-    f2 wt[WL ? 1 : KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
-    const uint32_t waddr = dw_lds_addr(lds_w) + (uint32_t)cp * DW_WSTRIDE;
+    f2 wt[KS * KS], b2 = zero2, cs = {1.f, 1.f}, ct = zero2;
     const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
@@ -328,21 +279,10 @@ __global__ __launch_bounds__(256, ((KS == 3 || WL) ? 4 : 3)) void k_dw_fwd(DwArg
         const bool ch_ok = ch < a.C;
         if (c0 != cur_c0) {       // first item: a workgroup only ever sees ONE channel block (see dw_setup)
             cur_c0 = c0;
-            if constexpr (WL) {
-                if (sxi == 0) {                  // (published by the barrier below, before anybody's first row)
-                    for (int t = 0; t < KS * KS; ++t) {
-                        f2 v;
-                        v.x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
-                        v.y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
-                        *(f2*)(lds_w + (size_t)cp * (DW_WSTRIDE / 4) + 2 * t) = v;
-                    }
-                }
-            } else {
 #pragma unroll
-                for (int t = 0; t < KS * KS; ++t) {
-                    wt[t].x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
-                    wt[t].y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
-                }
+            for (int t = 0; t < KS * KS; ++t) {
+                wt[t].x = ch_ok ? w[(size_t)t * a.C + ch] : 0.f;
+                wt[t].y = ch_ok ? w[(size_t)t * a.C + ch + 1] : 0.f;
             }
             b2.x = (bias && ch_ok) ? bias[ch] : 0.f;
             b2.y = (bias && ch_ok) ? bias[ch + 1] : 0.f;
@@ -381,17 +321,13 @@ __global__ __launch_bounds__(256, ((KS == 3 || WL) ? 4 : 3)) void k_dw_fwd(DwArg
                 if (iy >= 0 && iy < a.H) {           // uniform: rows outside the image contribute nothing
                     f2 xr[WIN_W];
                     dw_read_act_nm<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, xr);
-                    if constexpr (WL) {
-                        dw_scatter5_lds(A, xr, waddr);
-                    } else {
 #pragma unroll
-                        for (int i = 0; i < KS; ++i)
+                    for (int i = 0; i < KS; ++i)
 #pragma unroll
-                            for (int ox = 0; ox < DW_BW; ++ox)
+                        for (int ox = 0; ox < DW_BW; ++ox)
 #pragma unroll
-                                for (int kx = 0; kx < KS; ++kx)
-                                    A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
-                    }
+                            for (int kx = 0; kx < KS; ++kx)
+                                A[i][ox] = f2fma(wt[(KS - 1 - i) * KS + kx], xr[ox + kx], A[i][ox]);
                 }
                 if (oy >= 0 && oy < a.H && ch_ok) {
 #pragma unroll
@@ -667,17 +603,30 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
 static int dw_rings(int form) { return form < 0 ? 1 : (form == 1 ? 2 : 3); }      // form: -1 forward, else phase
 // Pick rows-per-group G in {4, 2} and the strip geometry for a launch form: 2-row groups halve the ring footprint (wider
 // strips / more channels per workgroup) at the price of a barrier every 2 rows instead of 4 (priced at 7 %).
-// 5x5 forward: filter taps streamed from LDS (<= 128 VGPRs, four waves per SIMD), with at most dw5f_cap() bytes of LDS per
-// workgroup (ring + tap table): four workgroups per CU.  (Constants in the shipped build; environment switches exist only in the
-// -DMNAS_DIAG build, tools/build_alt.sh.)
-static int dw5f_wl() { static int v = -1; if (v < 0) v = mnas_diag_env("MNAS_DW5F_WL", 1); return v; }
-static size_t dw5f_cap() { static int v = -1; if (v < 0) v = mnas_diag_env("MNAS_DW5F_CAP_KB", 40); return (size_t)v * 1024; }
-static bool dw_form_wl(int k, int form) { return dw5f_wl() && k == 5 && form < 0; }
+// DIAGNOSIS build only (tools/build_alt.sh): MNAS_DW_CPW / MNAS_DW_SX / MNAS_DW_G force the geometry (tools/kbench_dw.py sweeps)
+static bool dw_force(int N, int H, int W, int C, int k, int nrings, DwArgs* a, int* g) {
+    const int cpw = mnas_diag_env("MNAS_DW_CPW", 0), sx = mnas_diag_env("MNAS_DW_SX", 0), gg = mnas_diag_env("MNAS_DW_G", 0);
+    if (cpw <= 0 || sx <= 0 || (gg != 2 && gg != 4) || (cpw & 3) || cpw * sx > 256 || cpw > C / 2) return false;
+    const int cps = C / 2, cgn = cpw / 4, iw = sx * DW_BW + k - 1;
+    if ((size_t)nrings * 2 * gg * iw * cpw * 4 > 160 * 1024) return false;
+    a->N = N; a->H = H; a->W = W; a->C = C; a->score = 0.f;
+    a->cpw = cpw; a->sx = sx; a->cgn = cgn;
+    a->nthreads = ((sx * cpw + 63) / 64) * 64;
+    a->iw = iw;
+    a->strips_x = (W + sx * DW_BW - 1) / (sx * DW_BW);
+    a->cblocks = (cps + cpw - 1) / cpw;
+    a->items = N * a->strips_x * a->cblocks;
+    a->rc = iw * cgn;
+    a->nb = (a->rc + 63) / 64;
+    if (a->nb > 2 * (a->nthreads / 64)) return false;
+    *g = gg;
+    return true;
+}
 static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g) {
     DwArgs a4, a2;
     const int nrings = dw_rings(form);
-    const bool wl = dw_form_wl(k, form);
-    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4, wl, dw5f_cap()), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2, wl, dw5f_cap());
+    if (mnas_diag_env("MNAS_DW_CPW", 0) > 0 && dw_force(N, H, W, C, k, nrings, a, g)) return true;
+    const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2);
     if (!ok4 && !ok2) return false;
     if (ok2 && (!ok4 || 0.93f * a2.score > a4.score)) { *a = a2; *g = 2; }
     else { *a = a4; *g = 4; }
@@ -722,14 +671,11 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     size_t lds = (size_t)2 * g * a.rc * 16;
     const size_t red_need = (size_t)a.sx * 2 * 2 * a.cpw * sizeof(float);          // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
-    const bool wl = dw_form_wl(c->k, -1);
-    if (wl) lds = (size_t)2 * g * a.rc * 16 + (size_t)a.cpw * DW_WSTRIDE;         // (the ring alone always covers red_need)
     hipStream_t s = (hipStream_t)stream;
-#define MNAS_DWF(K_, G_, WL_) hipLaunchKernelGGL((k_dw_fwd<K_, G_, WL_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
-                                                 (uint32_t*)c->out, c->stats)
-    if (c->k == 3) { if (g == 4) MNAS_DWF(3, 4, false); else MNAS_DWF(3, 2, false); }
-    else if (wl) { if (g == 4) MNAS_DWF(5, 4, true); else MNAS_DWF(5, 2, true); }
-    else { if (g == 4) MNAS_DWF(5, 4, false); else MNAS_DWF(5, 2, false); }
+#define MNAS_DWF(K_, G_) hipLaunchKernelGGL((k_dw_fwd<K_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
+                                            (uint32_t*)c->out, c->stats)
+    if (c->k == 3) { if (g == 4) MNAS_DWF(3, 4); else MNAS_DWF(3, 2); }
+    else { if (g == 4) MNAS_DWF(5, 4); else MNAS_DWF(5, 2); }
 #undef MNAS_DWF
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
