@@ -391,7 +391,9 @@ int mnas_se_bwd_apply_cols(int N, int HW, int C);
  *                           N * kseg) on the UNGATED activation act(a): wpartial float[N*kseg][Co][Ci] holds per-image(-fraction)
  *                           sums of dy[pix][o] * act(a)[pix][c].  Writes du[n][c] = (sum_o W[o][c] * P_n[o][c]) * s (1 - s)
  *                           (= what mnas_se_bwd_reduce computes from gs = dy . W, without the pass over gs and a) and the conv's
- *                           weight gradient dW[o][c] (+)= sum_n s[n][c] * P_n[o][c].  W: the conv's fp32 weight [Co][Ci].
+ *                           weight gradient dW[o][c] (+)= sum_n s[n][c] * P_n[o][c].  W: the conv's fp32 MASTER weight [Co][Ci]
+ *                           (gs itself was formed with the bf16-rounded weight: du differs from mnas_se_bwd_reduce's by that
+ *                           rounding, <= 4e-3 relative per term, inside the gradient tolerances of tests/test_gpu_se.py).
  *                           wpartial is overwritten (scratch).  Deterministic (fixed summation order). */
 int mnas_se_gate(const float* u, int N, int C, float* gate, void* stream);
 int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, int Ci, const float* u, const float* W, float* dW,

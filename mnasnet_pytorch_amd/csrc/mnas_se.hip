@@ -170,9 +170,36 @@ extern "C" int mnas_se_gate(const float* u, int N, int C, float* gate, void* str
 // over the images) and writes du = du_pre * s (1 - s).  Both sums run in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void k_se_proj_du(float* __restrict__ wpartial, int kseg, int Co, int Ci, const float* __restrict__ u,
                                                     const float* __restrict__ W, float* __restrict__ du) {
+    // thread = (input channel c, output-channel group og): all 256 threads work whatever Ci is (the squeeze-excite project convs
+    // have Ci = 48 / 72 / 240: one thread per channel left 19-94 % of the workgroup idle on a launch that sits on the critical
+    // path); the og partial sums of a channel meet in LDS and are added in group order: deterministic.  W is the fp32 master
+    // weight (gs was formed with its bf16 rounding: the difference is inside the gradient tolerances, include/mnas.h says so).
+    __shared__ float part[256];
     const int n = blockIdx.x;
     const size_t slab = (size_t)Co * Ci;
     float* base = wpartial + (size_t)n * kseg * slab;
+    if (Ci <= 256) {
+        const int G = 256 / Ci;
+        const int c = threadIdx.x % Ci, og = threadIdx.x / Ci;
+        const float sg = se_sigmoid(u[(size_t)n * Ci + c]);
+        float acc = 0.f;
+        if (og < G) {
+            for (int o = og; o < Co; o += G) {
+                float p = base[(size_t)o * Ci + c];
+                for (int j = 1; j < kseg; ++j) p += base[j * slab + (size_t)o * Ci + c];
+                acc = fmaf(W[(size_t)o * Ci + c], p, acc);
+                base[(size_t)o * Ci + c] = p * sg;
+            }
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (og == 0) {
+            float a = part[c];
+            for (int g = 1; g < G; ++g) a += part[g * Ci + c];
+            du[(size_t)n * Ci + c] = a * sg * (1.f - sg);
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < Ci; c += 256) {
         const float sg = se_sigmoid(u[(size_t)n * Ci + c]);
         float acc = 0.f;

@@ -269,7 +269,7 @@ extern "C" int mnas_tconv_parts(int N, int Ho, int Wo, int Co, int Ci) {
     }
     int nt, pt; size_t lds;
     const long long M2 = (long long)N * Ho * Wo;
-    if (!tconv_ok(Ho, Wo, Co, Ci, &nt, &pt, &lds, M2)) return -1;
+    if (M2 * 4 * Ci > 0x7fffffff || !tconv_ok(Ho, Wo, Co, Ci, &nt, &pt, &lds, M2)) return -1;
     const int ntiles = (int)((M2 + 64 * pt - 1) / (64 * pt));
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu > 3) per_cu = 3;
@@ -281,7 +281,7 @@ extern "C" int mnas_tconv_parts(int N, int Ho, int Wo, int Co, int Ci) {
 extern "C" int mnas_tconv_dgrad(const MnasTconvDgrad* c, void* stream) {
     if (!c || !c->dy || !c->w || !c->out || c->nparts < 1) return MNAS_EINVAL;
     if (c->red_y && (!c->red_bn || !c->stats)) return MNAS_EINVAL;
-    if (mnas_tcx_ok(c->Ho, c->Wo, c->Co, c->Ci)) return mnas_tcx_dgrad(c, stream);
+    if (mnas_tcx_parts(c->N, c->Ho, c->Wo, c->Co, c->Ci) > 0) return mnas_tcx_dgrad(c, stream);    // (incl. the 32-bit offset limit)
     if (mnas_tcr_parts(c->N, c->Ho, c->Wo, c->Co, c->Ci) > 0) return mnas_tcr_dgrad(c, stream);
     int nt, pt; size_t lds;
     const long long M2 = (long long)c->N * c->Ho * c->Wo;

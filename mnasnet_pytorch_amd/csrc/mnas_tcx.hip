@@ -238,6 +238,7 @@ int mnas_tcx_ok(int Ho, int Wo, int Co, int Ci) {
 int mnas_tcx_parts(int N, int Ho, int Wo, int Co, int Ci) {
     TcxPlan p;
     if (!tcx_plan(Ho, Wo, Co, Ci, &p)) return -1;
+    if ((long long)N * Ho * Wo * 4 * Ci > 0x7fffffff) return -1;     // 32-bit element offsets: the caller falls back at BUILD time
     const long long groups = ((long long)N * Ho * Wo + 15) / 16;
     // persistent workgroups: 24 -> 16 at 112x112 105 us with 1024 (148 with 512, 123 with 2048; k_tconv 110); 40 -> 24 at 56x56
     // 52 us with 768 (61 with 512, 66 with 1024, 75 with 2048; k_igemm's parity form 79)
@@ -489,6 +490,7 @@ int mnas_tcr_ok(int Ho, int Wo, int Co, int Ci) {
 int mnas_tcr_parts(int N, int Ho, int Wo, int Co, int Ci) {
     int pm; size_t lds;
     if (N < 32 || !tcr_plan(Ho, Wo, Co, Ci, &pm, &lds)) return -1;
+    if ((long long)N * 4 * Ho * Wo * Ci > 0x7fffffff) return -1;     // 32-bit element offsets (as mnas_tcr_dgrad checks)
     return pm < N ? pm : N;
 }
 int mnas_tcr_dgrad(const MnasTconvDgrad* c, void* stream) {

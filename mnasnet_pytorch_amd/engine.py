@@ -210,6 +210,18 @@ class Program:
 
 
         fwd = self._fwd = _OpList(eng, "fwd")
+        # dy plane (Ho, Wo) of every stride-2 dense conv in THIS program: the transposed-conv input gradient is picked per plane
+        # (rectangular clusters, 192-px inputs ... get the form whenever the library has it for their plane)
+        self._tconv_ok = {}
+        Ht, Wt = H, W
+        for op, m, stage in eng.steps:
+            for cb in ([m] if op == "conv" else m):
+                ci = eng.info[id(cb)]
+                Ho_, Wo_ = ci.out_hw(Ht, Wt)
+                if eng.use_tconv and eng.materialize_dy and getattr(ci, "w_tconv", None) is not None and Ht == 2 * Ho_ and Wt == 2 * Wo_:
+                    self._tconv_ok[id(ci)] = bool(lib.mnas_tconv_supported(Ho_, Wo_, ci.cout, ci.cin)) and \
+                        lib.mnas_tconv_parts(N, Ho_, Wo_, ci.cout, ci.cin) > 0
+                Ht, Wt = Ho_, Wo_
         # ---- weight packing (once per forward; weights change every optimizer step): one batched launch
         descs = []
         for ci in eng.convs:
@@ -218,7 +230,7 @@ class Program:
                 descs.append((w.data_ptr(), ci.w_fwd.data_ptr(), L.PACK_FWD, ci.cout, ci.cin, ci.k * ci.k))
                 if training:
                     descs.append((w.data_ptr(), ci.w_dgrad.data_ptr(), L.PACK_DGRAD, ci.cout, ci.cin, ci.k * ci.k))
-                    if ci.w_tconv is not None:
+                    if self._tconv_ok.get(id(ci)):
                         descs.append((w.data_ptr(), ci.w_tconv.data_ptr(), L.PACK_TCONV, ci.cout, ci.cin, 9))
             elif ci.kind == "dw":
                 descs.append((w.data_ptr(), ci.w_fwd.data_ptr(), L.PACK_DW, ci.cout, 1, ci.k * ci.k))
@@ -676,8 +688,8 @@ class Program:
                 nparts = lib.mnas_conv_gemm_parts(1, Min, Co, ci.cin, ci.k * ci.k)
                 if nparts < 1:
                     nparts = max(1, min(1024, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
-                tconv = (eng.use_tconv and ci.kind == "dense" and getattr(ci, "w_tconv", None) is not None and gyd is not gy and resid is None
-                         and Hi == 2 * Ho and Wi == 2 * Wo and lib.mnas_tconv_supported(Ho, Wo, Co, ci.cin))
+                tconv = (eng.use_tconv and ci.kind == "dense" and self._tconv_ok.get(id(ci), False) and gyd is not gy and resid is None
+                         and Hi == 2 * Ho and Wi == 2 * Wo)
                 if tconv:
                     tp = lib.mnas_tconv_parts(N, Ho, Wo, Co, ci.cin)       # (-1: a form that needs a larger batch)
                     tconv = tp > 0
@@ -1011,10 +1023,9 @@ class Engine:
                 ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
                 ci.w_dgrad = torch.empty(nbytes(L.PACK_DGRAD, ci.cout, ci.cin, ci.k, ci.k), dtype=torch.uint8, device=device)
                 ci.w_tconv = None
-                # (the transposed-conv kernels are picked per dy plane size: pack the weights if any of the planes this network
-                # can see has one; the program builder asks again with the real plane)
-                if ci.kind == "dense" and ci.stride == 2 and self.use_tconv and self.materialize_dy and \
-                        any(self.lib.mnas_tconv_supported(h, h, ci.cout, ci.cin) for h in (7, 8, 14, 28, 56)):
+                # transposed-conv form of the stride-2 input gradient: the buffer exists for every stride-2 dense conv (< 1 MB each);
+                # whether a PROGRAM packs and uses it is decided from that program's real dy plane (Program.__init__)
+                if ci.kind == "dense" and ci.stride == 2 and self.use_tconv and self.materialize_dy:
                     ci.w_tconv = torch.empty(nbytes(L.PACK_TCONV, ci.cout, ci.cin, 3, 3), dtype=torch.uint8, device=device)
                 K = ci.k * ci.k * ci.cin
                 slabs = self.lib.mnas_conv_wgrad_slabs(ci.cout, ci.cin, ci.k * ci.k)
