@@ -124,11 +124,12 @@ def test_baseline_config_step_bs256():
     assert bool(torch.isfinite(p4).all())
 
 
-@pytest.mark.parametrize("nb,bs,size,steps", [(4, 32, 64, 30), (2, 64, 224, 8)], ids=["bs32_64px_30steps", "bs64_224px_8steps"])
+@pytest.mark.parametrize("nb,bs,size,steps", [(4, 32, 64, 30), (2, 48, 224, 6)], ids=["bs32_64px_30steps", "bs48_224px_6steps"])
 def test_training_trajectory_matches_cpu_oracle(nb, bs, size, steps):
     """What "matches the reference" means for bf16 TRAINING (train.py:423-440): Adam steps (lr 1e-3), 10 classes, dropout off,
     cycling over `nb` fixed batches, HIP Trainer vs the fp32 CPU oracle (oracle.train_step) from the same state on identical data
-    -- 30 steps at bs 32, 64x64, and (round 4) 8 steps at the bench resolution, bs 64 x 224 x 224.  Stated band: at every step
+    -- 30 steps at bs 32, 64x64, and (round 4; round 5: 6 steps at bs 48, the CPU oracle is what this test's minute goes to) the
+    bench resolution, 224 x 224.  Stated band: at every step
     |loss_hip - loss_ref| <= max(6 % of loss_ref, 0.03) (bf16 activations, fp32 master weights / statistics / optimizer; the
     absolute floor covers the end of the long run, where the 128 images are memorised and the loss is ~0.01), the mean gap over
     the steps with loss_ref > 0.1 is <= 3 %, and both runs learn (long run: last-5 mean < 0.2 x first-5 mean; short run: the last
