@@ -541,7 +541,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    smi = smi_snapshot() if (rank == 0 and not args.no_box) else None     # child process: BEFORE anything touches the GPU
+    # child process, BEFORE anything in this process touches the GPU -- and never under a profiler: rocprofv3's preloaded library
+    # has initialised the GPU before main() runs, and a process that has must not fork+exec on this pool
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ)
+    smi = smi_snapshot() if (rank == 0 and not args.no_box and not profiled) else None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:

@@ -19,3 +19,4 @@ for hw in 384x512 512x512 512x384; do
   python3 bench.py --hw $hw --batch 64 --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_bench_${hw}.json 2>/dev/null
 done
 python3 bench.py --clusters --no-cpu-baseline > gpurun_out/${TAG}_bench_clusters.json 2>/dev/null
+python3 bench.py --ccf --no-cpu-baseline > gpurun_out/${TAG}_bench_ccf.json 2>/dev/null

@@ -3,7 +3,7 @@
 per-launch list of the fused-block run)."""
 import json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 COPY = {"prof_%s_kernel_trace.txt": "%s_kernel_trace.txt", "prof_%s_timeline.txt": "%s_timeline.txt",
@@ -30,7 +30,7 @@ def entry(d, classes=True):
 runs = {}
 h = line("h2d")
 runs["h2d"] = dict(entry(h, False), pcie_inclusive=h["pcie_inclusive"])
-for name in ("k5", "se"):
+for name in ("k5", "se", "ccf"):
     runs[name] = entry(line(name))
 for hw in ("384x512", "512x512", "512x384"):
     runs[hw] = entry(line(hw), False)
@@ -43,6 +43,4 @@ note = ("one gpurun call (tools/collect_round.sh): variants of python bench.py o
         "different boxes (default command), so only numbers from the same call are comparable.")
 with open(os.path.join(dst, "%s_bench_variants.json" % tag), "w") as f:
     json.dump({"note": "round %s, " % tag[1:] + note, "runs": runs}, f, indent=1)
-for hw in ("112", "56"):
-    shutil.copyfile(os.path.join(src, "%s_chain%s.txt" % (tag, hw)), os.path.join(dst, "%s_chain%s.txt" % (tag, hw)))
 print("installed profiles/%s_*" % tag)
