@@ -203,15 +203,19 @@ typedef struct MnasDwFwd {
     MnasActIn in;
     const float* w;          /* fp32 [k*k][C] (tap-major) */
     const float* bias;       /* [C] or NULL */
-    void*  out;              /* bf16 (N,H,W,C) raw output */
-    float* stats;            /* float[2][C][rows] or NULL, rows = mnas_dw_rows(N,H,W,C,k,nparts,0) */
+    void*  out;              /* bf16 (N,Ho,Wo,C) raw output */
+    float* stats;            /* float[2][C][rows] or NULL, rows = mnas_dw_rows(N,H,W,C,k,nparts,0) (stride 2: which = 4) */
+    /* ABI 6: 0 / 1 = stride 1 (the LDS row-ring sweeps); 2 = the depthwise conv of SepConv(reduce=True) (mnasnet.py:73-81):
+     * Ho = (H + 2*(k/2) - k)/2 + 1, plain direct kernels (csrc/mnas_dw2.hip). */
+    int32_t stride, reserved;
 } MnasDwFwd;
 int mnas_dw_fwd(const MnasDwFwd* a, void* stream);
 /* Number of partial rows/columns a depthwise launch writes for this shape and nparts (host-side, no launch).
  * which = 0: forward statistics float[2][C][rows];
  * which = 1: both tables of a phase-0 (fused) backward launch: wpartial float[rows][k*k][C], reduce float[2][C][rows];
  * which = 2: the fused-reduce table of a phase-1 (input-gradient-only) launch;
- * which = 3: wpartial of a phase-2 (weight-gradient-only) launch.  Returns < 0 for unsupported shapes. */
+ * which = 3: wpartial of a phase-2 (weight-gradient-only) launch.  Returns < 0 for unsupported shapes.
+ * which = 4 / 7: the same as 0 / 3 for the STRIDE-2 kernels (MnasDwFwd.stride / MnasDwBwd.stride == 2). */
 /* Diagnostics: geometry picked for a launch form (`which` as in mnas_dw_rows).  out[7] = {channel pairs per workgroup,
  * 4-column strips per workgroup, threads, strips per image row, channel blocks, LDS bytes, rows per DMA group}. */
 int mnas_dw_geometry(int N, int H, int W, int C, int k, int which, int* out);
@@ -232,7 +236,9 @@ typedef struct MnasDwBwd {
     float* red_partial;
     int32_t phase;           /* 0: one fused sweep (input gradient + weight gradient + reduce); 1: input gradient (+reduce)
                                 only; 2: weight gradient only (lets the caller put the two on different streams) */
-    int32_t reserved0;
+    int32_t stride;          /* ABI 6: 0 / 1 = stride 1; 2 = SepConv(reduce=True)'s depthwise conv (N,H,W = the conv's INPUT dims): only the
+                                two-launch form -- phase 1 (input gradient, no fused reduce, no g_masked), phase 2 (weight gradient,
+                                wpartial float[mnas_dw_rows(...,7)][k*k][C]) */
     /* round 4: dy.g already holds dz = g*[s*y+t>0] (written by mnas_pw_bwd with gin_masked): dy-on-read skips the mask.
      * Phase 0 with the fused reduce only; results are bit-identical to the plain form on the unmasked g. */
     int32_t g_masked, reserved;

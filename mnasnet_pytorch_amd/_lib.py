@@ -39,14 +39,14 @@ class MnasConvWgrad(C.Structure):
 class MnasDwFwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("nparts", C.c_int32), ("in_", MnasActIn), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
-                ("stats", c_void_p)]
+                ("stats", c_void_p), ("stride", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasDwBwd(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("nparts", C.c_int32), ("x", MnasActIn), ("dy", MnasGradIn), ("w", c_void_p), ("gin", c_void_p),
                 ("wpartial", c_void_p), ("red_bn", c_void_p), ("red_partial", c_void_p), ("phase", C.c_int32),
-                ("reserved0", C.c_int32), ("g_masked", C.c_int32), ("reserved", C.c_int32)]
+                ("stride", C.c_int32), ("g_masked", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MnasPwBwd(C.Structure):

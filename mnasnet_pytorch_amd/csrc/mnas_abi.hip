@@ -53,8 +53,8 @@ extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
 //                   p: act.data,act.scale,act.shift, grad.g,grad.y,grad.coef, w,bias,resid,out,stats, red_y,red_bn
 //  CONV_WGRAD       i: N,Hi,Wi,Ci,Ho,Wo,Co,kh,kw,stride,pad,nsplit   p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, partial
 //  WGRAD_FINALIZE   i: nsplit,Co,Ci,taps,accumulate                  p: partial,grad
-//  DW_FWD           i: N,H,W,C,k,nparts      p: in.data,in.scale,in.shift, w,bias,out,stats
-//  DW_BWD           i: N,H,W,C,k,nparts,phase p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial, red_bn,red_partial
+//  DW_FWD           i: N,H,W,C,k,nparts,stride  p: in.data,in.scale,in.shift, w,bias,out,stats
+//  DW_BWD           i: N,H,W,C,k,nparts,phase,stride,g_masked p: x.data,x.scale,x.shift, dy.g,dy.y,dy.coef, w,gin,wpartial, red_bn,red_partial
 //  DW_WGRAD_FINALIZE i: nparts,C,k,accumulate p: wpartial,grad
 //  STEM_FWD         i: N,H,W,Ho,Wo,Co,nparts,in_u8 p: x,w,bias,out,stats,in_affine
 //  STEM_WGRAD       i: N,H,W,Ho,Wo,Co,nparts,in_u8 p: x, dy.g,dy.y,dy.coef, partial,in_affine
@@ -127,6 +127,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.N = i[0]; a.H = i[1]; a.W = i[2]; a.C = i[3]; a.k = i[4]; a.nparts = i[5];
             a.in.data = p[0]; a.in.scale = (const float*)p[1]; a.in.shift = (const float*)p[2];
             a.w = (const float*)p[3]; a.bias = (const float*)p[4]; a.out = p[5]; a.stats = (float*)p[6];
+            a.stride = i[6];
             return mnas_dw_fwd(&a, stream);
         }
         case MNAS_OP_DW_BWD: {
@@ -136,7 +137,7 @@ static int run_one(const MnasOp& o, void* stream) {
             a.dy.g = p[3]; a.dy.y = p[4]; a.dy.coef = (const float*)p[5];
             a.w = (const float*)p[6]; a.gin = p[7]; a.wpartial = (float*)p[8];
             a.red_bn = (const float*)p[9]; a.red_partial = (float*)p[10]; a.phase = i[6];
-            a.g_masked = i[8];     // (i[7], p[11..15]: the retired SRC / g-affine forms' slots)
+            a.g_masked = i[8]; a.stride = i[7];     // (p[11..15]: the retired SRC / g-affine forms' slots)
             return mnas_dw_bwd(&a, stream);
         }
         case MNAS_OP_DW_WGRAD_FINALIZE:

@@ -158,6 +158,9 @@ int mnas_pwd_enabled();      // MNAS_PWD (default 1): DMA-pipelined 1x1 input gr
 int mnas_pwd_parts(int M, int Ci, int Co);
 int mnas_pwd_dgrad(const MnasConvGemm* c, void* stream);
 // K-streaming 1x1 GEMM (mnas_pws.hip): long-K forward / input gradient on the small-M stages (diagnosis build: MNAS_PWS=0 off, 1 forward only)
+int mnas_dw2_rows(int N, int H, int W, int C, int k, int nparts, int which);      // csrc/mnas_dw2.hip: stride-2 depthwise (SepConv reduce)
+int mnas_dw2_fwd(const MnasDwFwd* c, void* stream);
+int mnas_dw2_bwd(const MnasDwBwd* c, void* stream);
 int mnas_pws_enabled();
 int mnas_pws_parts(int mode, int M, int K, int N);
 int mnas_pws_run(const MnasConvGemm* c, void* stream);

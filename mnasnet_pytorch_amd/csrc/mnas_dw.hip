@@ -643,6 +643,7 @@ static bool dw_finish(DwArgs* a, int nparts) {
 // launch;  which = 3 wpartial of a phase-2 launch.
 static const int dw_form_of[4] = {-1, 0, 1, 2};
 extern "C" int mnas_dw_rows(int N, int H, int W, int C, int k, int nparts, int which) {
+    if (which == 4 || which == 7) return mnas_dw2_rows(N, H, W, C, k, nparts, which - 4);      // stride 2 (csrc/mnas_dw2.hip)
     if (which < 0 || which > 3) return -1;
     DwArgs a;
     int g;
@@ -663,7 +664,8 @@ extern "C" int mnas_dw_geometry(int N, int H, int W, int C, int k, int which, in
 }
 
 extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
-    if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1) return MNAS_EINVAL;
+    if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1 || c->stride < 0 || c->stride > 2) return MNAS_EINVAL;
+    if (c->stride == 2) return mnas_dw2_fwd(c, stream);
     DwArgs a;
     int g;
     if (!dw_choose(c->N, c->H, c->W, c->C, c->k, -1, &a, &g) || !dw_finish(&a, c->nparts)) return MNAS_EINVAL;
@@ -683,6 +685,8 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
 
 extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     if (!c || (c->k != 3 && c->k != 5) || (c->C & 7) || c->nparts < 1 || c->phase < 0 || c->phase > 2) return MNAS_EINVAL;
+    if (c->stride < 0 || c->stride > 2) return MNAS_EINVAL;
+    if (c->stride == 2) return mnas_dw2_bwd(c, stream);
     hipStream_t s = (hipStream_t)stream;
     if (!c->x.data || !c->dy.g) return MNAS_EINVAL;
     const bool red = c->red_bn != nullptr && c->red_partial != nullptr;

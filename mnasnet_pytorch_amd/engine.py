@@ -57,8 +57,8 @@ class _ConvInfo:
                 raise NotImplementedError("1x1 convs are stride 1 / pad 0 in this network")
             self.kind = "pw"
         elif self.groups == self.cin == self.cout and self.groups > 1:
-            if self.k not in (3, 5) or self.stride != 1 or self.pad != self.k // 2:
-                raise NotImplementedError("depthwise: k in {3,5}, stride 1, pad k//2 (mnasnet.py:122-125)")
+            if self.k not in (3, 5) or self.stride not in (1, 2) or self.pad != self.k // 2:
+                raise NotImplementedError("depthwise: k in {3,5}, stride 1 or 2, pad k//2 (mnasnet.py:73-81,122-125)")
             self.kind = "dw"
         elif self.groups == 1 and self.k == 3 and self.pad == 1 and self.cin == 3 and self.stride == 2:
             self.kind = "stem"
@@ -453,9 +453,10 @@ class Program:
             self.patch_x.append((j, 0))
         elif ci.kind == "dw":
             nlaunch = max(64, min(_STATS_PARTS, _cdiv(M * ci.cout, 256 * 16 * 2)))
-            fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nlaunch], [],
+            # stride 2 = SepConv(reduce=True)'s depthwise conv (mnasnet.py:73-81): plain direct kernels (csrc/mnas_dw2.hip)
+            fwd.add(L.OP_DW_FWD, [N, Hi, Wi, ci.cout, ci.k, nlaunch, ci.stride], [],
                     a_in.act_ptrs() + [ci.w_fwd.data_ptr(), bias, y.data_ptr(), stats])
-            nparts = lib.mnas_dw_rows(N, Hi, Wi, ci.cout, ci.k, nlaunch, 0)      # columns of the stats table
+            nparts = lib.mnas_dw_rows(N, Hi, Wi, ci.cout, ci.k, nlaunch, 0 if ci.stride == 1 else 4)      # columns of the stats table
             if nparts < 1:
                 raise RuntimeError("unsupported depthwise shape %s" % ((N, Hi, Wi, ci.cout, ci.k),))
         else:
@@ -595,6 +596,21 @@ class Program:
                          [None] + gy + [eng.scratch_wgrad.data_ptr(), self._aff_ptr], WS)
             self.patch_x_bwd = (ops, jx, 0)
             ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+        elif ci.kind == "dw" and ci.stride == 2:
+            # SepConv(reduce=True): two plain launches, no fused reduce (the producer of x runs its own mnas_bn_bwd_reduce)
+            nparts = max(64, min(eng.dw_bwd_parts, _cdiv(M * Co, 256 * 16 * 2)))
+            if g.data_ptr() in self._masked_g:
+                raise AssertionError("masked gradient handed to the stride-2 depthwise backward")
+            wrows = lib.mnas_dw_rows(N, Hi, Wi, Co, ci.k, nparts, 7)
+            if wrows < 1 or wrows * ci.k * ci.k * Co > eng.scratch_wgrad.numel():
+                raise RuntimeError("unsupported stride-2 depthwise shape %s" % ((N, Hi, Wi, Co, ci.k),))
+            dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), None, eng.scratch_wgrad.data_ptr(), None, None]
+            ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 2, 2, 0], [], dwp, WS)              # weight gradient
+            ops.add(L.OP_DW_WGRAD_FINALIZE, [wrows, Co, ci.k, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+            if need_gin:
+                gin = new((N, Hi, Wi, ci.cin))
+                dwp = a_in.act_ptrs() + gy + [ci.w_fwd.data_ptr(), gin.data_ptr(), None, None, None]
+                ops.add(L.OP_DW_BWD, [N, Hi, Wi, Co, ci.k, nparts, 1, 2, 0], [], dwp, 0)           # input gradient
         elif ci.kind == "dw":
             nparts = max(64, min(eng.dw_bwd_parts, _cdiv(M * Co, 256 * 16 * 2)))
             gin = new((N, Hi, Wi, ci.cin))
@@ -723,7 +739,7 @@ class Program:
             if rec[3] is act or (rec[3].data is act.data and rec[3].bn is act.bn):
                 ci = rec[1]
                 # ... and carries the fused reduce (its own input is a virtual activation), the form g_masked exists for
-                return ci.kind == "dw" and ci.k in self.eng.dw_fused_k and rec[2] is not None and rec[2].bn is not None
+                return ci.kind == "dw" and ci.stride == 1 and ci.k in self.eng.dw_fused_k and rec[2] is not None and rec[2].bn is not None
         return False
 
     def _conv_bwd_se_proj(self, ops: _OpList, rec, g, g_reduced, se_rec):

@@ -44,6 +44,9 @@ SEPCONVS = {
     "sep_32_16": (32, 16, 3, False, 0, 2, 12, 12),           # the network's own SepConv (mnasnet.py:180)
     "sep_16_16_rep1": (16, 16, 3, False, 1, 2, 12, 12),
     "sep_24_32_rep2_k5": (24, 32, 5, False, 2, 2, 10, 12),
+    # reduce=True: the depthwise convs run with STRIDE 2 (mnasnet.py:73-75) -- with repeat = 1 twice in a row (12x13 -> 6x7 -> 3x4)
+    "sep_32_16_reduce": (32, 16, 3, True, 0, 2, 12, 12),
+    "sep_16_24_rep1_reduce_k5": (16, 24, 5, True, 1, 3, 12, 13),
 }
 # name: (ccf, N, H, W, train, proj_gamma)   -- SURVEY 8(c)(4); proj_gamma: see oracle.init_state
 NETS = {

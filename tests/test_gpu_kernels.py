@@ -366,6 +366,62 @@ def test_dw_bwd(shape, phase):
 
 
 # ---------------------------------------------------------------------------------------------------
+# stride-2 depthwise (SepConv(reduce=True), mnasnet.py:73-81; csrc/mnas_dw2.hip): forward + statistics, input gradient, weight
+# gradient through mnas_dw_fwd / mnas_dw_bwd with stride = 2; odd planes, 5x5, more than 256 channel pairs (two channel blocks)
+@pytest.mark.parametrize("shape", [(2, 12, 12, 48, 3), (3, 13, 11, 72, 5), (2, 9, 9, 600, 3), (5, 7, 8, 32, 5)])
+def test_dw_stride2(shape):
+    lib = L.load()
+    N, H, W, C_, k = shape
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // 2 + 1, (W + 2 * p - k) // 2 + 1
+    x = _x((N, C_, H, W), 1)
+    w = O.det_param("t.conv.weight", (C_, 1, k, k), 2)
+    bias = 0.1 * O.det_uniform((C_,), 3)
+    sc, sh = 1 + 0.3 * O.det_uniform((C_,), 4), 0.2 * O.det_uniform((C_,), 5)
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref = F.conv2d(a, w, bias, stride=2, padding=p, groups=C_)
+    assert tuple(ref.shape) == (N, C_, Ho, Wo)
+    xd, dsc, dsh, db = nhwc(x), sc.cuda(), sh.cuda(), bias.cuda()
+    wp = pack(w, L.PACK_DW)
+    nparts = 23
+    rows = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 4)
+    assert 1 <= rows <= nparts
+    out = torch.empty((N, Ho, Wo, C_), dtype=torch.bfloat16, device="cuda")
+    st = torch.full((2, C_, rows), float("nan"), device="cuda")
+    f = L.MnasDwFwd()
+    f.N, f.H, f.W, f.C, f.k, f.nparts, f.stride = N, H, W, C_, k, nparts, 2
+    f.in_ = act_in(xd, dsc, dsh)
+    f.w, f.bias, f.out, f.stats = wp.data_ptr(), db.data_ptr(), out.data_ptr(), st.data_ptr()
+    L.check(lib.mnas_dw_fwd(C.byref(f), L.cur_stream()), "dw_fwd stride 2")
+    assert relerr(from_nhwc(out), ref) < TOL_BF16
+    s1, s2 = st[0].cpu().double().sum(-1), st[1].cpu().double().sum(-1)
+    assert relerr(s1, ref.double().sum((0, 2, 3))) < 1e-3 and relerr(s2, (ref.double() ** 2).sum((0, 2, 3))) < 1e-3
+    # backward: dy-on-read from (g, y, coef) at the OUTPUT resolution
+    g, y = _x((N, C_, Ho, Wo), 6), _x((N, C_, Ho, Wo), 7)
+    b = rand_bn_coefs(C_, 9, O)
+    dy = dy_ref(g, y, b, rounded=False)
+    ref_gin = torch.nn.grad.conv2d_input((N, C_, H, W), w, dy, stride=2, padding=p, groups=C_)
+    ref_dw = torch.nn.grad.conv2d_weight(a, (C_, 1, k, k), dy, stride=2, padding=p, groups=C_)
+    gd, yd, bd = nhwc(g), nhwc(y), b.cuda()
+    gin = torch.empty((N, H, W, C_), dtype=torch.bfloat16, device="cuda")
+    wrows = lib.mnas_dw_rows(N, H, W, C_, k, nparts, 7)
+    wpart = torch.full((wrows, k * k, C_), float("nan"), device="cuda")
+    d = L.MnasDwBwd()
+    d.N, d.H, d.W, d.C, d.k, d.nparts, d.stride = N, H, W, C_, k, nparts, 2
+    d.x, d.dy = act_in(xd, dsc, dsh), grad_in(gd, yd, bd)
+    d.w, d.gin, d.wpartial = wp.data_ptr(), gin.data_ptr(), wpart.data_ptr()
+    for ph in (1, 2):
+        d.phase = ph
+        L.check(lib.mnas_dw_bwd(C.byref(d), L.cur_stream()), "dw_bwd stride 2")
+    assert relerr(from_nhwc(gin), ref_gin) < TOL_BF16
+    grad = torch.full((C_, 1, k, k), float("nan"), device="cuda")
+    L.check(lib.mnas_dw_wgrad_finalize(wpart.data_ptr(), wrows, C_, k, grad.data_ptr(), 0, L.cur_stream()))
+    assert relerr(grad.cpu(), ref_dw) < TOL_F32
+    d.phase = 0                                        # the fused one-sweep form exists for stride 1 only
+    assert lib.mnas_dw_bwd(C.byref(d), L.cur_stream()) == L.EINVAL
+
+
+# ---------------------------------------------------------------------------------------------------
 # (N, H, W[, Co]): W % 4 == 0 with 32 couts runs the band kernels (csrc/mnas_stem.hip; weight gradient also needs Wo % 8 == 0),
 # everything else the im2col staging of k_igemm / k_wgrad; partial last bands, odd heights, more bands than workgroups
 @pytest.mark.parametrize("shape", [(2, 12, 12), (3, 33, 21), (1, 64, 64), (3, 40, 48), (2, 37, 32), (11, 18, 16), (2, 224, 224),

@@ -128,9 +128,10 @@ def test_block(name, dw_split):
 @pytest.mark.parametrize("name", sorted(C.SEPCONVS))
 @pytest.mark.parametrize("train", [True, False])
 def test_sepconv(name, train):
-    """SepConv (mnasnet.py:64-103) as its own parity row: the network's instance and the list-multiplied forms (repeat = 1, 2:
+    """SepConv (mnasnet.py:64-103) as its own parity row: the network's instance, the list-multiplied forms (repeat = 1, 2:
     the shared (depthwise, pointwise) pair is traced `repeat` times with the same parameter pointers -- gradients accumulate,
-    the BatchNorm buffers are updated once per application) against the mirror (tight) and the reference's golden (loose)."""
+    the BatchNorm buffers are updated once per application) and reduce=True (STRIDE-2 depthwise convs, mnasnet.py:73-75:
+    csrc/mnas_dw2.hip; with repeat = 1 two of them in a row) against the mirror (tight) and the reference's golden (loose)."""
     from mnasnet_pytorch_amd import SepConv
     g = load("sepconvs")
     cin, cout, k, reduce, repeat, N, H, W = C.SEPCONVS[name]
@@ -163,17 +164,6 @@ def test_sepconv(name, train):
             assert int(sd[kk[len(tag) + 1:]]) == int(g[kk]), kk                       # `repeat` updates for the shared pair
         if kk.startswith(tag + "/") and "running" in kk:
             assert rl2(sd[kk[len(tag) + 1:]].cpu(), g[kk]) < 4e-2, kk
-
-
-def test_sepconv_reduce_is_refused_loudly():
-    """SepConv(reduce=True) (mnasnet.py:73-75: a stride-2 depthwise conv) is not on MNASNet's path (Mnasnet builds
-    SepConv(32, 16, 3) only, mnasnet.py:180) and has no HIP kernel: construction works (state_dict surface), running it raises --
-    never a silent fallback.  INTEGRATION.md lists it."""
-    from mnasnet_pytorch_amd import SepConv
-    m = SepConv(32, 16, kernel_size=3, reduce=True).cuda().train()
-    assert m.sequence[0].conv.stride == (2, 2)
-    with pytest.raises(NotImplementedError, match="depthwise: k in \\{3,5\\}, stride 1"):
-        m(torch.zeros(2, 32, 16, 16, device="cuda"))
 
 
 def _stage_setup(name, proj_gamma, spec=None):
