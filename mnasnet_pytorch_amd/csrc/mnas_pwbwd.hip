@@ -564,7 +564,7 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
 }
 
 // Supported channel pairs: the pointwise convs of the 112x112 / 56x56 / 28x28 stages of MNASNet-1.0 (16<->32/48, 24<->72,
-// 40<->240 channels) and the narrowing convs of the 14x14 stage (480->80, 576->96; channel slices).  Other shapes:
+// 40<->240 channels; 40<->120 for the cut_channels_first=True topology) and the narrowing convs of the 14x14 stage (480->80, 576->96; channel slices).  Other shapes:
 // MNAS_EINVAL (use mnas_conv_gemm + mnas_conv_wgrad).
 struct PwCfg { int nto, nti_total, nti_slice, nslices, pt; };
 static const PwCfg* pw_cfg(int Ci, int Co) {
@@ -574,6 +574,8 @@ static const PwCfg* pw_cfg(int Ci, int Co) {
     // 185 -> 143 VGPRs (RECOMP form 149 -> 108) = 3-4 resident workgroups per CU instead of 2, step 10.98 -> 10.83 ms in one
     // call; the same change is neutral for 72 -> 24 and loses on the 112x112 layers (11.07 ms with all five on 64-pixel tiles)
     static const PwCfg cfgs[] = {{1, 2, 2, 1, 2}, {1, 3, 3, 1, 2}, {3, 1, 1, 1, 2}, {5, 2, 2, 1, 1}, {2, 5, 5, 1, 2}, {15, 3, 3, 1, 1},
+                                 {8, 3, 3, 1, 1},       // 40 -> 120 and
+                                 {3, 8, 4, 2, 1},       // 120 -> 40 (two 64-channel slices): the 28x28 blocks of Mnasnet(cut_channels_first=True)
                                  {3, 15, 5, 3, 1},      // 240 -> 40: three 80-channel slices
                                  {5, 30, 5, 6, 1},      // 480 -> 80: six 80-channel slices
                                  {6, 36, 6, 6, 1}};     // 576 -> 96: six 96-channel slices
@@ -614,7 +616,7 @@ extern "C" int mnas_pw_bwd(const MnasPwBwd* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_PWB(O_, I_, P_) if (cfg->nto == O_ && cfg->nti_slice == I_ && cfg->pt == P_) return launch_pw_bwd<O_, I_, P_>(a, c->nparts, s, cfg->nslices);
     MNAS_PWB(1, 2, 2) MNAS_PWB(1, 3, 2) MNAS_PWB(3, 1, 2) MNAS_PWB(5, 2, 1) MNAS_PWB(2, 5, 2) MNAS_PWB(15, 3, 1)
-    MNAS_PWB(3, 5, 1) MNAS_PWB(5, 5, 1) MNAS_PWB(6, 6, 1)
+    MNAS_PWB(3, 5, 1) MNAS_PWB(5, 5, 1) MNAS_PWB(6, 6, 1) MNAS_PWB(8, 3, 1) MNAS_PWB(3, 4, 1)
 #undef MNAS_PWB
     return MNAS_EINVAL;
 }

@@ -624,7 +624,7 @@ def test_wgrad_finalize_split_ranges(nsplit, Co, Ci, taps, acc):
 # fused 1x1 backward (input gradient + weight gradient + BatchNorm-backward reduce of x's producer)
 PWB = [  # N,H,W,Ci,Co  -- every supported (cin tiles, cout tiles) pair; ragged pixel counts (tile tails)
     (2, 12, 12, 32, 16), (3, 11, 9, 48, 16), (2, 13, 12, 16, 48), (2, 9, 9, 24, 72), (2, 10, 9, 72, 24),
-    (1, 9, 8, 40, 240), (1, 11, 7, 240, 40), (1, 9, 7, 480, 80), (1, 10, 7, 576, 96),
+    (1, 9, 8, 40, 240), (1, 11, 7, 240, 40), (1, 9, 7, 480, 80), (1, 10, 7, 576, 96), (2, 9, 8, 40, 120), (2, 11, 7, 120, 40),
 ]
 
 
