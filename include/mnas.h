@@ -450,7 +450,8 @@ int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 #define MNAS_OP_ADD_ACT 12
 #define MNAS_OP_NCHW_TO_NHWC 13
 #define MNAS_OP_PACK_WEIGHTS 14
-#define MNAS_OP_EVENT_RECORD 15    /* p[0] = event handle from mnas_event_create: hipEventRecord on the op's stream */
+#define MNAS_OP_EVENT_RECORD 15    /* p[0] = event handle from mnas_event_create: hipEventRecord on the op's stream;
+                                      p[1] = NULL or a HOST int*: the record is skipped while *p[1] == 0 (measurement gating) */
 #define MNAS_OP_EVENT_WAIT 16      /* p[0] = event handle: hipStreamWaitEvent(op's stream, event) */
 #define MNAS_OP_PW_BWD 17
 #define MNAS_OP_PACK_BATCH 18

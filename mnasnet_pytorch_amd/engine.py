@@ -155,11 +155,12 @@ class _OpList:
                 and (self.eng.profile_filter is None or self.eng.profile_filter(opcode, tuple(ints))))
         if prof:
             ev0, ev1 = self.eng.new_event(), self.eng.new_event()
-            self.items.append((L.OP_EVENT_RECORD, [], [], [ev0], stream))
+            gate = C.addressof(self.eng.profile_gate)          # host int: 0 = these two records are skipped (Engine.profile_gate)
+            self.items.append((L.OP_EVENT_RECORD, [], [], [ev0, gate], stream))
         self.items.append((opcode, list(ints), list(dbls), list(ptrs), stream))
         idx = len(self.items) - 1
         if prof:
-            self.items.append((L.OP_EVENT_RECORD, [], [], [ev1], stream))
+            self.items.append((L.OP_EVENT_RECORD, [], [], [ev1, gate], stream))
             self.eng.profile_events.append(((self.tag, opcode, tuple(ints)), ev0, ev1))
         return idx
 
@@ -1011,6 +1012,8 @@ class Engine:
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
         self.profile_filter = None       # optional predicate (opcode, ints) -> bool narrowing the bracketed launches
         self.profile_events = []         # [(tag, start_handle, stop_handle)]
+        self.profile_gate = C.c_int(1)   # 0: the bracketing event records of the compiled programs are skipped (read at run time by
+                                         # mnas_run_ops: bench.py switches them on for the last step of a timed window only)
         self._events = []                # every HIP event handle the compiled programs own (destroyed with them)
         first = self.steps[0][1] if self.steps[0][0] == "conv" else self.steps[0][1][0]
         self.in_channels_hint = self.info[id(first)].cin

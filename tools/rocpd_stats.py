@@ -102,6 +102,15 @@ def timeline_main(path, nlast):
         print("# around a step boundary (us relative to k_adam start): queue start dur name")
         for st, en, name, qq in rows[max(0, i0 - 6):i0 + 40]:
             print("#   q%s %9.1f %8.1f  %s" % (qq, (st - base) / 1e3, (en - st) / 1e3, name[:70]))
+    # gaps of 2..50 us grouped by the kernel that was WAITING to start (round 5: kernels that use scratch memory pay a dispatch
+    # set-up of ~6 us that the others do not)
+    grp = {}
+    for g, a, b in gaps:
+        if 2000 <= g < 50000:
+            e = grp.setdefault((b or "")[:70], [0, 0]); e[0] += 1; e[1] += g
+    print("# gaps of 2-50 us by the kernel that starts after them: n, total us, mean us")
+    for k, (n_, tot) in sorted(grp.items(), key=lambda kv: -kv[1][1])[:30]:
+        print("#   %4d %9.1f %6.2f  %s" % (n_, tot / 1e3, tot / 1e3 / n_, k))
     print("# largest gaps (us): after -> before")
     for g, a, b in sorted(gaps, key=lambda x: -x[0])[:25]:
         print("%9.1f  %s  ->  %s" % (g / 1e3, (a or "")[:60], (b or "")[:60]))
