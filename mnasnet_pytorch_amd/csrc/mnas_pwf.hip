@@ -152,9 +152,18 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
                                                  (pwf_lds_ptr)(dst + 256 * i + wave * 64), 16, 0, 0);
         }
     };
+    // Single-k-step layers (Ci <= 32: 16 -> 48 at 112x112, 24 -> 72 at 56x56 -- bandwidth-bound, 5.4 TB/s on a materialised input):
+    // the activation is applied to the MFMA B fragment in REGISTERS after the LDS read (a fragment is read by exactly one wave, its
+    // 8 coefficient pairs are per-lane constants for the whole kernel) instead of in place in LDS, where the read-modify-write sat
+    // between the DMA wait and the barrier of every phase: 97 -> 77 us for 16 -> 48 on a virtual input (round 5, tools/kbench.py).
+    // Same act8 on the same raw chunk -> bit-identical.
+    const bool frag_xf = MODE == 0 && has_coef && a.nkc == 1 && a.kc == 32 && !PWF_ABL(a, 2);
+    float fx_s[8], fx_t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fx_s[j] = frag_xf ? lds_coef[lg * 8 + j] : 0.f; fx_t[j] = frag_xf ? lds_coef[a.Kpad + lg * 8 + j] : 0.f; }
     // relu(scale*x+shift) in place on the slots THIS thread's DMA wrote (after its own vmcnt wait)
     auto transform_a = [&](int slot, int tile0, int k0) {
-        if (!has_coef || PWF_ABL(a, 2)) return;
+        if (!has_coef || frag_xf || PWF_ABL(a, 2)) return;
         uint4* t = lds_a + slot * BP * pitch;
 #pragma unroll
         for (int i = 0; i < MAXA; ++i) {
@@ -290,8 +299,13 @@ __global__ __launch_bounds__(256) void k_pwf(PwfArgs a) {
             for (int ks = 0; ks < ksteps; ++ks) {
                 bf16x8_t bfrag[PT];
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
+                for (int pt = 0; pt < PT; ++pt) {
                     bfrag[pt] = *(const bf16x8_t*)(ta + ((wave * PT + pt) * 16 + l15) * pitch + ks * 4 + lg);
+                    if (frag_xf) {                           // (ks == 0: the layer has one k-step)
+                        const uint4 v = act8(*(const uint4*)&bfrag[pt], fx_s, fx_t);
+                        bfrag[pt] = *(const bf16x8_t*)&v;
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const bf16x8_t afrag = *(const bf16x8_t*)(tw + (nt * 16 + l15) * pitch + ks * 4 + lg);
