@@ -34,11 +34,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world2(tmp_path, side, opt="adam"):
+def _run_world2(tmp_path, side, opt="adam", mixed=False):
     port = _free_port()
     outs = [str(tmp_path / ("rank%d_side%d.pt" % (r, side))) for r in range(2)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "world2_worker.py"), str(r), "2", str(port), str(side), outs[r], opt],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "world2_worker.py"), str(r), "2", str(port), str(side), outs[r], opt] + (["mixed"] if mixed else []),
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     logs = []
     for p in procs:
@@ -54,7 +54,7 @@ def _run_world2(tmp_path, side, opt="adam"):
     return [torch.load(o) for o in outs]
 
 
-def _emulate(opt="adam"):
+def _emulate(opt="adam", mixed=False):
     """Both ranks in ONE process: rank 0's initial parameters, per step two forward+backward passes (one per rank's batch)
     accumulated into the same flat gradient buffer, optimizer with grad_scale = 1/2."""
     from mnasnet_pytorch_amd.train_step import Trainer
@@ -62,7 +62,7 @@ def _emulate(opt="adam"):
     _no_dropout(m)
     tr = Trainer(m, lr=1e-3, optimizer=opt)
     tr.optimizer.grad_scale = 0.5
-    batches = [tuple(v.cuda() for v in rank_batch(r)) for r in range(2)]
+    batches = [tuple(v.cuda() for v in rank_batch(r, mixed=mixed)) for r in range(2)]
     p0 = tr.flat_p.detach().cpu().clone()
     g1 = p1 = None
     for step in range(3):
@@ -136,3 +136,16 @@ def test_real_engine_world2_one_gpu_sgd(tmp_path):
     _check_ranks(r0, r1, 0)
     eu, d3 = _compare(r0, _emulate("sgd"), "sgd")
     assert eu < 1e-2 and d3 < 5e-6
+
+
+def test_real_engine_world2_mixed_shapes(tmp_path):
+    """BASELINE config 5's straggler case on the REAL engine: the two ranks of every step run different input shapes (64x96 and
+    96x64: different compiled programs, different launch lists, stage-done callbacks at different times).  The gradient layout
+    does not depend on the input shape, so the buckets still go out in the same order with the same bounds, the ranks end up with
+    bit-equal parameters, and step 1 equals the single-process emulation over the two differently shaped batches."""
+    r0, r1 = _run_world2(tmp_path, 0, "adam", mixed=True)
+    assert tuple(r0["shape"][2:]) == (64, 96) and tuple(r1["shape"][2:]) == (96, 64)
+    assert r0["programs"] != r1["programs"]
+    _check_ranks(r0, r1, 0)
+    eu, d3 = _compare(r0, _emulate("adam", mixed=True), "adam, mixed shapes across ranks")
+    assert eu < 0.25 and d3 <= 3 * 2 * 1e-3 * 1.01

@@ -11,11 +11,13 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 
-def rank_batch(rank, N=32, S=64):
-    """Different data on every rank (closed form: the parent process rebuilds the same batches for its emulation)."""
+def rank_batch(rank, N=32, S=64, mixed=False):
+    """Different data on every rank (closed form: the parent process rebuilds the same batches for its emulation).  mixed: the
+    ranks of one step run DIFFERENT input shapes (BASELINE config 5's straggler case: rank 0 a 64x96 cluster, rank 1 a 96x64 one)."""
     import torch
     import cases as C
-    x = C.det_input((N, 3, S, S), seed=C.INPUT_SEED + 17 * rank)
+    H, W = ((S, S + 32) if rank % 2 == 0 else (S + 32, S)) if mixed else (S, S)
+    x = C.det_input((N, 3, H, W), seed=C.INPUT_SEED + 17 * rank)
     t = (torch.arange(N) * 3 + rank) % 10
     return x, t
 
@@ -23,6 +25,7 @@ def rank_batch(rank, N=32, S=64):
 def main():
     rank, world, port, side, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     opt = sys.argv[6] if len(sys.argv) > 6 else "adam"
+    mixed = len(sys.argv) > 7 and sys.argv[7] == "mixed"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -42,7 +45,7 @@ def main():
         tr = Trainer(m, lr=1e-3, distributed=True, optimizer=opt)
         tr.engine.use_side_stream = bool(side)
         tr.engine.reset_programs()
-        x, t = rank_batch(rank)
+        x, t = rank_batch(rank, mixed=mixed)
         x, t = x.cuda(), t.cuda()
         p0 = tr.flat_p.detach().cpu().clone()           # after the rank-0 broadcast
         logs, losses, g1, p1 = [], [], None, None
@@ -56,7 +59,8 @@ def main():
         torch.cuda.synchronize()
         torch.save({"flat_p": tr.flat_p.detach().cpu(), "flat_p0": p0, "flat_p1": p1, "flat_g1": g1, "logs": logs, "losses": losses,
                     "bounds": list(tr.buckets.bounds), "world": tr.world, "side": tr.engine.use_side_stream,
-                    "rm0": m.features[0].bn.running_mean.detach().cpu()}, out)
+                    "rm0": m.features[0].bn.running_mean.detach().cpu(), "shape": tuple(x.shape),
+                    "programs": sorted(k[1:3] for k, lst in tr.engine.programs.items() if lst)}, out)
     finally:
         dist.destroy_process_group()
 
