@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-INCLUSIVE step rate (never `value`): pinned host batches, "
                                                       "double-buffered upload on a copy stream under the previous step, as fp32 "
                                                       "(what train.py:427 uploads) and as uint8 with the normalisation fused into the stem")
+    ap.add_argument("--one-device", action="store_true",
+                    help="FUNCTIONAL TEST ONLY (tests/test_gpu_world2.py): every rank on cuda:0, backend gloo on device tensors (RCCL "
+                         "refuses two ranks on one device) -- exercises this script's multi-rank code path on a 1-GPU box; the line "
+                         "says so in `overrides` and its numbers mean nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration probes (copy GB/s, packed-FMA TFLOP/s, clocks)")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
@@ -545,12 +549,17 @@ def main():
     # has initialised the GPU before main() runs, and a process that has must not fork+exec on this pool
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ)
     smi = smi_snapshot() if (rank == 0 and not args.no_box and not profiled) else None
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mnasnet_pytorch_amd import FineTuneModelPool, load_model, _lib as L
     from mnasnet_pytorch_amd.train_step import Trainer
@@ -578,6 +587,8 @@ def main():
     trainer = Trainer(model, lr=1e-3, distributed=distributed)
     eng = trainer.engine
     overrides = apply_overrides(eng)          # diagnosis switches (environment); every honoured one is echoed in the JSON line
+    if args.one_device:
+        overrides.append("--one-device (functional test of the multi-rank path: all ranks on cuda:0 over gloo; NOT a measurement)")
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
                L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD,

@@ -149,3 +149,24 @@ def test_real_engine_world2_mixed_shapes(tmp_path):
     _check_ranks(r0, r1, 0)
     eu, d3 = _compare(r0, _emulate("adam", mixed=True), "adam, mixed shapes across ranks")
     assert eu < 0.25 and d3 <= 3 * 2 * 1e-3 * 1.01
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py's own N > 1 code path (rank-0 broadcast inside Trainer, barrier + MAX-over-ranks timing, calibration steps on every
+    rank, only rank 0 printing) as the driver launches it -- `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` --
+    with --one-device (both ranks on cuda:0 over gloo): ONE JSON line, n_gpus 2, weak scaling, global batch = 2 x per-GPU batch, a
+    roofline object, no cpu_baseline (rank 0 at N = 1 only), and the override recorded so that the line can never pass for a
+    measurement."""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--batch", "32", "--size", "64", "--min-seconds", "0", "--one-device", "--no-box"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["config"]["global_batch"] == 64
+    assert d["value"] > 0 and d["config"]["parallelism"] == "dp2" and "cpu_baseline" not in d
+    assert d["roofline"]["launches_per_step"] >= 1 and any("--one-device" in o for o in d["overrides"])
