@@ -506,6 +506,7 @@ int mnas_event_elapsed_ms(void* start, void* stop, float* ms);   /* non-zero if 
  *                  flop = blocks*256*iters*8*4;  TFLOP/s / 65.536 = sustained shader clock in GHz (256 CUs x 4 SIMDs x 16 lanes). */
 int mnas_probe_copy(const void* src, void* dst, int64_t bytes, void* stream);
 int mnas_probe_valu(float* out, int blocks, int iters, void* stream);
+int mnas_probe_empty(int blocks, int threads, void* stream);      /* a kernel that does nothing: the cost of one launch in a stream */
 
 #ifdef __cplusplus
 }

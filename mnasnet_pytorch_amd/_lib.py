@@ -180,6 +180,7 @@ SYMBOLS = {
     "mnas_event_elapsed_ms": (c_int, [c_void_p, c_void_p, C.POINTER(c_float)]),
     "mnas_probe_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mnas_probe_valu": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mnas_probe_empty": (c_int, [c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -30,6 +30,15 @@ __global__ __launch_bounds__(256) void k_probe_valu(float* __restrict__ out, int
     if (s.x + s.y == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s.x;      // never true: keeps the chains alive
 }
 
+// a kernel that does nothing: what one dependent launch costs on this box (the floor under the 138 bookkeeping launches of a step)
+__global__ void k_probe_empty(int* p) { if (p && threadIdx.x == 1024) *p = 0; }
+extern "C" int mnas_probe_empty(int blocks, int threads, void* stream) {
+    if (blocks < 1 || threads < 1 || threads > 1024) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_probe_empty, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (int*)nullptr);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 extern "C" int mnas_probe_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     if (!src || !dst || bytes < 16 || (bytes & 15)) return MNAS_EINVAL;
     hipLaunchKernelGGL(k_probe_copy, dim3(8192), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, (size_t)(bytes >> 4));
