@@ -23,6 +23,9 @@
 //              is recomputed on the matrix cores (same MFMA, same k order as the forward -> the same bits) and dy is formed
 //              in place over the raw g tile.  One more barrier per tile; a third of the launch's reads gone.
 #include "mnas_common.h"
+#ifndef MNAS_PWB_PF
+#define MNAS_PWB_PF 1        // 0: no form prefetches (A/B builds)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) short pw_s4_t;
 typedef __attribute__((address_space(3))) pw_s4_t* pw_lds_s4_ptr;
@@ -60,7 +63,7 @@ __device__ __forceinline__ bf16x8_t pw_tr_frag(const uint16_t* tile, int ld, int
 // pixels are contiguous in memory, so these are full-line writes -- with the fused reduce done on that copy-out path (its
 // operand red_y loaded as 16-byte chunks before the MFMA phases).  The 8-byte-per-lane stores of the MFMA epilogue
 // (partial lines) sustained 2-2.4 TB/s of writes; the same change took the widening forward convs from 2.4 to 4.7 TB/s.
-template <int NTO, int NTI, int PT, bool OS, int FORM>
+template <int NTO, int NTI, int PT, bool OS, int FORM, bool PF>
 __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     static_assert(FORM == 0 || (FORM == 2 && !OS), "RECOMP rides on the plain epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,25 +191,39 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     // range (a fraction of ONE image for the squeeze-excite project conv: csrc/mnas_se.hip k_se_proj_du)
     const int mend = a.seg_px ? min(a.M, ((int)blockIdx.x + 1) * a.seg_px) : a.M;
     const int tstep = a.seg_px ? BP : (int)gridDim.x * BP;
-    for (int tile0 = a.seg_px ? (int)blockIdx.x * a.seg_px : (int)blockIdx.x * BP; tile0 < mend; tile0 += tstep) {
-        __syncthreads();                                     // previous tile's fragments consumed (first pass: setup visible)
-        // ---- issue every load of the tile, then transform + write
-        uint4 vg[ND], vy[ND], vx[NX];
+    // The tile's global loads (g, y of dy-on-load; the x chunks) are issued ONE TILE AHEAD (PF): right after the staging barrier of
+    // tile t the loads of tile t+1 go out into a second register set and land under the MFMA phases and the epilogue / copy-out
+    // of tile t, instead of standing exposed at the top of every tile.  Per-launch, round 5 (us without -> with): 576->96 72.6 ->
+    // 65.9, 480->80 64 -> 58, 240->40 98 -> 89, 72->24 88 -> 81, 24->72 75 -> 70, 48->16 199 -> 172, 16->48 161 -> 148.  Not for
+    // 40->240 (16 more uint4 per thread: 255 VGPRs + spills, 74 -> 80) and 32->16 (131 -> 140): launch_pw_bwd picks.
+    uint4 ng[ND], ny[ND], nx[NX];
+    auto issue = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            vg[i] = make_uint4(0, 0, 0, 0); vy[i] = make_uint4(0, 0, 0, 0);
-            if (pd[i] >= 0 && tile0 + pd[i] < mend) {
-                const size_t off = (size_t)(tile0 + pd[i]) * a.Co + cd8[i] * 8;
-                vg[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
-                if constexpr (FORM != 2) vy[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
+            ng[i] = make_uint4(0, 0, 0, 0); ny[i] = make_uint4(0, 0, 0, 0);
+            if (pd[i] >= 0 && t0 + pd[i] < mend) {
+                const size_t off = (size_t)(t0 + pd[i]) * a.Co + cd8[i] * 8;
+                ng[i] = *(const uint4*)((const uint16_t*)a.dy.g + off);
+                if constexpr (FORM != 2) ny[i] = *(const uint4*)((const uint16_t*)a.dy.y + off);
             }
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            vx[i] = make_uint4(0, 0, 0, 0);
-            if (pa[i] >= 0 && tile0 + pa[i] < mend)
-                vx[i] = *(const uint4*)((const uint16_t*)a.x.data + (size_t)(tile0 + pa[i]) * a.Ci + ci0 + ca8[i] * 8);
+            nx[i] = make_uint4(0, 0, 0, 0);
+            if (pa[i] >= 0 && t0 + pa[i] < mend)
+                nx[i] = *(const uint4*)((const uint16_t*)a.x.data + (size_t)(t0 + pa[i]) * a.Ci + ci0 + ca8[i] * 8);
         }
+    };
+    const int tfirst = a.seg_px ? (int)blockIdx.x * a.seg_px : (int)blockIdx.x * BP;
+    if (PF) issue(tfirst);
+    for (int tile0 = tfirst; tile0 < mend; tile0 += tstep) {
+        __syncthreads();                                     // previous tile's fragments consumed (first pass: setup visible)
+        if (!PF) issue(tile0);
+        uint4 vg[ND], vy[ND], vx[NX];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { vg[i] = ng[i]; vy[i] = ny[i]; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) vx[i] = nx[i];
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             if (pd[i] < 0) continue;
@@ -242,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             *(uint4*)(tile_a + pa[i] * lda + ca8[i] * 8) = v;
         }
         __syncthreads();
+        if (PF) issue(tile0 + tstep);                        // past the end: every predicate false, nothing issued
         if constexpr (FORM == 2) {
             // y1 = bf16(W act(x) + b) for this wave's pixels (D[co][pix]: a lane holds 4 consecutive co of one pixel), then
             // dy = c1*(g*[s*y+t>0]) + c2*y + c3 in place over the raw g values of the same (pixel, 4 channels)
@@ -531,6 +549,7 @@ static int pw_bwd_outstage() {
 template <int NTO, int NTI, int PT>
 static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int nslices = 1) {
     constexpr int BP = 64 * PT, COP = NTO * 16, CIP = NTI * 16;
+    constexpr bool PF = MNAS_PWB_PF && NTO != 15 && !(NTO == 1 && NTI == 2);    // loads one tile ahead (see the tile walk)
     const bool recomp = a.dy.y == nullptr;
     size_t lds = (size_t)(5 * COP + 14 * CIP) * sizeof(float) +
                  ((size_t)CIP * (a.Kd + 8) + (size_t)BP * (a.Kd + 8) + (size_t)BP * (CIP + 8)) * 2;
@@ -544,7 +563,7 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
         // reduce target is the depthwise conv that produced x); anything else takes the plain epilogue below
         const bool redx = !a.red_partial || a.red_y == a.x.data;
         if (pw_bwd_outstage() >= (NTI == NTO ? 2 : 1) && !a.resid && redx) {
-            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 0>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, true, 0, PF>), dim3(nparts, nslices), dim3(256), lds, stream, a);
             MNAS_CHECK_LAUNCH();
             return MNAS_OK;
         }
@@ -552,13 +571,13 @@ static int launch_pw_bwd(const PwBwdArgs& a, int nparts, hipStream_t stream, int
     if (a.gin_masked) return MNAS_EINVAL;                     // only the out-stage kernel masks (a -DMNAS_DIAG build can switch it off)
     if constexpr (NTO > NTI && NTI <= 2) {                    // the expand convs of the 112x112 / 56x56 stages
         if (recomp) {
-            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false, 2>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false, 2, PF>), dim3(nparts, nslices), dim3(256), lds, stream, a);
             MNAS_CHECK_LAUNCH();
             return MNAS_OK;
         }
     }
     if (recomp) return MNAS_EINVAL;
-    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false, 0>), dim3(nparts, nslices), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_pw_bwd<NTO, NTI, PT, false, 0, PF>), dim3(nparts, nslices), dim3(256), lds, stream, a);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }

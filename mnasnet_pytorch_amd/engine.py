@@ -1006,7 +1006,9 @@ class Engine:
         self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
-        self.pw_bwd_parts_small = 85     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices)
+        self.pw_bwd_parts_small = 80     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices): a
+                                         # multiple of 8 (the slices of one pixel column share an XCD's L2) with 6 x 80 <= the 512 resident
+                                         # slots; 85 -> 80: class -0.06 ms, 88 (528 workgroups, a second round): +0.15 ms
         self.side_stream = None
         self._in_norm, self._in_aff = None, {}
         self.profile_opcodes = None      # set of opcodes to bracket with HIP events (bench.py roofline leg)
