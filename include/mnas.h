@@ -55,7 +55,7 @@ typedef struct MnasGradIn {
     const float* coef;    /* float[5][C] */
 } MnasGradIn;
 
-int mnas_version(void);                 /* ABI version: 6 (struct layouts changed in rounds 2, 3, twice in round 4 -- 4 = the tiled-block forms,
+int mnas_version(void);                 /* ABI version: 7 (round 5: + mnas_se_fc_*; 6 = struct layouts changed in rounds 2, 3, twice in round 4 -- 4 = the tiled-block forms,
                                          * 5 = squeeze-excite on load: MnasConvGemm.gate, MnasPwBwd.seg_px -- and in round 5: 6 = the opt-in
                                          * forms that lost their A/B are gone (MnasPwBwd.dy_out / red4, MnasDwBwd.src_* / g_gate / g_bias,
                                          * mnas_dw_exp_*, mnas_irb_*, mnas_gram*, mnas_se_bn_assemble); their opcode numbers stay retired) */
@@ -404,6 +404,19 @@ int mnas_se_bwd_apply_cols(int N, int HW, int C);
 int mnas_se_gate(const float* u, int N, int C, float* gate, void* stream);
 int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, int Ci, const float* u, const float* W, float* dW,
                           int accumulate, float* du, void* stream);
+/* The excitation MLP in one launch per direction (ABI 7).  z [N][E] fp32 = the pooled activation, W1 [R][E] / b1 [R] = fc1, W2 [E][R] /
+ * b2 [E] = fc2 (torch.nn.Linear layouts, 4-byte alignment is enough), shapes: mnas_se_fc_supported:
+ *   mnas_se_fc_fwd : hb = relu(W1 z + b1) [N][R];  u = W2 hb + b2 [N][E];  gate = sigmoid(u) [N][E] when gate != NULL
+ *                    (replaces two mnas_head_linear_fwd calls and mnas_se_gate)
+ *   mnas_se_fc_bwd : from du = dL/du [N][E]:  dh = (du W2) * [hb > 0] [N][R] (caller-provided scratch);  dz = dh W1 [N][E];
+ *                    dW2 (+)= du^T hb, db2 (+)= sum_n du, dW1 (+)= dh^T z, db1 (+)= sum_n dh   (accumulate != 0: add to the buffers)
+ *                    (replaces two mnas_head_linear_bwd_w and two mnas_head_linear_bwd_x calls; two kernels, fixed summation order) */
+int mnas_se_fc_supported(int E, int R);     /* 1: the two calls below take this shape (R <= 48, E <= 1280, 64 KB of LDS); else use mnas_head_linear_* */
+int mnas_se_fc_fwd(const float* z, const float* W1, const float* b1, const float* W2, const float* b2, int N, int E, int R,
+                   float* hb, float* u, float* gate, void* stream);
+int mnas_se_fc_bwd(const float* du, const float* z, const float* hb, const float* W1, const float* W2, int N, int E, int R,
+                   float* dh, float* dz, float* dW1, float* db1, float* dW2, float* db2, int accumulate, void* stream);
+
 
 /* ---- weight packing (fp32 reference layout [Co][Ci/g][kh][kw] -> kernel layouts) -------------------- */
 #define MNAS_PACK_FWD   0   /* bf16 [Co_pad16][Kpad32], k = tap*Ci+ci            (mnas_conv_gemm mode 0) */
@@ -467,6 +480,8 @@ int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 #define MNAS_OP_SE_BWD_APPLY 33
 #define MNAS_OP_SE_GATE 34          /* ABI 5 */
 #define MNAS_OP_SE_PROJ_FIN 35      /* ABI 5 */
+#define MNAS_OP_SE_FC_FWD 37        /* ABI 7: i = {N, E, R}; p = {z, W1, b1, W2, b2, hb, u, gate or NULL} */
+#define MNAS_OP_SE_FC_BWD 38        /* ABI 7: i = {N, E, R, accumulate}; p = {du, z, hb, W1, W2, dh, dz, dW1, db1, dW2, db2} */
 typedef struct MnasOp {
     int32_t opcode;
     int32_t i[15];

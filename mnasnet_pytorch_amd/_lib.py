@@ -8,7 +8,7 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 6          # include/mnas.h: mnas_version()
+ABI_VERSION = 7          # include/mnas.h: mnas_version()
 LIB_PATH = os.environ.get("MNAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmnas_hip.so")      # override: A/B builds (tools/)
 
 c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
@@ -100,6 +100,7 @@ OP_POOL_ACT, OP_POOL_BWD, OP_DY_MAT = 22, 23, 24          # 19-21, 27-29, 36: re
 OP_BWD_POST, OP_TCONV_DGRAD = 25, 26
 OP_HEAD_LINEAR, OP_SE_SCALE, OP_SE_BWD_REDUCE, OP_SE_BWD_APPLY = 30, 31, 32, 33
 OP_SE_GATE, OP_SE_PROJ_FIN = 34, 35
+OP_SE_FC_FWD, OP_SE_FC_BWD = 37, 38
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 EINVAL = 10001      # MNAS_EINVAL
 
@@ -127,6 +128,9 @@ SYMBOLS = {
     "mnas_se_bwd_apply_cols": (c_int, [c_int, c_int, c_int]),
     "mnas_se_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mnas_se_proj_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "mnas_se_fc_supported": (c_int, [c_int, c_int]),
+    "mnas_se_fc_fwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 4),
+    "mnas_se_fc_bwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 6 + [c_int, c_void_p]),
     "mnas_conv_gemm_gate_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),

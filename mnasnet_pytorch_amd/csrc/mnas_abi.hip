@@ -34,7 +34,7 @@ int mnas_pws_enabled() {
     return on;
 }
 
-extern "C" int mnas_version(void) { return 6; }
+extern "C" int mnas_version(void) { return 7; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 
 extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {
@@ -212,6 +212,13 @@ static int run_one(const MnasOp& o, void* stream) {
         case MNAS_OP_SE_PROJ_FIN:
             return mnas_se_proj_finalize((float*)p[0], i[0], i[1], i[2], i[3], (const float*)p[1], (const float*)p[2], (float*)p[3],
                                          i[4], (float*)p[4], stream);
+        case MNAS_OP_SE_FC_FWD:
+            return mnas_se_fc_fwd((const float*)p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
+                                  i[0], i[1], i[2], (float*)p[5], (float*)p[6], (float*)p[7], stream);
+        case MNAS_OP_SE_FC_BWD:
+            return mnas_se_fc_bwd((const float*)p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
+                                  i[0], i[1], i[2], (float*)p[5], (float*)p[6], (float*)p[7], (float*)p[8], (float*)p[9], (float*)p[10],
+                                  i[3], stream);
         case MNAS_OP_SE_BWD_APPLY:
             return mnas_se_bwd_apply(p[0], (const float*)p[1], (const float*)p[2], i[0], i[1], i[2], p[3], p[4], (const float*)p[5],
                                      (float*)p[6], stream);

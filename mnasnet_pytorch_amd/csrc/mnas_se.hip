@@ -246,6 +246,345 @@ extern "C" int mnas_se_proj_finalize(float* wpartial, int N, int kseg, int Co, i
     return MNAS_OK;
 }
 
+// ---- the excitation MLP in one launch per direction (round 5, ABI 7) -----------------------------------------------------------
+// z [N][E] -> hb = relu(W1 z + b1) [N][R] -> u = W2 hb + b2 [N][E] (-> gate = sigmoid(u)), R = 8..48 hidden units.  As
+// mnas_head_linear_* calls these were 2 (+ the gate) forward and 4 backward launches per block of 9-13 us each on problems of a
+// few hundred kFLOP -- 102 launches, 1.17 ms of the squeeze-excite variant's step.  These kernels are bound by LOAD LATENCY, not by
+// bytes or flops: every loop over global memory is written as explicit batches of 16-40 independent loads (a plain loop with a
+// run-time trip count waits for each load in turn: the first version of k_se_fc_fwd took 100 us at E = 1152).  Parameters are
+// views of the trainer's flat buffer, 4-byte aligned only: scalar loads throughout.  Every sum runs in a fixed order.
+
+#define SE_NB 2              // images per workgroup of the per-image kernels (they share every weight load)
+#define SE_TR 256            // W2 rows per LDS tile
+#define SE_FC_MAXR 48
+__device__ __forceinline__ float se_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// W2 [E][R] is read one ROW per channel: SE_TR rows at a time go through LDS (coalesced flat copy, odd row pitch -> the row reads
+// are conflict-free) -- a thread walking its own row in global memory touches 64 different lines per load instruction of its wave.
+__device__ __forceinline__ void se_stage_rows(float* __restrict__ t_s, const float* __restrict__ W2, int e0, int E, int R, int ld, float rcp_r) {
+    const int rows = min(SE_TR, E - e0), total = rows * R;
+    const float* src = W2 + (size_t)e0 * R;
+    constexpr int U = SE_TR * SE_FC_MAXR / 256 / 2;                  // two batches of U loads cover the largest tile
+    for (int base = 0; base < total; base += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i = base + threadIdx.x + 256 * j;
+            v[j] = i < total ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i = base + threadIdx.x + 256 * j;
+            if (i < total) {
+                int row = (int)(((float)i + 0.5f) * rcp_r);          // i / R for i < 2^20 (R <= 48)
+                t_s[row * ld + (i - row * R)] = v[j];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_se_fc_fwd(const float* __restrict__ z, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                   const float* __restrict__ W2, const float* __restrict__ b2, int N, int E, int R,
+                                                   float* __restrict__ hb, float* __restrict__ u, float* __restrict__ gate) {
+    extern __shared__ float se_s[];                                 // [NB][E] z, [NB][R] hidden, [SE_TR][R|1] W2 rows
+    float* z_s = se_s;
+    float* h_s = se_s + SE_NB * E;
+    float* t_s = h_s + SE_NB * R;
+    const int ld = R | 1;
+    const float rcp_r = 1.f / (float)R;
+    const int n0 = blockIdx.x * SE_NB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        float v[SE_NB * 5];                                          // E <= 1280: one batch
+#pragma unroll
+        for (int j = 0; j < SE_NB * 5; ++j) {
+            const int i = tid + 256 * j;
+            v[j] = (i < SE_NB * E && n0 + (i >= E ? 1 : 0) < N) ? z[(size_t)n0 * E + i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < SE_NB * 5; ++j) {
+            const int i = tid + 256 * j;
+            if (i < SE_NB * E) z_s[i] = v[j];
+        }
+    }
+    __syncthreads();
+    // hidden rows: a wave takes rows r, r+4, r+8, r+12 at once (4 x 10 loads in flight per lane), lanes stride the channels
+    for (int r = wave; r < R; r += 16) {
+        float acc[4][SE_NB];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < SE_NB; ++b) acc[q][b] = 0.f;
+        for (int e0 = 0; e0 < E; e0 += 640) {
+            float w[4][10];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const int e = e0 + lane + 64 * j;
+                    w[q][j] = (e < E && r + 4 * q < R) ? W1[(size_t)(r + 4 * q) * E + e] : 0.f;
+                }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int e = e0 + lane + 64 * j;
+                if (e < E) {
+#pragma unroll
+                    for (int b = 0; b < SE_NB; ++b) {
+                        const float zz = z_s[b * E + e];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][b] = fmaf(w[q][j], zz, acc[q][b]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < SE_NB; ++b) {
+                const float v = se_wave_sum(acc[q][b]);
+                const int rr = r + 4 * q;
+                if (lane == 0 && rr < R) {
+                    const float h = fmaxf(v + b1[rr], 0.f);
+                    h_s[b * R + rr] = h;
+                    if (n0 + b < N) hb[(size_t)(n0 + b) * R + rr] = h;
+                }
+            }
+    }
+    for (int e0 = 0; e0 < E; e0 += SE_TR) {
+        __syncthreads();                                             // hidden rows written / previous tile consumed
+        se_stage_rows(t_s, W2, e0, E, R, ld, rcp_r);
+        __syncthreads();
+        const int e = e0 + tid;
+        if (e < E) {
+            float acc[SE_NB];
+            const float bb = b2[e];
+#pragma unroll
+            for (int b = 0; b < SE_NB; ++b) acc[b] = bb;
+            const float* w = t_s + tid * ld;
+#pragma unroll 8                                                     // (LDS latency: eight rows' reads in flight)
+            for (int r = 0; r < R; ++r) {
+                const float wr = w[r];
+#pragma unroll
+                for (int b = 0; b < SE_NB; ++b) acc[b] = fmaf(wr, h_s[b * R + r], acc[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < SE_NB; ++b) {
+                if (n0 + b < N) {
+                    u[(size_t)(n0 + b) * E + e] = acc[b];
+                    if (gate) gate[(size_t)(n0 + b) * E + e] = se_sigmoid(acc[b]);
+                }
+            }
+        }
+    }
+}
+// dh = (du W2) * [hb > 0],  dz = dh W1   (SE_NB images per workgroup; thread = channel e, W2 rows through LDS as above)
+__global__ __launch_bounds__(256) void k_se_fc_bwd_x(const float* __restrict__ du, const float* __restrict__ hb, const float* __restrict__ W1,
+                                                     const float* __restrict__ W2, int N, int E, int R, float* __restrict__ dh,
+                                                     float* __restrict__ dz) {
+    extern __shared__ float se_s[];
+    float* part = se_s;                                             // [S slices][NB][R] partial dh
+    float* h_s = part + 256;                                        // [NB][R] dh
+    float* d_s = h_s + SE_NB * R;                                   // [NB][SE_TR] du of the tile's channels
+    float* t_s = d_s + SE_NB * SE_TR;                               // [SE_TR][R|1] W2 rows
+    const int ld = R | 1;
+    const float rcp_r = 1.f / (float)R;
+    const int n0 = blockIdx.x * SE_NB, tid = threadIdx.x;
+    // dh: thread = (hidden unit r, image b, row slice sl): the S = 256 / (NB R) slices walk the tile rows sl, sl+S, ... (du
+    // broadcast, W2 row elements of consecutive r adjacent: conflict-free); slices are added in order at the end
+    const int S = 256 / (SE_NB * R);
+    const int pr = tid % (SE_NB * R), sl = tid / (SE_NB * R);
+    const int rb = pr / R, rr = pr - rb * R;
+    float dacc = 0.f;
+    for (int e0 = 0; e0 < E; e0 += SE_TR) {
+        __syncthreads();
+        se_stage_rows(t_s, W2, e0, E, R, ld, rcp_r);
+        {
+            float v[SE_NB];
+#pragma unroll
+            for (int b = 0; b < SE_NB; ++b) v[b] = (e0 + tid < E && n0 + b < N) ? du[(size_t)(n0 + b) * E + e0 + tid] : 0.f;
+#pragma unroll
+            for (int b = 0; b < SE_NB; ++b) d_s[b * SE_TR + tid] = v[b];
+        }
+        __syncthreads();
+        if (sl < S) {
+            const int rows = min(SE_TR, E - e0);
+#pragma unroll 8
+            for (int row = sl; row < rows; row += S) dacc = fmaf(d_s[rb * SE_TR + row], t_s[row * ld + rr], dacc);
+        }
+    }
+    if (sl < S) part[sl * SE_NB * R + pr] = dacc;
+    __syncthreads();
+    for (int i = tid; i < SE_NB * R; i += 256) {
+        const int b = i / R, r = i - b * R;
+        float v = part[i];
+        for (int q = 1; q < S; ++q) v += part[q * SE_NB * R + i];
+        float g = 0.f;
+        if (n0 + b < N) {
+            g = hb[(size_t)(n0 + b) * R + r] > 0.f ? v : 0.f;
+            dh[(size_t)(n0 + b) * R + r] = g;
+        }
+        h_s[i] = g;
+    }
+    __syncthreads();
+    // dz: thread = channels tid + 256 k (k < 5: E <= 1280); 8 hidden rows x 5 channels of W1 in flight per batch
+    float acc[5][SE_NB];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int b = 0; b < SE_NB; ++b) acc[k][b] = 0.f;
+    for (int r0 = 0; r0 < R; r0 += 8) {
+        float w[8][5];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int e = tid + 256 * k;
+                w[q][k] = (e < E && r0 + q < R) ? W1[(size_t)(r0 + q) * E + e] : 0.f;
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (r0 + q < R) {
+#pragma unroll
+                for (int b = 0; b < SE_NB; ++b) {
+                    const float hh = h_s[b * R + r0 + q];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) acc[k][b] = fmaf(hh, w[q][k], acc[k][b]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int e = tid + 256 * k;
+        if (e < E) {
+#pragma unroll
+            for (int b = 0; b < SE_NB; ++b)
+                if (n0 + b < N) dz[(size_t)(n0 + b) * E + e] = acc[k][b];
+        }
+    }
+}
+// dW2[e][r] (+)= sum_n du[n][e] hb[n][r], db2[e] (+)= sum_n du[n][e], dW1[r][e] (+)= sum_n dh[n][r] z[n][e], db1[r] (+)= sum_n dh[n][r]
+// workgroup (x, y) = 16 channels x 4 hidden units.  The images are dealt over 16 "phases" (4 lane groups x 4 waves): lane = channel
+// + 16 * group, so a lane walks N / 16 images -- ONE batch of loads for N = 256 (a thread walking all N images alone spent 14 us
+// waiting for 16 batches in turn).  hb / dh of the four units come from LDS; the phases' sums are added in a fixed order (lane
+// groups by shuffle, waves through LDS).
+#define SE_WCH 512           // images per LDS chunk of (hb, dh)
+__global__ __launch_bounds__(256) void k_se_fc_bwd_w(const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ hb,
+                                                     const float* __restrict__ dh, int N, int E, int R, float* __restrict__ dW1,
+                                                     float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2, int accumulate) {
+    __shared__ float hd_s[SE_WCH][8];                               // [image][hb of 4 units, dh of 4 units]
+    __shared__ float red_s[3][16][13];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ex = lane & 15, ph = wave * 4 + (lane >> 4);          // image phase 0..15
+    const int r0 = blockIdx.y * 4, e = blockIdx.x * 16 + ex;
+    const int ec = e < E ? e : E - 1;
+    float a2[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2 = 0.f;
+    for (int c0 = 0; c0 < N; c0 += SE_WCH) {
+        const int cn = min(SE_WCH, N - c0);
+        __syncthreads();
+        for (int base = 0; base < cn * 8; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = base + tid + 256 * j, nn = i >> 3, q = i & 7, r = r0 + (q & 3);
+                v[j] = (i < cn * 8 && r < R) ? (q < 4 ? hb : dh)[(size_t)(c0 + nn) * R + r] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = base + tid + 256 * j;
+                if (i < cn * 8) hd_s[i >> 3][i & 7] = v[j];
+            }
+        }
+        __syncthreads();
+        for (int nb = ph; nb < cn; nb += 256) {                      // 16 images of this phase per batch
+            float d[16], zz[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int nn = nb + 16 * j;
+                d[j] = nn < cn ? du[(size_t)(c0 + nn) * E + ec] : 0.f;
+                zz[j] = nn < cn ? z[(size_t)(c0 + nn) * E + ec] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int nn = nb + 16 * j;
+                if (nn < cn) {
+                    s2 += d[j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float h = hd_s[nn][q], g = hd_s[nn][4 + q];
+                        a2[q] = fmaf(d[j], h, a2[q]);
+                        a1[q] = fmaf(g, zz[j], a1[q]);
+                        s1[q] += g;
+                    }
+                }
+            }
+        }
+    }
+    // lane groups (phases 4w .. 4w+3) of a wave: butterfly over lanes ^16, ^32 -- the same tree for every run
+    float vals[13];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { vals[q] = a2[q]; vals[4 + q] = a1[q]; vals[8 + q] = s1[q]; }
+    vals[12] = s2;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        vals[k] += __shfl_xor(vals[k], 16, 64);
+        vals[k] += __shfl_xor(vals[k], 32, 64);
+    }
+    if (wave > 0 && lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) red_s[wave - 1][lane][k] = vals[k];
+    }
+    __syncthreads();
+    if (wave != 0 || lane >= 16) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int k = 0; k < 13; ++k) vals[k] += red_s[w][lane][k];
+    if (e < E) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            if (r < R) {
+                float* q2 = dW2 + (size_t)e * R + r;
+                float* q1 = dW1 + (size_t)r * E + e;
+                *q2 = (accumulate ? *q2 : 0.f) + vals[q];
+                *q1 = (accumulate ? *q1 : 0.f) + vals[4 + q];
+            }
+        }
+        if (blockIdx.y == 0) db2[e] = (accumulate ? db2[e] : 0.f) + vals[12];
+    }
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (r0 + q < R) db1[r0 + q] = (accumulate ? db1[r0 + q] : 0.f) + vals[8 + q];
+    }
+}
+// shapes the fused MLP kernels take: <= 48 hidden units, <= 1280 channels (k_se_fc_bwd_x's register tile), 64 KB of LDS
+extern "C" int mnas_se_fc_supported(int E, int R) {
+    return E >= 1 && E <= 1280 && R >= 1 && R <= SE_FC_MAXR &&
+           (size_t)(SE_NB * E + 256 + SE_NB * R + SE_NB * SE_TR + SE_TR * (R | 1)) * sizeof(float) <= 64 * 1024;
+}
+extern "C" int mnas_se_fc_fwd(const float* z, const float* W1, const float* b1, const float* W2, const float* b2, int N, int E, int R,
+                              float* hb, float* u, float* gate, void* stream) {
+    if (!z || !W1 || !b1 || !W2 || !b2 || !hb || !u || N < 1 || !mnas_se_fc_supported(E, R)) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_se_fc_fwd, dim3((N + SE_NB - 1) / SE_NB), dim3(256), (size_t)(SE_NB * (E + R) + SE_TR * (R | 1)) * sizeof(float),
+                       (hipStream_t)stream, z, W1, b1, W2, b2, N, E, R, hb, u, gate);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+extern "C" int mnas_se_fc_bwd(const float* du, const float* z, const float* hb, const float* W1, const float* W2, int N, int E, int R,
+                              float* dh, float* dz, float* dW1, float* db1, float* dW2, float* db2, int accumulate, void* stream) {
+    if (!du || !z || !hb || !W1 || !W2 || !dh || !dz || !dW1 || !db1 || !dW2 || !db2) return MNAS_EINVAL;
+    if (N < 1 || !mnas_se_fc_supported(E, R)) return MNAS_EINVAL;
+    hipLaunchKernelGGL(k_se_fc_bwd_x, dim3((N + SE_NB - 1) / SE_NB), dim3(256), (size_t)(256 + SE_NB * R + SE_NB * SE_TR + SE_TR * (R | 1)) * sizeof(float),
+                       (hipStream_t)stream, du, hb, W1, W2, N, E, R, dh, dz);
+    hipLaunchKernelGGL(k_se_fc_bwd_w, dim3((E + 15) / 16, (R + 3) / 4), dim3(256), 0, (hipStream_t)stream, du, z, hb, dh, N, E, R, dW1, db1,
+                       dW2, db2, accumulate ? 1 : 0);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
 // pixel splits per image: enough workgroups to fill the chip (>= ~2048), whole multiples of R pixels each
 static bool se_geom(int N, int HW, int C, SeGeom* g, int* splits) {
     if (N < 1 || HW < 1 || C < 8 || (C & 7) || C > 2048) return false;

@@ -498,13 +498,19 @@ class Program:
         u = new((N, E_), torch.float32)
         m_ = se.mod
         fwd.add(L.OP_POOL_ACT, [N, Hi * Wi, E_], [], h2.act_ptrs() + [z.data_ptr()])
-        fwd.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 0], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), hb.data_ptr()])
-        fwd.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 0], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), m_.fc2.bias.data_ptr(), u.data_ptr()])
         kseg = self._se_onload_kseg(p_ci, h2, Hi, Wi)
         gate = new((N, E_), torch.float32) if kseg else None
+        if eng.se_fused_mlp and lib.mnas_se_fc_supported(E_, R_):
+            # the whole excitation MLP (+ the gate table) in one launch (csrc/mnas_se.hip k_se_fc_fwd)
+            fwd.add(L.OP_SE_FC_FWD, [N, E_, R_], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), m_.fc2.weight.data_ptr(),
+                                                      m_.fc2.bias.data_ptr(), hb.data_ptr(), u.data_ptr(), gate.data_ptr() if kseg else None])
+        else:
+            fwd.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 0], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc1.bias.data_ptr(), hb.data_ptr()])
+            fwd.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 0, 0], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), m_.fc2.bias.data_ptr(), u.data_ptr()])
+            if kseg:
+                fwd.add(L.OP_SE_GATE, [N, E_], [], [u.data_ptr(), gate.data_ptr()])
         self._se_records[len(records)] = (se, h2, z, hb, u, kseg, gate)    # keyed by the record index of the project conv that follows
         if kseg:
-            fwd.add(L.OP_SE_GATE, [N, E_], [], [u.data_ptr(), gate.data_ptr()])
             return _Act(h2.data, h2.bn, Hi, Wi, E_, gate)
         a2s = new((N, Hi, Wi, E_))
         fwd.add(L.OP_SE_SCALE, [N, Hi * Wi, E_], [], h2.act_ptrs() + [u.data_ptr(), a2s.data_ptr()])
@@ -794,6 +800,25 @@ class Program:
                 raise RuntimeError("unsupported squeeze-excite shape %s" % ((N, HWl, E_),))
             dup = new((sb // 4,), torch.float32)
             ops.add(L.OP_SE_BWD_REDUCE, [N, HWl, E_], [], [gs.data_ptr()] + h2.act_ptrs() + [u.data_ptr(), du.data_ptr(), dup.data_ptr()], 0)
+        if eng.se_fused_mlp and lib.mnas_se_fc_supported(E_, R_):
+            # the MLP backward in one op (two kernels: per-image dh / dz, then the parameter gradients; csrc/mnas_se.hip)
+            ops.add(L.OP_SE_FC_BWD, [N, E_, R_, 1], [], [du.data_ptr(), z.data_ptr(), hb.data_ptr(), m_.fc1.weight.data_ptr(),
+                                                         m_.fc2.weight.data_ptr(), dh.data_ptr(), dzp.data_ptr(), eng.gptr(se, 0),
+                                                         eng.gptr(se, 1), eng.gptr(se, 2), eng.gptr(se, 3)], 0)
+        else:
+            self._se_mlp_bwd_unfused(ops, se, z, hb, du, dh, dzp)
+        # the BatchNorm2-backward reduce of the depthwise conv rides in the same pass (ga is its g; h2 = its raw output + bnbuf)
+        ncols = lib.mnas_se_bwd_apply_cols(N, HWl, E_)
+        fused = h2.bn is not None and 0 < ncols <= _STATS_PARTS
+        ops.add(L.OP_SE_BWD_APPLY, [N, HWl, E_], [],
+                [gs.data_ptr(), u.data_ptr(), dzp.data_ptr(), ga.data_ptr()] +
+                ([h2.data.data_ptr(), h2.bn.data_ptr(), eng.scratch_red.data_ptr()] if fused else [None, None, None]), 0)
+        return ga, (ncols if fused else 0)
+
+    def _se_mlp_bwd_unfused(self, ops, se, z, hb, du, dh, dzp):
+        """The excitation MLP's backward as four mnas_head_linear_* launches (Engine.se_fused_mlp = False: the A/B baseline)."""
+        eng, N, m_ = self.eng, self.N, se.mod
+        E_, R_ = se.channels, se.reduced
         # fc2: dW2 += du^T hb, db2 += sum du ; dh = (du W2) * [hb > 0]
         ops.add(L.OP_HEAD_LINEAR, [N, R_, E_, 0, 1, 1], [], [hb.data_ptr(), m_.fc2.weight.data_ptr(), None, None, du.data_ptr(),
                                                             eng.gptr(se, 2), eng.gptr(se, 3)], 0)
@@ -804,13 +829,6 @@ class Program:
                                                             eng.gptr(se, 0), eng.gptr(se, 1)], 0)
         ops.add(L.OP_HEAD_LINEAR, [N, E_, R_, 1, 0, 2], [], [z.data_ptr(), m_.fc1.weight.data_ptr(), None, None, dh.data_ptr(),
                                                             None, None, dzp.data_ptr(), None], 0)
-        # the BatchNorm2-backward reduce of the depthwise conv rides in the same pass (ga is its g; h2 = its raw output + bnbuf)
-        ncols = lib.mnas_se_bwd_apply_cols(N, HWl, E_)
-        fused = h2.bn is not None and 0 < ncols <= _STATS_PARTS
-        ops.add(L.OP_SE_BWD_APPLY, [N, HWl, E_], [],
-                [gs.data_ptr(), u.data_ptr(), dzp.data_ptr(), ga.data_ptr()] +
-                ([h2.data.data_ptr(), h2.bn.data_ptr(), eng.scratch_red.data_ptr()] if fused else [None, None, None]), 0)
-        return ga, (ncols if fused else 0)
 
     @staticmethod
     def _target_of(act: Optional[_Act]):
@@ -1001,6 +1019,7 @@ class Engine:
         self.dw_masked_g = True
         self.se_on_load = True           # squeeze-excite excitation applied in the project conv's load (forward) / folded into its
                                          # weight-gradient slabs (backward) where the kernels support the shape; False: k_se_scale
+        self.se_fused_mlp = True         # the squeeze-excite MLP as mnas_se_fc_fwd / mnas_se_fc_bwd (1 + 2 kernels per block instead of 3 + 4)
         self.pw_bwd_segments = 512       # > 0: the project convs' fused backward at >= 800 k pixels walks contiguous pixel segments,
                                          # at most this many workgroups (0: tiles strided over the grid everywhere)
         self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch

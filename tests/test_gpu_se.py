@@ -21,6 +21,53 @@ def rl2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+@pytest.mark.parametrize("N,E,R", [(256, 48, 8), (5, 240, 10), (33, 576, 24), (256, 1152, 48), (1, 72, 8), (7, 100, 13)])
+def test_se_fused_mlp(N, E, R):
+    """mnas_se_fc_fwd / mnas_se_fc_bwd (the excitation MLP in 1 + 2 kernels) against fp32 torch math; accumulate on and off, gate on
+    and off.  fp32 sums in another order: <= 1e-5 of max |ref| (measured 1e-6)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(N * 1000 + E)
+    z = torch.rand(N, E, generator=g)
+    W1, b1 = torch.randn(R, E, generator=g) / E ** 0.5, 0.1 * torch.randn(R, generator=g)
+    W2, b2 = torch.randn(E, R, generator=g) / R ** 0.5, 0.1 * torch.randn(E, generator=g)
+    du = torch.randn(N, E, generator=g)
+    pre = z.double() @ W1.double().t() + b1.double()
+    hb_ref = torch.relu(pre)
+    u_ref = hb_ref @ W2.double().t() + b2.double()
+    dh_ref = (du.double() @ W2.double()) * (hb_ref > 0)
+    dz_ref = dh_ref @ W1.double()
+    refs = {"dW1": dh_ref.t() @ z.double(), "db1": dh_ref.sum(0), "dW2": du.double().t() @ hb_ref, "db2": du.double().sum(0)}
+    d = {k: v.cuda().contiguous() for k, v in dict(z=z, W1=W1, b1=b1, W2=W2, b2=b2, du=du).items()}
+    nan = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+    for with_gate in (True, False):
+        hb, u, gate = nan(N, R), nan(N, E), nan(N, E)
+        L.check(lib.mnas_se_fc_fwd(d["z"].data_ptr(), d["W1"].data_ptr(), d["b1"].data_ptr(), d["W2"].data_ptr(), d["b2"].data_ptr(), N, E, R,
+                                   hb.data_ptr(), u.data_ptr(), gate.data_ptr() if with_gate else None, L.cur_stream()), "se_fc_fwd")
+        assert relerr(hb.cpu(), hb_ref) < 1e-5 and relerr(u.cpu(), u_ref) < 1e-5
+        if with_gate:
+            assert relerr(gate.cpu(), torch.sigmoid(u_ref)) < 1e-5
+        else:
+            assert bool(torch.isnan(gate).all())
+    # the hidden row the backward masks with is the one the forward stored (a pre-activation at +-1e-7 may round either way)
+    hb_used = hb.cpu().double()
+    dh_ref = (du.double() @ W2.double()) * (hb_used > 0)
+    dz_ref = dh_ref @ W1.double()
+    refs["dW1"], refs["db1"], refs["dW2"] = dh_ref.t() @ z.double(), dh_ref.sum(0), du.double().t() @ hb_used
+    for acc in (0, 1):
+        dh, dz = nan(N, R), nan(N, E)
+        base = {k: (0.5 * torch.randn(v.shape, generator=g)) for k, v in refs.items()}
+        out = {k: (base[k].cuda().contiguous() if acc else nan(*v.shape)) for k, v in refs.items()}
+        L.check(lib.mnas_se_fc_bwd(d["du"].data_ptr(), d["z"].data_ptr(), hb.data_ptr(), d["W1"].data_ptr(), d["W2"].data_ptr(), N, E, R,
+                                   dh.data_ptr(), dz.data_ptr(), out["dW1"].data_ptr(), out["db1"].data_ptr(), out["dW2"].data_ptr(),
+                                   out["db2"].data_ptr(), acc, L.cur_stream()), "se_fc_bwd")
+        assert relerr(dh.cpu(), dh_ref) < 1e-5 and relerr(dz.cpu(), dz_ref) < 1e-5
+        for k, v in refs.items():
+            want = v + (base[k].double() if acc else 0)
+            assert relerr(out[k].cpu(), want) < 1e-5, (k, acc)
+    assert lib.mnas_se_fc_fwd(d["z"].data_ptr(), d["W1"].data_ptr(), d["b1"].data_ptr(), d["W2"].data_ptr(), d["b2"].data_ptr(), N, E, 49,
+                              hb.data_ptr(), u.data_ptr(), None, L.cur_stream()) != 0          # more hidden units than the kernels hold
+
+
 @pytest.mark.parametrize("shape", [(3, 14, 14, 48), (2, 7, 7, 1152), (5, 28, 28, 240), (2, 5, 9, 72), (4, 112, 112, 48)])
 @pytest.mark.parametrize("virt", [True, False])
 def test_se_kernels(shape, virt):
