@@ -489,6 +489,8 @@ OVERRIDES = [
     # (variable, what it does, setter(eng))
     ("MNAS_NO_SIDE", "weight-gradient kernels on the main stream (the default)", lambda e: setattr(e, "use_side_stream", False)),
     ("MNAS_SIDE", "weight-gradient kernels on a second stream (default until round 3)", lambda e: setattr(e, "use_side_stream", True)),
+    ("MNAS_SIDE_MAXPX", "with MNAS_SIDE: only layers of at most this many output pixels use the second stream",
+     lambda e: setattr(e, "side_stream_max_pixels", _ov_int("MNAS_SIDE_MAXPX"))),
     ("MNAS_PW_SPLIT_MAX", "pixel count below which project convs use dgrad + wgrad kernels",
      lambda e: setattr(e, "pw_split_max_pixels", _ov_int("MNAS_PW_SPLIT_MAX"))),
     ("MNAS_PW_FUSED_MIN", "pixel count from which 1x1 convs use the fused backward",

@@ -588,7 +588,7 @@ class Program:
             dyb = new((N, Ho, Wo, Co))
             ops.add(L.OP_DY_MAT, [Co], [float(M)], gy + [dyb.data_ptr()], 0)
             gyd = [dyb.data_ptr(), None, None]
-        WS = 1 if eng.use_side_stream else 0
+        WS = 1 if (eng.use_side_stream and M <= eng.side_stream_max_pixels) else 0
         if WS:
             ops.fork()
         gin, ncols = None, 0
@@ -989,6 +989,7 @@ class Engine:
         # two streams (11.17-11.21 ms with it, 11.07-11.13 without, same call) -- and it hid per-kernel gains on the main stream
         # (the K-streaming input gradient: neutral with the side stream, -0.1 ms without).  Off by default; the path stays tested.
         self.use_side_stream = False
+        self.side_stream_max_pixels = 1 << 40     # with use_side_stream: only layers with at most this many output pixels fork
         # workgroups of a k_wgrad launch (pixel splits x 64x64 slabs): 512 rather than 1024 leaves the main stream's persistent
         # grids more of the chip while it runs beside them (11.57 vs 11.66 ms/step, three same-call A/B pairs; 256: 11.77)
         self.wgrad_wgs = 512
