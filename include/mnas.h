@@ -280,6 +280,12 @@ int mnas_stem_wgrad(const MnasStemWgrad* a, void* stream);
  * (host-side, no launch).  Co == 32, W % 4 == 0 (and Wo % 8 == 0 for the weight gradient) run as band kernels
  * (csrc/mnas_stem.hip: input rows staged once per band in LDS); other shapes use the im2col staging of the GEMM kernels. */
 int mnas_stem_parts(int which, int N, int H, int W, int Co);
+/* Input gradient of the stem conv = dL/d image, fp32 NCHW (N,3,H,W): ATen conv2d input gradient of ConvBlock(3, Co, 3, stride 2,
+ * pad 1) with dy-on-load; w = the reference fp32 [Co][3][3][3] weight (rounded to bf16 inside, like the forward's packed copy);
+ * in_affine as in MnasStemFwd (the result is the gradient w.r.t. the RAW float image: scaled by in_affine[0][c]) or NULL.
+ * Not on the training path (train.py:427) -- a plain gather kernel for autograd completeness (saliency, adversarial inputs). */
+int mnas_stem_dgrad(const MnasGradIn* dy, const float* w, int N, int H, int W, int Ho, int Wo, int Co, const float* in_affine,
+                    float* dx, void* stream);
 
 /* ---- BatchNorm2d bookkeeping (replaces ATen native_batch_norm / native_batch_norm_backward) ---------- */
 /* partial: float[2][C][nparts] (sum, sumsq over `count` elements per channel).
@@ -481,6 +487,7 @@ int mnas_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 #define MNAS_OP_SE_GATE 34          /* ABI 5 */
 #define MNAS_OP_SE_PROJ_FIN 35      /* ABI 5 */
 #define MNAS_OP_SE_FC_FWD 37        /* ABI 7: i = {N, E, R}; p = {z, W1, b1, W2, b2, hb, u, gate or NULL} */
+#define MNAS_OP_STEM_DGRAD 39       /* ABI 7: i = {N, H, W, Ho, Wo, Co}; p = {g, y, coef, w fp32, in_affine or NULL, dx} */
 #define MNAS_OP_SE_FC_BWD 38        /* ABI 7: i = {N, E, R, accumulate}; p = {du, z, hb, W1, W2, dh, dz, dW1, db1, dW2, db2} */
 typedef struct MnasOp {
     int32_t opcode;

@@ -101,6 +101,7 @@ OP_BWD_POST, OP_TCONV_DGRAD = 25, 26
 OP_HEAD_LINEAR, OP_SE_SCALE, OP_SE_BWD_REDUCE, OP_SE_BWD_APPLY = 30, 31, 32, 33
 OP_SE_GATE, OP_SE_PROJ_FIN = 34, 35
 OP_SE_FC_FWD, OP_SE_FC_BWD = 37, 38
+OP_STEM_DGRAD = 39
 PACK_FWD, PACK_DGRAD, PACK_DW, PACK_TCONV = 0, 1, 2, 3
 EINVAL = 10001      # MNAS_EINVAL
 
@@ -128,6 +129,7 @@ SYMBOLS = {
     "mnas_se_bwd_apply_cols": (c_int, [c_int, c_int, c_int]),
     "mnas_se_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mnas_se_proj_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "mnas_stem_dgrad": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 3),
     "mnas_se_fc_supported": (c_int, [c_int, c_int]),
     "mnas_se_fc_fwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 4),
     "mnas_se_fc_bwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 6 + [c_int, c_void_p]),

@@ -158,6 +158,10 @@ static int run_one(const MnasOp& o, void* stream) {
             a.in_affine = (const float*)p[5]; a.in_u8 = i[7];
             return mnas_stem_wgrad(&a, stream);
         }
+        case MNAS_OP_STEM_DGRAD: {
+            MnasGradIn d = {p[0], p[1], (const float*)p[2]};
+            return mnas_stem_dgrad(&d, (const float*)p[3], i[0], i[1], i[2], i[3], i[4], i[5], (const float*)p[4], (float*)p[5], stream);
+        }
         case MNAS_OP_BN_FWD_FINALIZE:
             return mnas_bn_fwd_finalize((const float*)p[0], i[0], i[1], o.d[0], (const float*)p[1], (const float*)p[2],
                                         (float*)p[3], (float*)p[4], (int64_t*)p[5], (float)o.d[1], (float)o.d[2], i[2],

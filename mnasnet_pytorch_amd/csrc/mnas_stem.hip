@@ -353,3 +353,63 @@ int mnas_stem_wgrad_band(const MnasStemWgrad* c, void* stream) {
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }
+
+// ---- input gradient of the stem: dL/d image (round 5) --------------------------------------------------------------------------
+// Not on the training path (train.py:427: images do not require grad); it exists so that autograd through the drop-in module is
+// complete (saliency maps, adversarial examples): ATen's conv2d input gradient of ConvBlock(3, Co, 3, stride 2) (mnasnet.py:179)
+// with dy-on-load, as a plain gather -- thread = one image pixel, its 1 / 2 / 4 contributing output pixels (by the parity of the
+// row and the column) x Co channels x 3 planes.  dy and the weights are rounded to bf16 like every other input gradient of the
+// path; fp32 accumulate, fp32 NCHW result; with the fused input normalisation the result is scaled by in_affine[0][c].
+__global__ __launch_bounds__(256) void k_stem_dgrad(MnasGradIn d, const float* __restrict__ w, int N, int H, int W, int Ho, int Wo, int Co,
+                                                    const float* __restrict__ in_affine, float* __restrict__ dx) {
+    extern __shared__ float sd_s[];                                  // [27][Co] weights (bf16-rounded), [5][Co] dy coefficients
+    float* w_s = sd_s;
+    float* c_s = sd_s + 27 * Co;
+    for (int i = threadIdx.x; i < 27 * Co; i += 256) {
+        const int k = i / Co, co = i - k * Co;
+        w_s[i] = bf_lo(pack_bf16(w[(size_t)co * 27 + k], 0.f));
+    }
+    for (int i = threadIdx.x; i < 5 * Co; i += 256) c_s[i] = d.coef[i];
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * H * W) return;
+    const int iw = (int)(idx % W), ih = (int)((idx / W) % H), n = (int)(idx / ((long long)W * H));
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 3; ++kh) {
+        const int t = ih + 1 - kh;
+        if (t < 0 || (t & 1) || (t >> 1) >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int u = iw + 1 - kw;
+            if (u < 0 || (u & 1) || (u >> 1) >= Wo) continue;
+            const size_t base = (((size_t)n * Ho + (t >> 1)) * Wo + (u >> 1)) * Co;
+            const int tap = kh * 3 + kw;
+            for (int c8 = 0; c8 < Co; c8 += 8) {
+                const uint4 g8 = *(const uint4*)((const uint16_t*)d.g + base + c8);
+                const uint4 y8 = *(const uint4*)((const uint16_t*)d.y + base + c8);
+                float o[8];
+                dy8(g8, y8, c_s + c8, c_s + Co + c8, c_s + 2 * Co + c8, c_s + 3 * Co + c8, c_s + 4 * Co + c8, o);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t pk = pack_bf16(o[j], o[j + 1]);
+                    const float d0 = bf_lo(pk), d1 = bf_hi(pk);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        acc[c] = fmaf(d1, w_s[(c * 9 + tap) * Co + c8 + j + 1], fmaf(d0, w_s[(c * 9 + tap) * Co + c8 + j], acc[c]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        dx[(((size_t)n * 3 + c) * H + ih) * W + iw] = acc[c] * (in_affine ? in_affine[c] : 1.f);
+}
+extern "C" int mnas_stem_dgrad(const MnasGradIn* dy, const float* w, int N, int H, int W, int Ho, int Wo, int Co, const float* in_affine,
+                               float* dx, void* stream) {
+    if (!dy || !dy->g || !dy->y || !dy->coef || !w || !dx || N < 1 || H < 1 || W < 1 || Co < 8 || (Co & 7) || Co > 128) return MNAS_EINVAL;
+    if (Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return MNAS_EINVAL;           // 3x3, stride 2, pad 1
+    const long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)32 * Co * sizeof(float), (hipStream_t)stream,
+                       *dy, w, N, H, W, Ho, Wo, Co, in_affine, dx);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}

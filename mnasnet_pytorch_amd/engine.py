@@ -352,7 +352,7 @@ class Program:
             # what produced the step's INPUT: a ConvBlock (virtual act) or a block's residual sum / the network input
             if kind == "conv":
                 rec = records[start]
-                need = (not first) or (need_dx and not self.x_is_image)
+                need = (not first) or need_dx
                 if rec[2] is not None and rec[2].bn is None and si > 0 and step_records[si - 1][0] == "block":
                     # input is the previous block's materialised sum r: its gradient G feeds that block's project conv
                     prev_p = records[step_records[si - 1][2] + 2]
@@ -413,6 +413,9 @@ class Program:
             ops_obj, idx, slot = self.patch_x_bwd
             st = [s for s in order if seg_ops[s] is ops_obj][0]
             self.patch_x_bwd = (st, idx, slot)
+        if self.patch_dx is not None and not isinstance(self.patch_dx[0], int):
+            ops_obj, idx, slot = self.patch_dx
+            self.patch_dx = ([s for s in order if seg_ops[s] is ops_obj][0], idx, slot)
 
     def _new(self, shape, dtype=torch.bfloat16):
         t = torch.empty(shape, dtype=dtype, device=self.eng.device)
@@ -603,6 +606,12 @@ class Program:
                          [None] + gy + [eng.scratch_wgrad.data_ptr(), self._aff_ptr], WS)
             self.patch_x_bwd = (ops, jx, 0)
             ops.add(L.OP_WGRAD_FINALIZE, [nsp, Co, 27, 1, 1], [], [eng.scratch_wgrad.data_ptr(), eng.gptr(ci, 0)], WS)
+            if need_gin:
+                # dL/d image (fp32 NCHW; csrc/mnas_stem.hip k_stem_dgrad): not on the training path, autograd completeness only
+                if self.in_u8:
+                    raise RuntimeError("a uint8 image has no gradient")
+                jd = ops.add(L.OP_STEM_DGRAD, [N, Hi, Wi, Ho, Wo, Co], [], gy + [ci.mod.conv.weight.data_ptr(), self._aff_ptr, None], 0)
+                self.patch_dx = (ops, jd, 5)
         elif ci.kind == "dw" and ci.stride == 2:
             # SepConv(reduce=True): two plain launches, no fused reduce (the producer of x runs its own mnas_bn_bwd_reduce)
             nparts = max(64, min(eng.dw_bwd_parts, _cdiv(M * Co, 256 * 16 * 2)))
@@ -1287,11 +1296,6 @@ class Engine:
         """pooled=True returns the global average of the features, [N, C] fp32 (AdaptiveAvgPool2d(1) + flatten fused in)."""
         self.check_input(x)
         track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params))
-        if track and x.requires_grad and self.starts_with_stem and self.root.training:
-            # the stem's input gradient (fp32 NCHW image gradient) is not part of the training path (train.py:427:
-            # images do not require grad): fail loudly instead of returning a missing gradient
-            raise NotImplementedError("gradient w.r.t. the input image is not implemented by the HIP engine (the stem's "
-                                      "dgrad is skipped); pass the image with requires_grad=False")
         if x.dtype == torch.uint8 and self.starts_with_stem and getattr(self, "_in_norm", None) is not None:
             x = x.contiguous()              # uint8 images stay uint8: the stem converts and normalises on load
         else:

@@ -72,7 +72,7 @@ def conv_fwd(spec: ConvSpec, a_in, st, train, image=None):
     y = round_bf16(y32)
     out = MAct(y, s, t)
     saved = dict(spec=spec, a=a, w=w, w32=W, y=y, s=s, t=t, mean=mean.float(), invstd=invstd.float(), M=M,
-                 in_shape=tuple(a.shape))
+                 in_shape=tuple(a.shape), image=image is not None)
     return out, saved
 
 
@@ -119,7 +119,7 @@ def conv_bwd(saved, g, grads, resid=None, need_gin=True, se=None):
     gin = torch.nn.grad.conv2d_input(saved["in_shape"], w, dy, stride=spec.stride, padding=spec.pad, groups=spec.groups)
     if resid is not None:
         gin = gin + resid
-    return round_bf16(gin)
+    return gin if saved.get("image") else round_bf16(gin)          # dL/d image leaves the path as fp32 (csrc/mnas_stem.hip k_stem_dgrad)
 
 
 def se_fwd(se, a2: "MAct", st):
@@ -192,7 +192,7 @@ def run(program, st, x, train=True, cot=None, need_dx=False, se_on_load=None):
         kind, sv = tape[n]
         first_step = n == 0
         if kind == "conv":
-            need = (not first_step) or (need_dx and not is_image)
+            need = (not first_step) or need_dx
             g = conv_bwd(sv, g, grads, None, need)
         else:
             G = g

@@ -462,6 +462,18 @@ def test_stem(shape):
     grad = torch.full((Co, 3, 3, 3), float("nan"), device="cuda")
     L.check(lib.mnas_wgrad_finalize(partial.data_ptr(), nparts, Co, 27, 1, grad.data_ptr(), 0, L.cur_stream()))
     assert relerr(grad.cpu(), ref_dw) < TOL_F32
+    # input gradient (dL/d image, fp32 NCHW): bf16 dy and weights, fp32 accumulate; with the fused input normalisation's scale
+    ref_dx = torch.nn.grad.conv2d_input((N, 3, H, W), w, bf16r(dy), stride=2, padding=1)
+    w32 = w.cuda().contiguous()
+    for aff in (None, torch.tensor([[2.0, 0.5, 1.25], [0.1, 0.2, 0.3]])):
+        dx = torch.full((N, 3, H, W), float("nan"), device="cuda")
+        affd = aff.cuda().contiguous() if aff is not None else None
+        gi = grad_in(gd, yd, bd)
+        L.check(lib.mnas_stem_dgrad(C.byref(gi), w32.data_ptr(), N, H, W, Ho, Wo, Co, affd.data_ptr() if aff is not None else None,
+                                    dx.data_ptr(), L.cur_stream()), "stem_dgrad")
+        want = ref_dx if aff is None else ref_dx * aff[0].view(1, 3, 1, 1)
+        assert relerr(dx.cpu(), want) < TOL_F32
+    assert lib.mnas_stem_dgrad(C.byref(gi), w32.data_ptr(), N, H, W, Ho + 1, Wo, Co, None, dx.data_ptr(), L.cur_stream()) == L.EINVAL
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -261,11 +261,54 @@ def test_too_many_live_forwards_raise():
     del keep
 
 
-def test_image_gradient_request_raises():
-    m = build("512").train()
-    x = C.det_input((2, 3, 64, 64)).cuda().requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="input image"):
-        m(x)
+@pytest.mark.parametrize("shape", [(4, 3, 64, 64), (2, 3, 57, 75)])
+def test_image_gradient_vs_mirror(shape):
+    """dL/d image through the drop-in module (round 5: the stem's input gradient, csrc/mnas_stem.hip k_stem_dgrad; autograd
+    completeness -- train.py:427 never asks for it): the front of the network (stem, SepConv, the 112x112 stage's three block
+    applications and the stride-2 conv; well-conditioned state) against the bf16 mirror.  The image gradient is an ELEMENTWISE
+    function of the stem's dy (32 channels x <= 4 taps per pixel: no averaging over pixels as in a weight gradient), so it carries
+    dy's own bf16 noise after 12 layers of backward: measured rel-L2 0.097-0.105, cosine 0.994-0.995 (bounds 0.15 / 0.99) -- the level
+    of the PARAMETER gradients of the same pass at these small sizes (median 0.097-0.101, max 0.15-0.16); the kernel itself is held
+    to 2e-3 on identical inputs by tests/test_gpu_kernels.py::test_stem.
+    The parameter gradients of the same backward must not change with the extra launch."""
+    from mnasnet_pytorch_amd import Mnasnet
+    from oracle import bf16_mirror as M
+
+    class Front(torch.nn.Module):
+        def __init__(self, mods):
+            super().__init__()
+            self.features = torch.nn.Sequential(*mods)
+
+        def forward(self, x):
+            return self.features(x)
+
+    net = Mnasnet(cut_channels_first=False)
+    st = O.init_state(False, C.STATE_SEED, proj_gamma=0.1)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    x0 = C.det_input(shape)
+    front = Front([net.features[0], net.features[1], net.features[2]])
+    res = []
+    for rg in (True, False):
+        front.zero_grad(set_to_none=True)
+        x = x0.cuda().requires_grad_(rg)
+        y = front(x)
+        cot = C.cotangent(tuple(y.shape))
+        (y * cot.cuda()).sum().backward()
+        res.append((x.grad.cpu() if rg else None, {k: p.grad.clone() for k, p in front.named_parameters()}))
+    dx, g_with = res[0]
+    for k, gv in res[1][1].items():
+        assert torch.equal(gv, g_with[k]), k              # same launches, same bits
+    prog, _ = O.build_program(False)
+    r = M.run(prog[:7], O.init_state(False, C.STATE_SEED, proj_gamma=0.1), x0, True, cot, need_dx=True)
+    assert r["dx"] is not None and tuple(r["dx"].shape) == shape
+    a, b = dx.double().flatten(), r["dx"].double().flatten()
+    e, cos = float((a - b).norm() / b.norm()), float((a @ b) / (a.norm() * b.norm()))
+    pe = sorted(float((g_with[k].cpu().double() - r["grads"][k].double()).norm() / (r["grads"][k].double().norm() + 1e-30))
+                for k in g_with if not k.endswith("conv.bias"))
+    print("image gradient vs mirror: rel-L2 %.4f cosine %.5f; parameter gradients of the same pass: median %.4f max %.4f"
+          % (e, cos, pe[len(pe) // 2], pe[-1]))
+    assert bool(torch.isfinite(dx).all()) and e < 0.15 and cos > 0.99
 
 
 def test_wrong_dtype_and_mixed_modes_fail_loudly():
