@@ -311,6 +311,19 @@ def test_image_gradient_vs_mirror(shape):
     assert bool(torch.isfinite(dx).all()) and e < 0.15 and cos > 0.99
 
 
+def test_image_gradient_whole_model_finite():
+    """x.requires_grad_(True) through the whole drop-in model (features + head + loss): x.grad exists, is finite and not zero, and
+    the Trainer path (images without grad) is unaffected."""
+    m = build("512").train()
+    _no_dropout(m)
+    x = C.det_input((4, 3, 64, 64)).cuda().requires_grad_(True)
+    t = torch.tensor([1, 2, 3, 4]).cuda()
+    loss = torch.nn.CrossEntropyLoss()(m(x), t)
+    loss.backward()
+    assert x.grad is not None and tuple(x.grad.shape) == (4, 3, 64, 64)
+    assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+
+
 def test_wrong_dtype_and_mixed_modes_fail_loudly():
     x = C.det_input((2, 3, 64, 64)).cuda()
     m = build("512").train()
