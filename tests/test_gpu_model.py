@@ -12,6 +12,7 @@
          whole network, well-conditioned state (gain ~5)      y <= 8e-2
          whole network, default state (gain ~110, measured)   y <= 0.7  (sanity only; any bf16 pipeline is here)
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -467,7 +468,7 @@ def test_net_full_size_bit_reproducible():
 # MEASURED on MI355X (round 5, printed by the test): ccf=False per-stage medians 0.17-0.24, worst tensor 0.288 (a bn.weight) /
 # 0.273 (everything else); ccf=True medians 0.13-0.19, worst 0.280 / 0.267.  (The whole-network backward amplifies the 1-ulp bf16
 # rounding-order differences between the engine and the mirror ~100x; per stage the same quantities are held to 3-5e-2 by
-# test_stage_full_size_vs_mirror.)  The bound is PER PARAMETER TENSOR, 1.5x the worst measurement: a wrong sign (rel-L2 2), a
+# test_stage_full_size_vs_mirror; a larger batch does not change it: MNAS_TEST_NET_N=96 measures worst 0.281 / 0.280.)  The bound is PER PARAMETER TENSOR, 1.5x the worst measurement: a wrong sign (rel-L2 2), a
 # wrong scale (>= 0.5) or a dropped application of a shared block in ONE small tensor fails it -- a cosine median does not see that.
 NET_GRAD_RL2 = {False: (0.42, 0.45), True: (0.42, 0.45)}      # {ccf: (bound for all, bound for bn.weight)}
 
@@ -480,7 +481,7 @@ def test_net_full_size_vs_mirror(ccf):
     m = Mnasnet(cut_channels_first=ccf)
     m.load_state_dict(O.init_state(ccf, C.STATE_SEED, proj_gamma=0.1))
     m = m.cuda().train()
-    x0 = C.det_input((32, 3, 224, 224))
+    x0 = C.det_input((int(os.environ.get("MNAS_TEST_NET_N", "32")), 3, 224, 224))
     y = m(x0.cuda())
     cot = C.cotangent(tuple(y.shape))
     (y * cot.cuda()).sum().backward()
