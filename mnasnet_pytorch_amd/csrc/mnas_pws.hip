@@ -266,8 +266,9 @@ int mnas_pws_parts(int mode, int M, int K, int N) {
     PwsPlan p;
     if (!mnas_pws_enabled() || !pws_plan(mode, M, K, N, &p)) return -1;
     const int ngroups = (M + 15) / 16;
-    int want = 512 / p.nblocks;                       // two workgroups per CU
-    if (p.nw == 8) want = 256 / p.nblocks;
+    const int base = mnas_diag_env("MNAS_PWS_WGS", 512);      // (diagnosis build: the sweep of DESIGN_HISTORY.md round 5)
+    int want = base / p.nblocks;                      // two workgroups per CU
+    if (p.nw == 8) want = base / 2 / p.nblocks;
     if (want < 32) want = 32;
     return ngroups < want ? ngroups : want;
 }
