@@ -538,7 +538,7 @@ static int launch_igemm(const IgemmArgs& a_in, int nparts, int nblocks, hipStrea
     else pipe = phases >= 2 && nkc > 1 && !s2;
     // long reductions on small pixel counts (the 14x14 / 7x7 stages, dense 3x3): 128-wide K chunks put 4x more
     // bytes in flight per staging pass (these launches are latency-bound, not bandwidth-bound)
-    if constexpr (PT == 1 && (NT == 2 || NT == 3 || NT == 6)) {
+    if constexpr (PT == 1 && (NT == 2 || NT == 3 || NT == 4 || NT == 6)) {
         if (a.kch == 128) return launch_igemm_k<MODE, NT, PT, 128>(a, nparts, nblocks, pipe, stream);
     }
     return a.kch >= 64 ? launch_igemm_k<MODE, NT, PT, 64>(a, nparts, nblocks, pipe, stream)
@@ -672,7 +672,7 @@ extern "C" int mnas_conv_gemm(const MnasConvGemm* c, void* stream) {
 
     int best_nt, nblocks, pt;
     igemm_tiling(c->Co, a.Kpad, a.M, &best_nt, &nblocks, &pt);
-    if (pt == 1 && a.Kpad >= 256 && (best_nt == 2 || best_nt == 3 || best_nt == 6)) a.kch = 128;
+    if (pt == 1 && a.Kpad >= 256 && (best_nt == 2 || best_nt == 3 || best_nt == 6 || (best_nt == 4 && mnas_diag_env("MNAS_IG_K128_NT4", 1)))) a.kch = 128;
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_IG(MODE_, NT_) \
     if (c->mode == MODE_ && best_nt == NT_) return pt == 2 ? launch_igemm<MODE_, NT_, 2>(a, c->nparts, nblocks, s) \
