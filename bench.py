@@ -514,6 +514,7 @@ OVERRIDES = [
      lambda e: [setattr(e, n, int(v)) for n, v in zip(("pw_bwd_parts_large", "pw_bwd_parts_mid", "pw_bwd_parts_small"),
                                                       os.environ["MNAS_PWB"].split(","))]),
     ("MNAS_SE_MLP_UNFUSED", "squeeze-excite MLP as separate head-GEMM launches", lambda e: setattr(e, "se_fused_mlp", False)),
+    ("MNAS_GRAPHS", "launch lists replayed as hipGraphs", lambda e: setattr(e, "use_graphs", True)),
     ("MNAS_NO_DYMAT", "dense 3x3 backward forms dy on load", lambda e: setattr(e, "materialize_dy", False)),
     ("MNAS_WGRAD_WGS", "workgroups per k_wgrad launch", lambda e: setattr(e, "wgrad_wgs", _ov_int("MNAS_WGRAD_WGS"))),
     ("MNAS_NO_RECOMP", "expand convs' fused backward reads the stored y1 instead of recomputing it", lambda e: setattr(e, "pw_recompute_y", False)),

@@ -502,6 +502,12 @@ int mnas_run_ops(const MnasOp* ops, int n, void* stream, int* failed_at);
  * streams is expressed with MNAS_OP_EVENT_RECORD / MNAS_OP_EVENT_WAIT ops.  Used to run the weight-gradient
  * kernels of a layer concurrently with the input-gradient chain (they only share read-only inputs). */
 int mnas_run_ops_multi(const MnasOp* ops, int n, void* const* streams, int nstreams, int* failed_at);
+/* The same launch list captured once into a hipGraph and replayed (ABI 7).  mnas_graph_create runs the list under stream capture on
+ * streams[0] (nothing executes) and instantiates it; mnas_graph_launch replays it on `stream`.  Everything in the list is baked in
+ * -- pointers, integers, and whether a gated EVENT_RECORD was live at capture time: re-create when the list changes. */
+int mnas_graph_create(const MnasOp* ops, int n, void* const* streams, int nstreams, void** exec_out, int* failed_at);
+int mnas_graph_launch(void* exec, void* stream);
+int mnas_graph_destroy(void* exec);
 
 /* ---- scratch sizes (bytes) of the partial tables the launches above write; the library never allocates.
  * kind MNAS_WS_CONV_STATS:  float[2][c][n]      (c = Co, n = nparts; also the fused-reduce tables)

@@ -134,6 +134,9 @@ SYMBOLS = {
     "mnas_se_fc_fwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 4),
     "mnas_se_fc_bwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 6 + [c_int, c_void_p]),
     "mnas_conv_gemm_gate_ok": (c_int, [c_int, c_int, c_int, c_int]),
+    "mnas_graph_create": (c_int, [C.POINTER(MnasOp), c_int, C.POINTER(c_void_p), c_int, C.POINTER(c_void_p), C.POINTER(c_int)]),
+    "mnas_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "mnas_graph_destroy": (c_int, [c_void_p]),
     "mnas_version": (c_int, []),
     "mnas_arch": (C.c_char_p, []),
     "mnas_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),

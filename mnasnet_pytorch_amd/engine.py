@@ -306,6 +306,9 @@ class Program:
         self.patch_gout = None
         self.patch_dx = None
         self.patch_x_bwd = None
+        self._graphs = {}
+        self._out_buf = None
+        self._gout_buf = None
         if training:
             self._build_backward(step_records, cur)
 
@@ -851,13 +854,55 @@ class Program:
     def _run(self, arr, n, what):
         failed = C.c_int(-1)
         streams = (C.c_void_p * 2)(L.cur_stream(), self.eng.side_stream_handle())
+        live_events = bool(self.eng.profile_opcodes) and self.eng.profile_gate.value != 0      # bracketing event records: per-launch path
+        # (not with the second stream: a segment may fork onto it and join only at the end of a later segment -- an unjoined capture)
+        if self.eng.use_graphs and n > 1 and not live_events and not self.eng.use_side_stream:
+            # the list as a hipGraph (csrc/mnas_abi.hip mnas_graph_create): captured at first use and whenever a run-time
+            # pointer of the list (input batch, output, incoming gradient) or the event-record gate has changed since
+            key = hash(bytes(arr))
+            slot = self._graphs.setdefault(id(arr), {"exec": None, "key": None, "miss": 0})
+            if slot["key"] != key and slot["miss"] < 4:
+                if slot["exec"] is not None:
+                    self.eng.lib.mnas_graph_destroy(slot["exec"])
+                    slot["exec"] = None
+                    slot["miss"] += 1             # a list whose pointers change every step is not worth capturing: fall through
+                ex = C.c_void_p()
+                # capture on a stream of our own (the legacy default stream cannot capture); the graph is LAUNCHED on the current one
+                if self.eng._capture_stream is None or self.eng._capture_stream.device != self.eng.device:
+                    self.eng._capture_stream = torch.cuda.Stream(device=self.eng.device)
+                cap = (C.c_void_p * 2)(self.eng._capture_stream.cuda_stream, streams[1])
+                rc = self.eng.lib.mnas_graph_create(arr, n, cap, 2, C.byref(ex), C.byref(failed))
+                if rc != 0:
+                    raise RuntimeError("%s: graph capture failed with code %d at op %d" % (what, rc, failed.value))
+                slot["exec"], slot["key"] = ex, key
+            if slot["key"] == key and slot["exec"] is not None:
+                rc = self.eng.lib.mnas_graph_launch(slot["exec"], streams[0])
+                if rc != 0:
+                    raise RuntimeError("%s: hipGraphLaunch failed with code %d" % (what, rc))
+                return
         rc = self.eng.lib.mnas_run_ops_multi(arr, n, streams, 2, C.byref(failed))
         if rc != 0:
             raise RuntimeError("%s: mnas_run_ops failed with code %d at op %d (opcode %d)" %
                                (what, rc, failed.value, arr[failed.value].opcode if failed.value >= 0 else -1))
 
-    def run_forward(self, x):
-        out = torch.empty(self.out_shape, dtype=torch.float32, device=x.device)
+    def __del__(self):
+        try:
+            for slot in getattr(self, "_graphs", {}).values():
+                if slot["exec"] is not None:
+                    self.eng.lib.mnas_graph_destroy(slot["exec"])
+                    slot["exec"] = None
+        except Exception:
+            pass
+
+    def run_forward(self, x, static_io=False):
+        """static_io (Trainer's autograd-free path with Engine.use_graphs): the output lives in a buffer of the program, so that the
+        captured graph's pointers stay valid from step to step (the caller consumes it before the next forward of this program)."""
+        if static_io and self.eng.use_graphs:
+            if self._out_buf is None or self._out_buf.device != x.device:
+                self._out_buf = torch.empty(self.out_shape, dtype=torch.float32, device=x.device)
+            out = self._out_buf
+        else:
+            out = torch.empty(self.out_shape, dtype=torch.float32, device=x.device)
         for j, slot in self.patch_x:
             self.fwd_ops[j].p[slot] = x.data_ptr()
         j, slot = self.patch_out
@@ -866,7 +911,12 @@ class Program:
         self._run(self.fwd_ops, self.fwd_n, "forward")
         return out
 
-    def run_backward(self, gout, on_stage_done: Optional[Callable[[int], None]] = None):
+    def run_backward(self, gout, on_stage_done: Optional[Callable[[int], None]] = None, static_io=False):
+        if static_io and self.eng.use_graphs:
+            if self._gout_buf is None or self._gout_buf.shape != gout.shape or self._gout_buf.device != gout.device:
+                self._gout_buf = torch.empty_like(gout)
+            self._gout_buf.copy_(gout)                       # (a few hundred KB) keeps the captured pointer valid
+            gout = self._gout_buf
         segs = {st: (arr, n) for st, arr, n in self.bwd_segments}
         st, j, slot = self.patch_gout
         segs[st][0][j].p[slot] = gout.data_ptr()
@@ -997,6 +1047,8 @@ class Engine:
         # by round 3 the main-stream kernels and k_wgrad_t fill the chip on their own and the overlap only trades time between the
         # two streams (11.17-11.21 ms with it, 11.07-11.13 without, same call) -- and it hid per-kernel gains on the main stream
         # (the K-streaming input gradient: neutral with the side stream, -0.1 ms without).  Off by default; the path stays tested.
+        self.use_graphs = False          # launch lists replayed as hipGraphs (Program._run)
+        self._capture_stream = None
         self.use_side_stream = False
         self.side_stream_max_pixels = 1 << 40     # with use_side_stream: only layers with at most this many output pixels fork
         # workgroups of a k_wgrad launch (pixel splits x 64x64 slabs): 512 rather than 1024 leaves the main stream's persistent

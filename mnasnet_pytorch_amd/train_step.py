@@ -384,12 +384,12 @@ class Trainer:
             eng.ensure_setup(x.device)
             eng._check_modes()
             prog = eng.program(x.shape[0], x.shape[2], x.shape[3], True, False, True, u8)
-            f = prog.run_forward(x)
+            f = prog.run_forward(x, static_io=True)
             head.calls = self.optimizer.step_count           # dropout masks follow the CHECKPOINTED step count: a resumed run does
                                                              # not replay the masks of the first steps
             self.last_logits, loss, df = head.loss_and_grad(f.view(f.size(0), -1), target, self.criterion.ignore_index)
             accumulate = eng.prepare_grads()
-            prog.run_backward(df, eng.on_stage_done)
+            prog.run_backward(df, eng.on_stage_done, static_io=True)
             eng.finish_grads(accumulate)
         else:
             out = self.model(x.float())
