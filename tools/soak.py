@@ -2,7 +2,8 @@
 on, 4 fixed batches cycling) executed twice from the same state; every step's loss and the final flat parameter / moment buffers
 must be bit-identical (no float atomics, fixed summation orders: a difference is a race or an uninitialised read -- the kind of
 bug that never shows in small tests, cf. dma_barrier in csrc/mnas_common.h), the loss finite throughout and lower at the end.
-usage (GPU box): python3 tools/soak.py [steps=150] [batch=256] [se|HxW]      (se: the 5x5 + squeeze-excite variant of BASELINE config 4)"""
+usage (GPU box): python3 tools/soak.py [steps=150] [batch=256] [se|ccf|graphs|HxW ...]   (se: the 5x5 + squeeze-excite variant of BASELINE
+config 4; ccf: Mnasnet(cut_channels_first=True); graphs: the second run replays hipGraphs)"""
 import sys, os, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,18 +12,21 @@ from mnasnet_pytorch_amd.train_step import Trainer
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-SE = len(sys.argv) > 3 and sys.argv[3] == "se"
+SE = "se" in sys.argv[3:]
+CCF = "ccf" in sys.argv[3:]             # the reference's default topology, Mnasnet(cut_channels_first=True)
+GRAPHS = "graphs" in sys.argv[3:]       # second run replays the launch lists as hipGraphs (Engine.use_graphs): must give the same bits
 HW = (224, 224)
 for a_ in sys.argv[3:]:
     if "x" in a_ and a_.replace("x", "").isdigit():
         HW = tuple(int(v) for v in a_.split("x"))            # e.g. 384x512: a rectangular cluster of BASELINE config 5
 
 
-def run():
+def run(graphs=False):
     torch.manual_seed(1234)
-    base = Mnasnet(False, kernel_size=5, se_ratio=0.25) if SE else load_model("mnasnet")      # seeded default init
+    base = Mnasnet(False, kernel_size=5, se_ratio=0.25) if SE else (Mnasnet(cut_channels_first=True) if CCF else load_model("mnasnet"))
     m = FineTuneModelPool(base, "mnasnet", 1000, "512").cuda().train()
     tr = Trainer(m, lr=1e-3)
+    tr.engine.use_graphs = graphs
     g = torch.Generator(device="cuda").manual_seed(7)
     xs = [torch.randn(B, 3, HW[0], HW[1], device="cuda", generator=g) for _ in range(4)]
     ts = [torch.randint(0, 1000, (B,), device="cuda", generator=g) for _ in range(4)]
@@ -39,7 +43,7 @@ def run():
 
 
 a = run()
-b = run()
+b = run(GRAPHS)
 print("steps %d, batch %d: loss %.4f -> %.4f (min %.4f)" % (K, B, a[0][0], a[0][-1], min(a[0])))
 print("run 1 params %s  buffers %s" % (a[1][:16], a[2][:16]))
 print("run 2 params %s  buffers %s" % (b[1][:16], b[2][:16]))
