@@ -414,6 +414,17 @@ class Program:
             built[st] = seg_ops[st].build()
         self.bwd_segments = [(st,) + built[st] for st in order]
         self._seg_index = {st: n for n, st in enumerate(order)}
+        # all segments as ONE list (graph mode without a stage-done callback: one hipGraphLaunch per backward instead of one per
+        # stage -- every graph boundary is ~9 us of idle GPU)
+        n_all = sum(built[st][1] for st in order)
+        self.bwd_all = (L.MnasOp * max(1, n_all))()
+        self.bwd_all_n, self._seg_off, k = n_all, {}, 0
+        for st in order:
+            arr, n = built[st]
+            self._seg_off[st] = k
+            for j in range(n):
+                C.memmove(C.byref(self.bwd_all, k * C.sizeof(L.MnasOp)), C.byref(arr, j * C.sizeof(L.MnasOp)), C.sizeof(L.MnasOp))
+                k += 1
         if self.patch_x_bwd is not None:
             ops_obj, idx, slot = self.patch_x_bwd
             st = [s for s in order if seg_ops[s] is ops_obj][0]
@@ -930,16 +941,23 @@ class Program:
             self._gout_buf.copy_(gout)                       # (a few hundred KB) keeps the captured pointer valid
             gout = self._gout_buf
         segs = {st: (arr, n) for st, arr, n in self.bwd_segments}
-        st, j, slot = self.patch_gout
-        segs[st][0][j].p[slot] = gout.data_ptr()
+
+        def patch(where, ptr):
+            st, j, slot = where
+            segs[st][0][j].p[slot] = ptr
+            self.bwd_all[self._seg_off[st] + j].p[slot] = ptr
+
+        patch(self.patch_gout, gout.data_ptr())
         if self.patch_x_bwd is not None:
-            st, j, slot = self.patch_x_bwd
-            segs[st][0][j].p[slot] = self.x_ref.data_ptr()
+            patch(self.patch_x_bwd, self.x_ref.data_ptr())
         dx = None
         if self.patch_dx is not None:
             dx = torch.empty((self.N, self.in_channels, self.H, self.W), dtype=torch.float32, device=gout.device)
-            st, j, slot = self.patch_dx
-            segs[st][0][j].p[slot] = dx.data_ptr()
+            patch(self.patch_dx, dx.data_ptr())
+        if self.eng.use_graphs and on_stage_done is None and not self.eng.use_side_stream:
+            self._run(self.bwd_all, self.bwd_all_n, "backward")
+            self.x_ref = None
+            return dx
         for st, arr, n in self.bwd_segments:
             self._run(arr, n, "backward[stage %d]" % st)
             if on_stage_done is not None:
