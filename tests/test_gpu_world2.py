@@ -81,7 +81,7 @@ def _emulate(opt="adam", mixed=False):
 
 
 def _check_ranks(r0, r1, side):
-    assert r0["world"] == r1["world"] == 2 and r0["side"] == r1["side"] == bool(side)
+    assert r0["world"] == r1["world"] == 2 and r0["side"] == r1["side"] == (side == 1)
     # one model on both ranks, bit for bit (rank 1 started from perturbed parameters: the rank-0 broadcast made them equal)
     assert torch.equal(r0["flat_p0"], r1["flat_p0"])
     assert torch.equal(r0["flat_p"], r1["flat_p"])
@@ -121,7 +121,7 @@ def _compare(r0, emu, what):
     return eu, d3
 
 
-@pytest.mark.parametrize("side", [0, 1])
+@pytest.mark.parametrize("side", [0, 1, 2])          # 0 one stream, 1 weight gradients on the second stream, 2 hipGraph replay
 def test_real_engine_world2_one_gpu(tmp_path, side):
     """Adam (the reference's optimizer, train.py:219)."""
     r0, r1 = _run_world2(tmp_path, side)

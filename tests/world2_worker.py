@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_world2.py: ONE data-parallel rank of the real step -- Trainer(distributed=True) over the HIP
 engine, stage-done callback, two-bucket asynchronous all-reduce, fused Adam with 1/world -- on cuda:0.  Two of these run side
 by side on the same GPU with backend "gloo" on device tensors (RCCL refuses two ranks on one device); everything except the
-transport is what `bench.py --gpus 2` runs.   python world2_worker.py <rank> <world> <port> <side 0|1> <out.pt> [optimizer]"""
+transport is what `bench.py --gpus 2` runs.   python world2_worker.py <rank> <world> <port> <side 0|1|2=graphs> <out.pt> [optimizer]"""
 import os
 import sys
 
@@ -43,7 +43,8 @@ def main():
                 for p in m.parameters():
                     p.add_(0.01 * torch.randn_like(p))
         tr = Trainer(m, lr=1e-3, distributed=True, optimizer=opt)
-        tr.engine.use_side_stream = bool(side)
+        tr.engine.use_side_stream = side == 1
+        tr.engine.use_graphs = side == 2                # 2: every launch list replayed as a hipGraph (one per backward stage: the callback runs between them)
         tr.engine.reset_programs()
         x, t = rank_batch(rank, mixed=mixed)
         x, t = x.cuda(), t.cuda()
