@@ -335,7 +335,7 @@ def cpu_baseline(seconds, kernel=None, se_ratio=0.0):
     x = torch.randn(bs, 3, 224, 224, generator=g)
     t = torch.randint(0, 1000, (bs,), generator=g)
     # thread count: oneDNN stops scaling on these small convs well before the host's core count and then LOSES (EPYC 9575F,
-    # bs 32: 16 threads 1.42 s/step, 32: 1.54, 64: 2.57, 128: 4.9 -- tools/probe/oracle_threads.py): one step at each candidate,
+    # bs 32: 16 threads 1.42 s/step, 32: 1.54, 64: 2.57, 128: 4.9, measured in round 5): one step at each candidate,
     # the fastest runs the sample, so that the baseline is the best this host does with the port
     cands = sorted({min(ncpu, c) for c in (64, 32, 16)}, reverse=True)
     torch.set_num_threads(cands[0])
