@@ -61,8 +61,13 @@ def parse():
                     help="FUNCTIONAL TEST ONLY (tests/test_gpu_world2.py): every rank on cuda:0, backend gloo on device tensors (RCCL "
                          "refuses two ranks on one device) -- exercises this script's multi-rank code path on a 1-GPU box; the line "
                          "says so in `overrides` and its numbers mean nothing")
+    ap.add_argument("--dump-state", type=str, default="",
+                    help="TESTS: after the timed windows every rank writes <dir>/rank<r>.json (sha256 of its flat parameter buffer, "
+                         "the bucket schedule of its last step, whether it ran the roofline calibration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration probes (copy GB/s, packed-FMA TFLOP/s, clocks)")
+    ap.add_argument("--smi", action="store_true", help="also keep a rocm-smi / amd-smi snapshot in the box object: a CHILD process, started before this "
+                                                      "process touches the GPU and never when a profiler / tool library is preloaded")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed window until this much timed work exists; "
@@ -242,11 +247,29 @@ def sysfs_clocks(d):
     return out or None
 
 
+def gpu_maybe_initialised():
+    """True when this process may already have initialised the GPU -- torch says so, or a tool library that does it at load time
+    (rocprofv3's, roctracer's, any LD_PRELOAD) is mapped.  A process in that state must not fork+exec on this pool."""
+    if torch.cuda.is_initialized() or os.environ.get("LD_PRELOAD"):
+        return True
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ):
+        return True
+    try:
+        with open("/proc/self/maps") as f:
+            maps = f.read().lower()
+    except OSError:
+        return True
+    return any(t in maps for t in ("rocprofiler", "roctracer", "rocprof-sdk", "librocpd", "libroctx"))
+
+
 def smi_snapshot():
-    """rocm-smi / amd-smi clocks and power as a CHILD process.  Called only BEFORE this process touches the GPU (a process that
-    has initialised HIP must not fork+exec on this pool); None if neither tool is present or it does not answer in time."""
+    """rocm-smi / amd-smi clocks and power as a CHILD process (opt-in: --smi).  Only BEFORE this process touches the GPU (a
+    process that has initialised HIP must not fork+exec on this pool) -- refused when gpu_maybe_initialised(); None if neither
+    tool is present or it does not answer in time."""
     import shutil
     import subprocess
+    if gpu_maybe_initialised():
+        return {"skipped": "the GPU may already be initialised in this process (profiler / preload): no child process is started"}
     for tool, argv in (("rocm-smi", ["--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"]),
                        ("amd-smi", ["metric", "--clock", "--power", "--json"])):
         exe = shutil.which(tool) or ("/opt/rocm/bin/" + tool if os.path.exists("/opt/rocm/bin/" + tool) else None)
@@ -272,9 +295,6 @@ class BoxProbe:
 
     def __init__(self, lib, dev):
         self.lib, self.dev = lib, dev
-        self.src = torch.empty(self.COPY_BYTES // 4, dtype=torch.float32, device=dev).fill_(1.0)
-        self.dst = torch.empty_like(self.src)
-        self.out = torch.zeros(self.VALU_BLOCKS * 256, dtype=torch.float32, device=dev)
         self.sysfs = _sysfs_dir(dev)
 
     def _time(self, fn, reps):
@@ -290,26 +310,33 @@ class BoxProbe:
         return best
 
     def measure(self):
+        """The 2 x 1 GiB of probe buffers exist only inside this call (nothing of the probe stays allocated during the timed windows)."""
         from mnasnet_pytorch_amd._lib import check, cur_stream
-        lib = self.lib
-        copy = lambda: check(lib.mnas_probe_copy(self.src.data_ptr(), self.dst.data_ptr(), self.COPY_BYTES, cur_stream()), "probe_copy")
-        valu = lambda it=self.VALU_ITERS: check(lib.mnas_probe_valu(self.out.data_ptr(), self.VALU_BLOCKS, it, cur_stream()), "probe_valu")
-        copy(); valu()
+        lib, dev = self.lib, self.dev
+        src = torch.empty(self.COPY_BYTES // 4, dtype=torch.float32, device=dev).fill_(1.0)
+        dst = torch.empty_like(src)
+        out = torch.zeros(self.VALU_BLOCKS * 256, dtype=torch.float32, device=dev)
+        sink = torch.zeros(65536, dtype=torch.int32, device=dev)
+        copy = lambda: check(lib.mnas_probe_copy(src.data_ptr(), dst.data_ptr(), self.COPY_BYTES, cur_stream()), "probe_copy")
+        copy4 = lambda: check(lib.mnas_probe_copy4(src.data_ptr(), dst.data_ptr(), self.COPY_BYTES, 0, cur_stream()), "probe_copy4")
+        read = lambda: check(lib.mnas_probe_read(src.data_ptr(), sink.data_ptr(), self.COPY_BYTES, 0, cur_stream()), "probe_read")
+        valu = lambda it=self.VALU_ITERS: check(lib.mnas_probe_valu(out.data_ptr(), self.VALU_BLOCKS, it, cur_stream()), "probe_valu")
+        copy(); copy4(); read(); valu()
         torch.cuda.synchronize()
-        cms = self._time(copy, 5)
+        cms, c4ms, rms = self._time(copy, 5), self._time(copy4, 5), self._time(read, 5)
         vms = self._time(valu, 5)
         flop = self.VALU_BLOCKS * 256.0 * self.VALU_ITERS * 8 * 4
-        res = {"copy_GBps": round(2 * self.COPY_BYTES / cms / 1e6, 1), "valu_pk_fma_TFLOPps": round(flop / vms / 1e9, 2),
+        res = {"copy_GBps": round(2 * self.COPY_BYTES / cms / 1e6, 1), "copy4_nt_GBps": round(2 * self.COPY_BYTES / c4ms / 1e6, 1),
+               "read_GBps": round(self.COPY_BYTES / rms / 1e6, 1), "valu_pk_fma_TFLOPps": round(flop / vms / 1e9, 2),
                "valu_clock_GHz": round(flop / vms / 1e9 / 65.536, 3)}
         if self.sysfs:
             valu(self.VALU_ITERS * 25)              # ~50 ms of pure vector load: sample the clocks from the host meanwhile
             time.sleep(0.02)
             res["under_valu_load"] = sysfs_clocks(self.sysfs)
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        del src, dst, out, sink
+        torch.cuda.empty_cache()
         return res
-
-    def free(self):
-        del self.src, self.dst, self.out
 
 
 def cpu_model():
@@ -549,6 +576,9 @@ def main():
         # in this process yet; never exec from a process that has) and hand its exit code back
         import socket
         import subprocess
+        if not args.one_device and torch.cuda.device_count() < args.gpus:
+            sys.exit("bench.py: --gpus %d needs %d visible GPUs, this box has %d. Nothing was measured. (--one-device runs the "
+                     "multi-rank code path on cuda:0 over gloo as a functional test.)" % (args.gpus, args.gpus, torch.cuda.device_count()))
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
@@ -562,10 +592,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    # child process, BEFORE anything in this process touches the GPU -- and never under a profiler: rocprofv3's preloaded library
-    # has initialised the GPU before main() runs, and a process that has must not fork+exec on this pool
-    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ)
-    smi = smi_snapshot() if (rank == 0 and not args.no_box and not profiled) else None
+    # opt-in child process, BEFORE anything in this process touches the GPU and never with a tool library mapped (smi_snapshot
+    # refuses by itself: rocprofv3's preloaded library has initialised the GPU before main() runs)
+    smi = smi_snapshot() if (rank == 0 and args.smi and not args.no_box) else None
+    if not args.one_device:
+        ndev = torch.cuda.device_count()             # counts devices without initialising the GPU
+        if ndev < max(1, (args.gpus if distributed else 1)) or local_rank >= max(ndev, 1):
+            sys.exit("bench.py: --gpus %d needs %d visible GPUs, this box has %d (rank %d, LOCAL_RANK %d). Nothing was measured. "
+                     "(--one-device runs the multi-rank code path on cuda:0 over gloo as a functional test.)"
+                     % (args.gpus, args.gpus, ndev, rank, local_rank))
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -632,6 +667,13 @@ def main():
             import torch.distributed as dist
             dist.destroy_process_group()
         return
+    # ---- box calibration, first half: BEFORE the warm-up steps (round 6: it used to run right in front of the timed windows --
+    # 75 ms of full vector load and 12 GiB of copies, on rank 0 only, changed the thermal / clock state the windows were measured
+    # in); every rank runs it (the MAX-over-ranks time must not depend on which rank was heated), rank 0 reports
+    box, probe = None, None
+    if not args.no_box:
+        probe = BoxProbe(L.load(), dev)
+        box = {"before": probe.measure()}
     for _ in range(args.warmup):
         trainer.step(x, target)
     barrier()
@@ -651,15 +693,13 @@ def main():
             dom_key = max(calib["agg"].items(), key=lambda kv: kv[1][0])[0]
             eng.profile_filter = lambda opc, ints: class_key(opc, ints, L) == dom_key
             eng.reset_programs()
-        for _ in range(2):
+        if profile:
+            eng.profile_gate.value = 0               # as in all but the last step of a window; with MNAS_GRAPHS this is where the
+        for _ in range(2):                           # launch lists are captured and instantiated -- outside the timed windows
             trainer.step(x, target)
     # ---- timed region: windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced with
     # MAX over ranks; windows are repeated until >= --min-seconds of timed work exist (a 20-step window is 0.2 s: too short for
     # an external GPU-busy sampler to see) and the MEDIAN window is reported
-    box, probe = None, None
-    if rank == 0 and not args.no_box:
-        probe = BoxProbe(L.load(), dev)
-        box = {"before": probe.measure()}
     windows, host_dts = [], []
     while True:
         barrier()
@@ -682,14 +722,28 @@ def main():
             break
     if probe is not None:
         box["after"] = probe.measure()
-        probe.free()
         pr = torch.cuda.get_device_properties(dev)
         box.update({"device": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count,
                     "hbm_GiB": round(pr.total_memory / 2 ** 30, 1), "torch_clock_rate_khz": getattr(pr, "clock_rate", None),
                     "smi_before_gpu_init": smi,
-                    "note": "copy_GBps = 2 x 1 GiB / float4-copy time; valu_pk_fma_TFLOPps = pure v_pk_fma_f32 loop, "
+                    "note": "copy_GBps = 2 x 1 GiB / plain grid-stride float4 copy (ONE 16-byte load in flight per lane); "
+                            "copy4_nt_GBps = the same bytes with four independent nontemporal 16-byte loads in flight per lane and "
+                            "nontemporal stores (how the step's streaming kernels are built: the rate they may be compared with); "
+                            "read_GBps = 1 GiB read-only stream, four loads in flight; valu_pk_fma_TFLOPps = pure v_pk_fma_f32 loop, "
                             "valu_clock_GHz = that / 65.536 flop per clock (256 CUs x 4 SIMDs x 16 lanes x 2 x 2); best of 5, HIP "
-                            "events, taken right before and right after the timed windows (csrc/mnas_probe.hip)"})
+                            "events; 'before' is taken ahead of the warm-up steps, 'after' right after the timed windows, on every "
+                            "rank (rank 0 reported); no probe buffer is allocated during the windows (csrc/mnas_probe.hip)"})
+    if args.dump_state:
+        import hashlib
+        torch.cuda.synchronize()
+        os.makedirs(args.dump_state, exist_ok=True)
+        with open(os.path.join(args.dump_state, "rank%d.json" % rank), "w") as f:
+            json.dump({"rank": rank, "world": world, "local_rank": local_rank, "profiled": bool(profile),
+                       "flat_p_sha256": hashlib.sha256(trainer.flat_p.detach().cpu().numpy().tobytes()).hexdigest(),
+                       "schedule": [list(e) for e in trainer.schedule.log] if trainer.schedule is not None else None,
+                       "steps_run": trainer.steps if hasattr(trainer, "steps") else None,
+                       "running_mean0_sha256": hashlib.sha256(model.state_dict()[next(k for k in model.state_dict() if k.endswith("running_mean"))]
+                                                              .detach().cpu().numpy().tobytes()).hexdigest()}, f)
     order = sorted(range(len(windows)), key=lambda i: windows[i])
     mid = order[(len(order) - 1) // 2]
     dt, host_dt = windows[mid], host_dts[mid]
@@ -761,6 +815,13 @@ def main():
             for key, ints, msv, nb_ in calib["detail"]:
                 sys.stderr.write("%-18s %-48s %8.1f us %8.1f GB/s\n" % (key, ",".join(map(str, ints)), msv * 1e3,
                                                                       nb_ / max(msv, 1e-9) / 1e6))
+    if eng.use_graphs:
+        res["graph_mode"] = {"captured_before_timed_region": True,
+                             "per_launch_steps_per_window": 1 if profile else 0,
+                             "note": "launch lists replayed as hipGraphs; the graphs are captured in an untimed step before the first "
+                                     "window" + ("; the LAST step of every %d-step window runs per-launch (its dominant-class "
+                                                 "launches are bracketed with HIP events for the roofline object; --no-roofline "
+                                                 "gives a pure replay measurement)" % args.steps if profile else "")}
     if box is not None:
         res["box"] = box
     if args.h2d and world == 1:

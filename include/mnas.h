@@ -55,7 +55,7 @@ typedef struct MnasGradIn {
     const float* coef;    /* float[5][C] */
 } MnasGradIn;
 
-int mnas_version(void);                 /* ABI version: 7 (round 5: + mnas_se_fc_*; 6 = struct layouts changed in rounds 2, 3, twice in round 4 -- 4 = the tiled-block forms,
+int mnas_version(void);                 /* ABI version: 8 (round 6: + mnas_probe_copy4 / _read; 7 = round 5: + mnas_se_fc_*; 6 = struct layouts changed in rounds 2, 3, twice in round 4 -- 4 = the tiled-block forms,
                                          * 5 = squeeze-excite on load: MnasConvGemm.gate, MnasPwBwd.seg_px -- and in round 5: 6 = the opt-in
                                          * forms that lost their A/B are gone (MnasPwBwd.dy_out / red4, MnasDwBwd.src_* / g_gate / g_bias,
                                          * mnas_dw_exp_*, mnas_irb_*, mnas_gram*, mnas_se_bn_assemble); their opcode numbers stay retired) */
@@ -534,6 +534,12 @@ int mnas_event_elapsed_ms(void* start, void* stop, float* ms);   /* non-zero if 
  *                  flop = blocks*256*iters*8*4;  TFLOP/s / 65.536 = sustained shader clock in GHz (256 CUs x 4 SIMDs x 16 lanes). */
 int mnas_probe_copy(const void* src, void* dst, int64_t bytes, void* stream);
 int mnas_probe_valu(float* out, int blocks, int iters, void* stream);
+/* round 6 (ABI 8): the probes a kernel of the step may be compared with -- four independent 16-byte nontemporal loads in flight
+ * per lane (k_probe_copy keeps one).  mnas_probe_copy4: rate = 2*bytes / time.  mnas_probe_read: read-only stream, `sink`
+ * (>= 4 * workgroups bytes) is never written; rate = bytes / time.  Both: bytes % 16384 == 0.  blocks = 0: one 16 KB trip per
+ * workgroup up to 65536 workgroups, > 0: that many persistent workgroups. */
+int mnas_probe_copy4(const void* src, void* dst, int64_t bytes, int blocks, void* stream);
+int mnas_probe_read(const void* src, void* sink, int64_t bytes, int blocks, void* stream);
 int mnas_probe_empty(int blocks, int threads, void* stream);      /* a kernel that does nothing: the cost of one launch in a stream */
 
 #ifdef __cplusplus

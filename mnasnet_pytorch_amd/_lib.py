@@ -8,7 +8,7 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 7          # include/mnas.h: mnas_version()
+ABI_VERSION = 8          # include/mnas.h: mnas_version()
 LIB_PATH = os.environ.get("MNAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmnas_hip.so")      # override: A/B builds (tools/)
 
 c_void_p, c_int, c_float, c_double, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
@@ -189,6 +189,8 @@ SYMBOLS = {
     "mnas_event_elapsed_ms": (c_int, [c_void_p, c_void_p, C.POINTER(c_float)]),
     "mnas_probe_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mnas_probe_valu": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mnas_probe_copy4": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnas_probe_read": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnas_probe_empty": (c_int, [c_int, c_int, c_void_p]),
 }
 

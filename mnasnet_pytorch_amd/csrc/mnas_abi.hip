@@ -34,7 +34,7 @@ int mnas_pws_enabled() {
     return on;
 }
 
-extern "C" int mnas_version(void) { return 7; }
+extern "C" int mnas_version(void) { return 8; }
 extern "C" const char* mnas_arch(void) { return "gfx950"; }
 
 extern "C" int64_t mnas_workspace_bytes(int kind, int n, int c, int k) {

@@ -12,6 +12,38 @@ __global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ sr
     for (; i < n; i += st) dst[i] = src[i];
 }
 
+// The same copy built the way the streaming kernels of the step are built: FOUR independent 16-byte loads in flight per lane
+// (a workgroup moves 16 KB per trip, each wave four consecutive 1 KB lines), nontemporal loads and stores (nothing is re-read).
+// This -- not the plain grid-stride copy above, which keeps one load per lane in flight -- is the rate a kernel of the step may
+// be compared with (round 6: k_pw_bwd 16->48 at 112^2 sustained more algorithmic bytes than k_probe_copy did).
+__global__ __launch_bounds__(256) void k_probe_copy4(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, size_t n) {
+    const size_t st = (size_t)gridDim.x * 1024;
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + 768 < n; i += st) {
+        const u32x4_t a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256);
+        const u32x4_t c = __builtin_nontemporal_load(src + i + 512), d = __builtin_nontemporal_load(src + i + 768);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + 256);
+        __builtin_nontemporal_store(c, dst + i + 512);
+        __builtin_nontemporal_store(d, dst + i + 768);
+    }
+}
+
+// read-only stream: four independent 16-byte loads in flight per lane, folded with XOR; the sink is never written (the
+// comparison value cannot occur), it only keeps the loads alive.  rate = bytes / time.
+__global__ __launch_bounds__(256) void k_probe_read(const u32x4_t* __restrict__ src, uint32_t* __restrict__ sink, size_t n) {
+    const size_t st = (size_t)gridDim.x * 1024;
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    u32x4_t acc = {0u, 0u, 0u, 0u};
+    for (; i + 768 < n; i += st) {
+        const u32x4_t a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256);
+        const u32x4_t c = __builtin_nontemporal_load(src + i + 512), d = __builtin_nontemporal_load(src + i + 768);
+        acc.x ^= a.x ^ b.x ^ c.x ^ d.x; acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
+        acc.z ^= a.z ^ b.z ^ c.z ^ d.z; acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u && sink) sink[blockIdx.x] = acc.x;
+}
+
 // 8 independent v_pk_fma_f32 chains per lane, nothing else in the loop: flops = blocks * 256 * iters * 8 * 2 lanes * 2.
 // At one packed FMA per SIMD per 4 cycles the chip does 256 CUs * 4 SIMDs * 16 lanes * 2 * 2 = 65 536 flop per clock, so
 // TFLOP/s / 65.536 = the shader clock in GHz this box sustains under vector load.
@@ -42,6 +74,26 @@ extern "C" int mnas_probe_empty(int blocks, int threads, void* stream) {
 extern "C" int mnas_probe_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     if (!src || !dst || bytes < 16 || (bytes & 15)) return MNAS_EINVAL;
     hipLaunchKernelGGL(k_probe_copy, dim3(8192), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, (size_t)(bytes >> 4));
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+extern "C" int mnas_probe_copy4(const void* src, void* dst, int64_t bytes, int blocks, void* stream) {
+    if (!src || !dst || bytes < 16384 || (bytes & 16383) || blocks < 0) return MNAS_EINVAL;      // whole 16 KB trips only
+    const size_t n = (size_t)(bytes >> 4);
+    const size_t trips = n / 1024;
+    const int g = blocks > 0 ? blocks : (int)(trips < 65536 ? trips : 65536);
+    hipLaunchKernelGGL(k_probe_copy4, dim3(g), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)src, (u32x4_t*)dst, n);
+    MNAS_CHECK_LAUNCH();
+    return MNAS_OK;
+}
+
+extern "C" int mnas_probe_read(const void* src, void* sink, int64_t bytes, int blocks, void* stream) {
+    if (!src || !sink || bytes < 16384 || (bytes & 16383) || blocks < 0) return MNAS_EINVAL;     // whole 16 KB trips only
+    const size_t n = (size_t)(bytes >> 4);
+    const size_t trips = n / 1024;
+    const int g = blocks > 0 ? blocks : (int)(trips < 65536 ? trips : 65536);
+    hipLaunchKernelGGL(k_probe_read, dim3(g), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)src, (uint32_t*)sink, n);
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
 }

@@ -307,6 +307,10 @@ class Program:
         self.patch_dx = None
         self.patch_x_bwd = None
         self._graphs = {}
+        # what the launch lists were BUILT with (the capture decision in _run must not follow later changes of the engine's
+        # switches: a list with stream-1 fork/join pairs or live event records cannot be captured whatever the switches say now)
+        self._built_side = bool(eng.use_side_stream)
+        self._built_prof = bool(eng.profile_opcodes)
         self._out_buf = None
         self._gout_buf = None
         self._x_buf = None
@@ -867,15 +871,18 @@ class Program:
     def _run(self, arr, n, what):
         failed = C.c_int(-1)
         streams = (C.c_void_p * 2)(L.cur_stream(), self.eng.side_stream_handle())
-        live_events = bool(self.eng.profile_opcodes) and self.eng.profile_gate.value != 0      # bracketing event records: per-launch path
+        live_events = self._built_prof and self.eng.profile_gate.value != 0      # bracketing event records: per-launch path
         # (not with the second stream: a segment may fork onto it and join only at the end of a later segment -- an unjoined capture)
-        if self.eng.use_graphs and n > 1 and not live_events and not self.eng.use_side_stream:
+        if self.eng.use_graphs and n > 1 and not live_events and not self._built_side:
             # the list as a hipGraph (csrc/mnas_abi.hip mnas_graph_create): captured at first use and whenever a run-time
             # pointer of the list (input batch, output, incoming gradient) or the event-record gate has changed since
             key = hash(bytes(arr))
             slot = self._graphs.setdefault(id(arr), {"exec": None, "key": None, "miss": 0})
             if slot["key"] != key and slot["miss"] < 4:
                 if slot["exec"] is not None:
+                    # the previous launch of this exec may still be running (the host enqueues a step in < 1 ms of a 10 ms step)
+                    # and the exec owns its kernel arguments: wait for the device first (at most 4 re-captures per list)
+                    torch.cuda.synchronize(self.eng.device)
                     self.eng.lib.mnas_graph_destroy(slot["exec"])
                     slot["exec"] = None
                     slot["miss"] += 1             # a list whose pointers change every step is not worth capturing: fall through
@@ -898,12 +905,19 @@ class Program:
             raise RuntimeError("%s: mnas_run_ops failed with code %d at op %d (opcode %d)" %
                                (what, rc, failed.value, arr[failed.value].opcode if failed.value >= 0 else -1))
 
+    def destroy_graphs(self):
+        """Destroy the captured graph executables -- after a device sync: one of them may still be executing."""
+        slots = [s for s in getattr(self, "_graphs", {}).values() if s["exec"] is not None]
+        if not slots:
+            return
+        torch.cuda.synchronize(self.eng.device)
+        for slot in slots:
+            self.eng.lib.mnas_graph_destroy(slot["exec"])
+            slot["exec"] = None
+
     def __del__(self):
         try:
-            for slot in getattr(self, "_graphs", {}).values():
-                if slot["exec"] is not None:
-                    self.eng.lib.mnas_graph_destroy(slot["exec"])
-                    slot["exec"] = None
+            self.destroy_graphs()
         except Exception:
             pass
 
@@ -954,7 +968,7 @@ class Program:
         if self.patch_dx is not None:
             dx = torch.empty((self.N, self.in_channels, self.H, self.W), dtype=torch.float32, device=gout.device)
             patch(self.patch_dx, dx.data_ptr())
-        if self.eng.use_graphs and on_stage_done is None and not self.eng.use_side_stream:
+        if self.eng.use_graphs and on_stage_done is None and not self._built_side:
             self._run(self.bwd_all, self.bwd_all_n, "backward")
             self.x_ref = None
             return dx
@@ -1241,6 +1255,9 @@ class Engine:
         The HIP events they own are destroyed (after a device sync: a launch list may still be in flight)."""
         if any(p.busy for lst in self.programs.values() for p in lst):
             raise RuntimeError("reset_programs() while a forward is waiting for its backward")
+        for lst in self.programs.values():
+            for p in lst:
+                p.destroy_graphs()            # syncs first when a program holds a graph executable
         self.programs.clear()
         self.profile_events = []
         if self._events:

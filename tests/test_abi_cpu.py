@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
         assert name in _lib.SYMBOLS, "ctypes prototype missing for " + name
-    assert lib.mnas_version() == _lib.ABI_VERSION == 7 and lib.mnas_arch() == b"gfx950"
+    assert lib.mnas_version() == _lib.ABI_VERSION == 8 and lib.mnas_arch() == b"gfx950"
     assert ctypes.sizeof(_lib.MnasOp) == 4 + 15 * 4 + 4 * 8 + 16 * 8
     assert lib.mnas_packed_bytes(_lib.PACK_FWD, 48, 16, 1, 1) == 48 * 32 * 2
     assert lib.mnas_packed_bytes(_lib.PACK_DGRAD, 48, 16, 1, 1) == 16 * 64 * 2

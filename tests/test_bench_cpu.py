@@ -45,3 +45,26 @@ def test_class_key_and_work_accounting():
     nb, _ = b.launch_work(L.OP_PW_BWD, (50176, 576, 96, 85, 1, 0), L)
     assert nb == 2 * 50176 * (2 * 96 + 2 * 576)
     assert b.class_key(L.OP_CONV_GEMM, (1, 256, 7, 7, 320, 7, 7, 192, 3, 3), L) == "k_igemm<dgrad>"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus 8` on a box with fewer GPUs (none here): clear message, non-zero exit, no JSON line, no child processes --
+    as the plain command and as one rank of a torchrun launch (round 6; tests/test_gpu_world2.py repeats it on the GPU box)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for extra in ({}, {"RANK": "5", "LOCAL_RANK": "5", "WORLD_SIZE": "8", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                           capture_output=True, text=True, timeout=300, env=dict(env, **extra))
+        assert r.returncode != 0 and "needs 8 visible GPUs" in (r.stderr + r.stdout), r.stderr[-500:]
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpu_maybe_initialised_guard(monkeypatch):
+    """The opt-in rocm-smi child process is refused whenever a tool library may have initialised the GPU."""
+    b = _bench()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert b.gpu_maybe_initialised() and "skipped" in b.smi_snapshot()
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert b.gpu_maybe_initialised()

@@ -34,12 +34,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world2(tmp_path, side, opt="adam", mixed=False):
+def _run_world2(tmp_path, side, opt="adam", mixed=False, world=2):
     port = _free_port()
-    outs = [str(tmp_path / ("rank%d_side%d.pt" % (r, side))) for r in range(2)]
+    outs = [str(tmp_path / ("rank%d_side%d.pt" % (r, side))) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "world2_worker.py"), str(r), "2", str(port), str(side), outs[r], opt] + (["mixed"] if mixed else []),
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "world2_worker.py"), str(r), str(world), str(port), str(side), outs[r], opt] + (["mixed"] if mixed else []),
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     for p in procs:
         try:
@@ -170,3 +170,72 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["config"]["global_batch"] == 64
     assert d["value"] > 0 and d["config"]["parallelism"] == "dp2" and "cpu_baseline" not in d
     assert d["roofline"]["launches_per_step"] >= 1 and any("--one-device" in o for o in d["overrides"])
+
+
+# ---- world 8 on one device (round 6): the day an 8-GPU node exists, the first real run must not fail on plumbing -----------------
+def test_real_engine_world8_one_gpu(tmp_path):
+    """Eight real Trainer(distributed=True) ranks on cuda:0 over gloo (ranks 2..7 have never existed before round 6): ranks start
+    from eight different parameter sets, see eight different batches (even ranks 64x96, odd ranks 96x64: two compiled programs),
+    and after 3 Adam steps hold ONE model bit for bit; bucket 0 goes out right after stage 5 on every rank in every step;
+    BatchNorm statistics stay per rank."""
+    res = _run_world2(tmp_path, 0, "adam", mixed=True, world=8)
+    assert all(r["world"] == 8 for r in res)
+    for r in res[1:]:
+        assert torch.equal(res[0]["flat_p0"], r["flat_p0"]) and torch.equal(res[0]["flat_g1"], r["flat_g1"])
+        assert torch.equal(res[0]["flat_p"], r["flat_p"])
+    assert torch.isfinite(res[0]["flat_p"]).all() and not torch.equal(res[0]["flat_p"], res[0]["flat_p0"])
+    assert len({r["rm0"].numpy().tobytes() for r in res}) == 8                      # per-rank running statistics
+    for r in res:
+        assert len(r["logs"]) == 3
+        for log in r["logs"]:
+            log = [tuple(e) for e in log]
+            assert log.index(("launch", 0)) == log.index(("stage", 5)) + 1
+            assert log.index(("launch", 0)) < log.index(("stage", 4)) < log.index(("stage", 0)) < log.index(("launch", 1))
+            assert log.count(("launch", 0)) == 1 and log[-1] == ("launch", 1)
+
+
+def test_bench_world8_dry_run_on_one_gpu(tmp_path):
+    """The driver's multi-GPU command line, dry: plain `python3 bench.py --gpus 8 --one-device --batch 32 --steps 5 --warmup 2`
+    (bench.py starts its eight ranks as a CHILD torch.distributed.run on a free port; nothing is exec'ed from a process that
+    has touched the GPU).  ONE JSON line, n_gpus 8, global batch 256; every rank finished with bit-equal parameters and the same
+    bucket order; only rank 0 ran the roofline calibration; per-rank BatchNorm statistics differ."""
+    import json
+    root = os.path.dirname(HERE)
+    dump = str(tmp_path / "state")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--one-device", "--batch", "32", "--steps", "5", "--warmup", "2",
+           "--min-seconds", "0", "--dump-state", dump]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 5 and d["warmup"] == 2
+    assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp8" and "cpu_baseline" not in d
+    assert d["value"] > 0 and d["roofline"]["launches_per_step"] >= 1 and any("--one-device" in o for o in d["overrides"])
+    assert "copy4_nt_GBps" in d["box"]["before"] and "read_GBps" in d["box"]["after"]
+    st = [json.load(open(os.path.join(dump, "rank%d.json" % k))) for k in range(8)]
+    assert [s["rank"] for s in st] == list(range(8)) and all(s["world"] == 8 for s in st)
+    assert len({s["flat_p_sha256"] for s in st}) == 1                       # one model on all eight ranks, bit for bit
+    assert len({s["running_mean0_sha256"] for s in st}) == 8                # per-rank BatchNorm statistics (different data per rank)
+    assert [s["profiled"] for s in st] == [True] + [False] * 7              # roofline calibration on rank 0 only
+    for s in st:
+        log = [tuple(e) for e in s["schedule"]]
+        assert log.index(("launch", 0)) == log.index(("stage", 5)) + 1 and log[-1] == ("launch", 1)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`bench.py --gpus 8` WITHOUT --one-device on a box with fewer GPUs: a clear message and a non-zero exit code right away (it
+    used to die inside torch.cuda.set_device / hang in the rendezvous), both as the plain command and as a torchrun rank."""
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box has 8 GPUs")
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "needs 8 visible GPUs" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300,
+                       env=dict(env, RANK="5", LOCAL_RANK="5", WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+    assert r.returncode != 0 and "needs 8 visible GPUs" in (r.stderr + r.stdout)
