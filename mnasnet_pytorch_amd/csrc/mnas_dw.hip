@@ -30,6 +30,19 @@
 #define MNAS_DW_XFILL 1      // backward: out-of-image ring columns of x pre-filled, window read without per-column selects (as the forward)
 #endif
 
+// DIAGNOSIS builds only (tools/build_alt.sh mnas_dw.hip -D...): the sweep without its DMA (compute on whatever the LDS holds) and
+// without its arithmetic (ring fills and barriers only, nothing stored) -- the compute-only / memory-only decomposition of DESIGN.md
+#ifndef MNAS_DW_NODMA
+#define MNAS_DW_NODMA 0
+#endif
+#ifndef MNAS_DW_NOCOMP
+#define MNAS_DW_NOCOMP 0
+#endif
+
+#ifndef MNAS_DW_RA
+#define MNAS_DW_RA 1         // 1: the window of row j+1 is read from LDS before row j is computed (0: A/B builds)
+#endif
+
 #define DW_G 4          // rows per sweep step (default; the 5x5 weight-gradient sweep uses 2, see mnas_dw_bwd)
 #define DW_BW 4         // output columns per thread
 #define DW_RR 8         // ring rows = 2 * G (two buffers of G rows)
@@ -124,13 +137,13 @@ __device__ __forceinline__ void dw_dma_plan(const DwArgs& a, DwDma& p, int wave,
         p.goff[j] = x * (a.C >> 3) + cgl;
     }
 }
-
 // copy image rows [row0, row0+G) of one tensor (rows outside the image are skipped: readers test the row themselves)
 template <int KS, int G>
 __device__ __forceinline__ void dw_dma_rows(const DwArgs& a, const DwDma& p, uint32_t* ring, const uint4* __restrict__ src,
                                             int n, int row0, int x0, int c0, int wave, int nwaves) {
     constexpr int PAD = KS / 2;
     const int C8 = a.C >> 3;
+    if (MNAS_DW_NODMA) return;
 #pragma unroll
     for (int r = 0; r < G; ++r) {
         const int gy = row0 + r;
@@ -182,6 +195,26 @@ __device__ __forceinline__ void dw_read_act_nm(const uint32_t* rowp, int ps, boo
         if (has_coef) {
             v = f2fma(v, s, t);
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);       // v_max_f32(qNaN, 0) = 0 (IEEE maxNum)
+        }
+        xr[xx] = v;
+    }
+}
+// The two halves of dw_read_act_nm for the software-pipelined sweeps: the RAW window of row j+1 is read from LDS before the
+// arithmetic of row j starts (the row body used to open with WIN_W ds_reads and a full lgkmcnt(0) -- at 3 waves per SIMD the LDS
+// latency of every row was exposed), the activation is applied when the row is consumed.
+template <int WIN_W>
+__device__ __forceinline__ void dw_ld_raw(const uint32_t* rowp, int ps, uint32_t (&r)[WIN_W]) {
+#pragma unroll
+    for (int xx = 0; xx < WIN_W; ++xx) r[xx] = rowp[xx * ps];
+}
+template <int WIN_W>
+__device__ __forceinline__ void dw_act_raw(const uint32_t (&r)[WIN_W], bool has_coef, f2 s, f2 t, f2 (&xr)[WIN_W]) {
+#pragma unroll
+    for (int xx = 0; xx < WIN_W; ++xx) {
+        f2 v = f2bf(r[xx]);
+        if (has_coef) {
+            v = f2fma(v, s, t);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
         }
         xr[xx] = v;
     }
@@ -252,19 +285,22 @@ __device__ __forceinline__ void dw_block_reduce(float* scratch, const f2 (&v)[NV
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------
-template <int KS, int G>
+// HC ("has coefficients", round 6): whether the input is a virtual activation is a template parameter -- as a run-time flag
+// the window read computed both forms and selected (16 v_cndmask per row on top of the 8 packed FMAs + 16 v_max of the
+// activation itself: 9 % of the 5x5 row body's ~185 vector instructions)
+template <int KS, int G, bool HC>
 __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, MnasActIn in, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, uint32_t* __restrict__ out,
                                                                    float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1;
+    constexpr int PAD = KS / 2, WIN_W = DW_BW + KS - 1, RR = 2 * G;
     const int cblk = 2 * a.cpw;
     uint32_t* ring = (uint32_t*)smem;                    // [RR][rc*4 dwords]; reused as reduction scratch at the end
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
     const bool active = sxi < a.sx;
-    const bool has_coef = in.scale != nullptr;
+    constexpr bool has_coef = HC;
     const f2 zero2 = {0.f, 0.f};
     f2 s1 = zero2, s2 = zero2;
     int cur_c0 = -1;
@@ -304,23 +340,18 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         // rows are two buffers of G = 4: the DMA of group s+1 is in flight while group s is computed.  One barrier per
         // step (dma_barrier: vmcnt(0) then s_barrier): it publishes group s and retires the readers of group s-1, whose
         // buffer the next DMA overwrites.
-        __syncthreads();                             // previous item's last group consumed
-        dw_fill_edges<2 * G>(a, plan, ring, wave, nwaves, lane, has_coef);
+        __syncthreads();                             // previous item's last group consumed (nothing is in flight here)
+        dw_fill_edges<RR>(a, plan, ring, wave, nwaves, lane, has_coef);
         dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
             dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
             if (s + 1 < nsteps) dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, r0 + G, x0, c0, wave, nwaves);
-            if (!active) continue;
-            // unrolled over the row group (3x3: all G rows, 5x5: two -- more spills past 168 VGPRs): the register-ring shift of
-            // consecutive rows becomes renaming instead of KS*DW_BW 64-bit moves per row (3x3 at 112x112: 146 -> 132 us)
-#pragma unroll (KS == 3 ? G : (G == 4 ? 2 : 1))
-            for (int j = 0; j < G; ++j) {
-                const int iy = r0 + j;
+            if (!active || MNAS_DW_NOCOMP) continue;
+            // One image row: scatter its window into the register ring, emit the completed output row, shift the ring.
+            auto row = [&](int iy, const f2 (&xr)[WIN_W], bool have) {
                 const int oy = iy - PAD;             // A[0] is complete after this row
-                if (iy >= 0 && iy < a.H) {           // uniform: rows outside the image contribute nothing
-                    f2 xr[WIN_W];
-                    dw_read_act_nm<WIN_W>(colp + (size_t)dw_slot<(2 * G)>(iy) * a.rc * 4, ps, has_coef, cs, ct, xr);
+                if (have) {                          // uniform: rows outside the image contribute nothing
 #pragma unroll
                     for (int i = 0; i < KS; ++i)
 #pragma unroll
@@ -346,6 +377,36 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
                     for (int ox = 0; ox < DW_BW; ++ox) A[i][ox] = A[i + 1][ox];
 #pragma unroll
                 for (int ox = 0; ox < DW_BW; ++ox) A[KS - 1][ox] = b2;
+            };
+            // rows in PAIRS (3x3: the whole group unrolled, 5x5: one pair per trip -- more spills past 168 VGPRs): the register-
+            // ring shift of consecutive rows becomes renaming instead of KS*DW_BW 64-bit moves per row (3x3 at 112x112: 146 ->
+            // 132 us), and the raw window of the next row is in flight while a row is computed (MNAS_DW_RA; reads of rows outside
+            // the image land on some ring row and are dropped)
+            const auto rowp = [&](int iy) { return colp + (size_t)dw_slot<RR>(iy) * a.rc * 4; };
+            constexpr bool RA = MNAS_DW_RA && KS == 3;            // 5x5: the second raw window spills (168 VGPRs = 3 waves per SIMD)
+            constexpr int STEP = (KS == 5 && G == 2) ? 1 : 2;     // 5x5 with 2-row groups: single rows (the pair spills as well)
+            uint32_t wa[WIN_W], wb[WIN_W];
+            if (RA) dw_ld_raw<WIN_W>(rowp(r0), ps, wa);
+#pragma unroll (KS == 3 ? G / 2 : 1)
+            for (int j = 0; j < G; j += STEP) {
+                const int iy = r0 + j;
+                const bool in0 = iy >= 0 && iy < a.H, in1 = iy + 1 >= 0 && iy + 1 < a.H;
+                f2 xr[WIN_W];
+                if constexpr (RA) {
+                    dw_ld_raw<WIN_W>(rowp(iy + 1), ps, wb);
+                    dw_act_raw<WIN_W>(wa, has_coef, cs, ct, xr);
+                    row(iy, xr, in0);
+                    if (j + 2 < G) dw_ld_raw<WIN_W>(rowp(iy + 2), ps, wa);
+                    dw_act_raw<WIN_W>(wb, has_coef, cs, ct, xr);
+                    row(iy + 1, xr, in1);
+                } else {
+                    if (in0) dw_read_act_nm<WIN_W>(rowp(iy), ps, has_coef, cs, ct, xr);
+                    row(iy, xr, in0);
+                    if constexpr (STEP == 2) {
+                        if (in1) dw_read_act_nm<WIN_W>(rowp(iy + 1), ps, has_coef, cs, ct, xr);
+                        row(iy + 1, xr, in1);
+                    }
+                }
             }
         }
     }
@@ -370,7 +431,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
 //                                   its centre 4 columns become D[0] of the dy ring (D[q] = dy row iy-q)
 //   xa = act(x) row r = iy-PAD   -> WG: wacc[ky][kx] += D[ky][ox] * xa[ox+kx]      (dy rows r-ky+PAD = iy-ky)
 //   RED: the raw x centre values of row iy-PAD are in the x ring too: sum dz, sum dz*xhat for the emitted gin row.
-template <int KS, bool DG, bool WG, bool RED, int G, bool GM = false>
+template <int KS, bool DG, bool WG, bool RED, int G, bool GM = false, bool HC = true>
 __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void k_dw_bwd(
     DwArgs a, MnasActIn x, MnasGradIn d, const float* __restrict__ w, uint32_t* __restrict__ gin, float* __restrict__ wpartial,
     float* __restrict__ red_partial, const float* __restrict__ red_bn) {
@@ -386,7 +447,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     const int cp = tid % a.cpw, sxi = tid / a.cpw;
     const bool active = sxi < a.sx;
-    const bool has_coef = x.scale != nullptr;
+    constexpr bool has_coef = HC || !WG;       // only the activation window of the weight gradient depends on it (HC = false: raw x)
     const uint32_t* xglob = (const uint32_t*)x.data;
     const f2 zero2 = {0.f, 0.f};
     int cur_c0 = -1;
@@ -418,7 +479,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                 cf[r].x = ch_ok ? d.coef[(size_t)r * a.C + ch] : 0.f;
                 cf[r].y = ch_ok ? d.coef[(size_t)r * a.C + ch + 1] : 0.f;
             }
-            if (has_coef && ch_ok) { cs.x = x.scale[ch]; cs.y = x.scale[ch + 1]; ct.x = x.shift[ch]; ct.y = x.shift[ch + 1]; }
+            if (x.scale != nullptr && ch_ok) { cs.x = x.scale[ch]; cs.y = x.scale[ch + 1]; ct.x = x.shift[ch]; ct.y = x.shift[ch + 1]; }
             if (RED && ch_ok) {
                 ris.x = red_bn[6 * a.C + ch]; ris.y = red_bn[6 * a.C + ch + 1];
                 rmu.x = -red_bn[5 * a.C + ch] * ris.x; rmu.y = -red_bn[5 * a.C + ch + 1] * ris.y;
@@ -481,7 +542,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
                     for (int ox = 0; ox < DW_BW; ++ox) xq[j][ox] = xn[j][ox];
             }
             if (s + 1 < nsteps) { dma_group(r0 + G); load_xn(r0 + G); }
-            if (!active) continue;
+            if (!active || MNAS_DW_NOCOMP) continue;
 #pragma unroll 1       // unrolling the group would drop the ring-shift moves (as in k_dw_fwd), but needs > 168 VGPRs: measured 266 -> 300 us at 2 waves/SIMD
             for (int j = 0; j < G; ++j) {
                 const int iy = r0 + j;
@@ -625,6 +686,7 @@ static bool dw_force(int N, int H, int W, int C, int k, int nrings, DwArgs* a, i
 static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, int* g) {
     DwArgs a4, a2;
     const int nrings = dw_rings(form);
+    // (two ring buffers of G rows; three -- the DMA two groups ahead behind a counted vmcnt -- measured 1-18 % slower in round 6)
     if (mnas_diag_env("MNAS_DW_CPW", 0) > 0 && dw_force(N, H, W, C, k, nrings, a, g)) return true;
     const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2);
     if (!ok4 && !ok2) return false;
@@ -674,13 +736,30 @@ extern "C" int mnas_dw_fwd(const MnasDwFwd* c, void* stream) {
     const size_t red_need = (size_t)a.sx * 2 * 2 * a.cpw * sizeof(float);          // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
     hipStream_t s = (hipStream_t)stream;
-#define MNAS_DWF(K_, G_) hipLaunchKernelGGL((k_dw_fwd<K_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
-                                            (uint32_t*)c->out, c->stats)
+#define MNAS_DWF(K_, G_) do { if (c->in.scale) hipLaunchKernelGGL((k_dw_fwd<K_, G_, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
+                                            (uint32_t*)c->out, c->stats); \
+                              else hipLaunchKernelGGL((k_dw_fwd<K_, G_, false>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->in, c->w, c->bias, \
+                                            (uint32_t*)c->out, c->stats); } while (0)
     if (c->k == 3) { if (g == 4) MNAS_DWF(3, 4); else MNAS_DWF(3, 2); }
     else { if (g == 4) MNAS_DWF(5, 4); else MNAS_DWF(5, 2); }
 #undef MNAS_DWF
     MNAS_CHECK_LAUNCH();
     return MNAS_OK;
+}
+
+// HC = false (a materialised x: only direct callers of the C ABI; the network's depthwise inputs are virtual activations) exists
+// for the forms that read the activation window (WG) only
+template <int KS, bool DG, bool WG, bool RED, int G, bool GM>
+static void dw_bwd_launch(const DwArgs& a, size_t lds, hipStream_t s, const MnasDwBwd* c) {
+    if constexpr (WG) {
+        if (!c->x.scale) {
+            hipLaunchKernelGGL((k_dw_bwd<KS, DG, WG, RED, G, GM, false>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->w,
+                               (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_dw_bwd<KS, DG, WG, RED, G, GM, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, c->x, c->dy, c->w,
+                       (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn);
 }
 
 extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
@@ -700,16 +779,12 @@ extern "C" int mnas_dw_bwd(const MnasDwBwd* c, void* stream) {
     size_t lds = (size_t)nrings * 2 * g * a.rc * 16;
     const size_t red_need = (size_t)a.sx * (want_wg ? c->k * c->k : 2) * 2 * a.cpw * sizeof(float);   // dw_block_reduce scratch
     if (lds < red_need) lds = red_need;
-#define MNAS_DWB(K_, DG_, WG_, R_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, DG_, WG_, R_, G_>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
-                                                         c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
+#define MNAS_DWB(K_, DG_, WG_, R_, G_) dw_bwd_launch<K_, DG_, WG_, R_, G_, false>(a, lds, s, c)
 #define MNAS_DWB_G(K_, DG_, WG_, R_) do { if (g == 4) MNAS_DWB(K_, DG_, WG_, R_, 4); else MNAS_DWB(K_, DG_, WG_, R_, 2); } while (0)
     if (c->g_masked) {                       // fused sweep only (what the engine runs behind a project conv's masked gradient)
         if (!(want_dg && want_wg && red)) return MNAS_EINVAL;
-#define MNAS_DWM(K_, G_) hipLaunchKernelGGL((k_dw_bwd<K_, true, true, true, G_, true>), dim3(a.geff), dim3(a.nthreads), lds, s, a, \
-                                            c->x, c->dy, c->w, (uint32_t*)c->gin, c->wpartial, c->red_partial, c->red_bn)
-        if (c->k == 3) { if (g == 4) MNAS_DWM(3, 4); else MNAS_DWM(3, 2); }
-        else { if (g == 4) MNAS_DWM(5, 4); else MNAS_DWM(5, 2); }
-#undef MNAS_DWM
+        if (c->k == 3) { if (g == 4) dw_bwd_launch<3, true, true, true, 4, true>(a, lds, s, c); else dw_bwd_launch<3, true, true, true, 2, true>(a, lds, s, c); }
+        else { if (g == 4) dw_bwd_launch<5, true, true, true, 4, true>(a, lds, s, c); else dw_bwd_launch<5, true, true, true, 2, true>(a, lds, s, c); }
         MNAS_CHECK_LAUNCH();
         return MNAS_OK;
     }

@@ -293,6 +293,25 @@ def test_stage_full_size_vs_mirror(name):
             continue
         e = rl2(gv, r["grads"][kk])
         assert e < (0.1 if kk.endswith("bn.weight") else tol), (kk, e)
+    # ---- scale of every gradient tensor (round 6): the projection coefficient <g_hip, g_mirror> / |g_mirror|^2.  At stage scope
+    # the rounding noise is 3-5e-2 of a tensor's norm and nearly orthogonal to it, so the projection sits within STAGE_PROJ of 1
+    # (measured worst: see STAGE_PROJ) and a 10 % scale error in ONE tensor -- e.g. a BatchNorm-weight gradient, which the 0.1
+    # rel-L2 bound above can let through -- is seen.  The whole network cannot resolve that for a 16..120-element tensor (its
+    # per-tensor noise is 0.15-0.29, test_net_full_size_vs_mirror); every stage at its full size can.
+    agree = _grad_agreement(grads, r["grads"])
+    wp = max(agree.items(), key=lambda kv: abs(kv[1]["proj"] - 1.0))
+    print("   projection coefficient: worst %.4f (%s, %d elements)" % (wp[1]["proj"], wp[0], wp[1]["n"]))
+    if not os.environ.get("MNAS_SCALE_PRINT_ONLY"):
+        for kk, v in agree.items():
+            assert abs(v["proj"] - 1.0) <= STAGE_PROJ, (kk, v)
+        victim = [kk for kk in grads if kk.endswith("bn.weight")][1]
+        hurt = dict(grads)
+        hurt[victim] = grads[victim] * 1.1                    # a deliberately injected x1.1 on one bn.weight gradient ...
+        bad = [kk for kk, v in _grad_agreement(hurt, r["grads"]).items() if abs(v["proj"] - 1.0) > STAGE_PROJ]
+        assert bad == [victim], bad                           # ... fails the check, and nothing else does
+
+
+STAGE_PROJ = 0.02      # |projection - 1| per tensor at stage scope; MEASURED worst over the 14 full-size stages: 0.0079 (round 6, MI355X)
 
 
 @pytest.mark.parametrize("name", ["features2_16_24_k3_112", "features3_24_40_k5_56", "features4_40_80_k5_28"])
@@ -471,9 +490,19 @@ def test_net_full_size_bit_reproducible():
 # test_stage_full_size_vs_mirror; a larger batch does not change it: MNAS_TEST_NET_N=96 measures worst 0.281 / 0.280.)  The bound is PER PARAMETER TENSOR, 1.5x the worst measurement: a wrong sign (rel-L2 2), a
 # wrong scale (>= 0.5) or a dropped application of a shared block in ONE small tensor fails it -- a cosine median does not see that.
 NET_GRAD_RL2 = {False: (0.42, 0.45), True: (0.42, 0.45)}      # {ccf: (bound for all, bound for bn.weight)}
-# Scale agreement per tensor (round 6): |projection coefficient - 1| and |norm ratio - 1| bounds, MEASURED values in
-# the comment of _scale_violations.  {suffix: (projection bound, norm-ratio bound)}
-NET_GRAD_SCALE = {"bn.weight": (1.0, 1.0), "bn.bias": (1.0, 1.0), "conv.weight": (1.0, 1.0)}     # PLACEHOLDER until measured
+# Scale agreement per tensor at WHOLE-NETWORK scope (round 6): bounds on |projection coefficient - 1| and
+# |norm ratio - 1|, {suffix: (projection, norm ratio)} ~ 1.5x the MEASURED worst (MI355X, batch 32, both topologies):
+#   conv.weight (432 .. 614 400 elements): projection 0.974 .. 0.996, norm ratio 0.991 .. 1.009
+#   bn.bias     (16 .. 1920 elements):     projection 0.929 .. 1.048, norm ratio 0.950 .. 1.066
+#   bn.weight   (16 .. 1920 elements):     projection 0.909 .. 1.089, norm ratio 0.934 .. 1.115
+# -- the old bound was 0.5 .. 2.0.  The noise of the whole-network backward (rel-L2 0.15-0.29 per tensor) is nearly orthogonal to
+# a big tensor's gradient, so a 10 % scale error in any conv weight gradient is seen here; in a 16..120-element BatchNorm tensor it
+# moves the projection by up to 0.09 by itself (averaging over 6 inputs still leaves 0.056: tools/probe/scale_noise_k.py), so a
+# 10 % error in ONE such tensor is resolved where the noise is small -- per stage at full size, STAGE_PROJ = 0.02 above.  What the
+# network adds to the stages is the wiring between them: an error there scales EVERY gradient upstream of it, which the
+# per-stage MEDIAN projection (noise averaged over 15-40 tensors) resolves to NET_STAGE_MEDIAN.
+NET_GRAD_SCALE = {"bn.weight": (0.14, 0.17), "bn.bias": (0.11, 0.10), "conv.weight": (0.04, 0.02)}
+NET_STAGE_MEDIAN = 0.04     # |median projection of a stage's tensors - 1|; PLACEHOLDER until measured
 
 
 def _grad_agreement(grads, ref):
@@ -488,6 +517,14 @@ def _grad_agreement(grads, ref):
         out[kk] = {"rel": float((a - b).norm() / (b.norm() + 1e-30)), "cos": float((a @ b) / (a.norm() * b.norm() + 1e-30)),
                    "proj": float(a @ b) / nb2, "ratio": float(a.norm() / (b.norm() + 1e-30)), "n": a.numel()}
     return out
+
+
+def _stage_medians(agree):
+    """{stage: median projection coefficient over the stage's parameter tensors}."""
+    by = {}
+    for kk, v in agree.items():
+        by.setdefault(kk.split(".")[1], []).append(v["proj"])
+    return {kk: float(np.median(v)) for kk, v in by.items()}
 
 
 def _scale_violations(agree):
@@ -537,15 +574,20 @@ def test_net_full_size_vs_mirror(ccf):
         print("    %-11s projection in [%.4f, %.4f], norm ratio in [%.4f, %.4f]"
               % (suffix, min(v["proj"] for v in sel), max(v["proj"] for v in sel), min(v["ratio"] for v in sel), max(v["ratio"] for v in sel)))
     assert not bad, bad
-    # the check must SEE a 10 % scale error in one small tensor: inject x1.1 into one BatchNorm-weight gradient of the 14x14 stage
-    victim = "features.6.layers.0.sequence.1.bn.weight" if "features.6.layers.0.sequence.1.bn.weight" in grads else \
-        [kk for kk in grads if kk.startswith("features.6") and kk.endswith("bn.weight")][1]
-    hurt = dict(grads)
-    hurt[victim] = grads[victim] * 1.1
-    bad_inj = _scale_violations(_grad_agreement(hurt, r["grads"]))
-    print("  injected x1.1 on %s: projection %.4f -> flagged %s" % (victim, _grad_agreement(hurt, r["grads"])[victim]["proj"], [b[0] for b in bad_inj]))
+    med = _stage_medians(agree)
+    print("    per-stage median projection: " + "  ".join("features.%s %.4f" % (kk, v) for kk, v in sorted(med.items())))
     if not os.environ.get("MNAS_SCALE_PRINT_ONLY"):
+        assert all(abs(v - 1.0) <= NET_STAGE_MEDIAN for v in med.values()), med
+        # the checks must SEE what they are for.  (a) x1.1 on ONE conv weight gradient: flagged per tensor, nothing else is.
+        victim = [kk for kk in grads if kk.startswith("features.6") and kk.endswith("sequence.1.conv.weight")][0]
+        hurt = dict(grads)
+        hurt[victim] = grads[victim] * 1.1
+        bad_inj = _scale_violations(_grad_agreement(hurt, r["grads"]))
         assert [b[0] for b in bad_inj] == [victim], bad_inj
+        # (b) a wiring error: x1.1 on the gradient handed from features.5 to features.4 scales everything upstream of it
+        hurt = {kk: (gv * 1.1 if int(kk.split(".")[1]) <= 4 else gv) for kk, gv in grads.items()}
+        med_inj = _stage_medians(_grad_agreement(hurt, r["grads"]))
+        assert sorted(kk for kk, v in med_inj.items() if abs(v - 1.0) > NET_STAGE_MEDIAN) == ["0", "1", "2", "3", "4"], med_inj
     print("full-size net ccf=%s: y vs mirror %.4f, grad cosine min %.4f median %.4f" % (ccf, e_y, min(coss), float(np.median(coss))))
     by_stage = {}
     for kk, e in rels.items():
