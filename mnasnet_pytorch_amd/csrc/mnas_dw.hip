@@ -687,6 +687,8 @@ static bool dw_choose(int N, int H, int W, int C, int k, int form, DwArgs* a, in
     DwArgs a4, a2;
     const int nrings = dw_rings(form);
     // (two ring buffers of G rows; three -- the DMA two groups ahead behind a counted vmcnt -- measured 1-18 % slower in round 6)
+    // (4 output columns per thread; a 2-column forward form -- seven strips cover a 14-wide row exactly, 125 VGPRs = four waves per
+    // SIMD for the 5x5 -- measured equal at 14x14x576 and 5-18 % slower everywhere else, round 6)
     if (mnas_diag_env("MNAS_DW_CPW", 0) > 0 && dw_force(N, H, W, C, k, nrings, a, g)) return true;
     const bool ok4 = dw_pick(N, H, W, C, k, nrings, 8, &a4), ok2 = dw_pick(N, H, W, C, k, nrings, 4, &a2);
     if (!ok4 && !ok2) return false;

@@ -281,6 +281,7 @@ def test_dense_wgrad_slabs_and_empty_splits(shape, nsplit):
 DW = [  # N,H,W,C,k
     (2, 12, 12, 48, 3), (2, 12, 12, 72, 5), (2, 7, 9, 240, 5), (3, 14, 14, 480, 3), (5, 7, 7, 1152, 3),
     (2, 33, 20, 32, 3), (2, 28, 28, 72, 5), (3, 7, 7, 576, 5), (1, 40, 24, 120, 5),
+    (3, 14, 14, 576, 5), (2, 14, 13, 96, 5),          # the 14-wide planes (forward: 2-column strips, round 6)
 ]
 
 

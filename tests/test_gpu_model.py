@@ -502,7 +502,7 @@ NET_GRAD_RL2 = {False: (0.42, 0.45), True: (0.42, 0.45)}      # {ccf: (bound for
 # network adds to the stages is the wiring between them: an error there scales EVERY gradient upstream of it, which the
 # per-stage MEDIAN projection (noise averaged over 15-40 tensors) resolves to NET_STAGE_MEDIAN.
 NET_GRAD_SCALE = {"bn.weight": (0.14, 0.17), "bn.bias": (0.11, 0.10), "conv.weight": (0.04, 0.02)}
-NET_STAGE_MEDIAN = 0.04     # |median projection of a stage's tensors - 1|; PLACEHOLDER until measured
+NET_STAGE_MEDIAN = 0.05     # |median projection of a stage's tensors - 1|; MEASURED: 0.968 .. 0.991 (ccf=False), 0.981 .. 1.015 (ccf=True)
 
 
 def _grad_agreement(grads, ref):
