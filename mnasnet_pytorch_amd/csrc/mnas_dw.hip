@@ -38,6 +38,13 @@
 #ifndef MNAS_DW_NOCOMP
 #define MNAS_DW_NOCOMP 0
 #endif
+#ifndef MNAS_DW_NOBARRIER
+#define MNAS_DW_NOBARRIER 0      // 1: the per-step workgroup barrier is dropped (WRONG results: an upper bound of what wave-private rings could gain)
+#endif
+__device__ __forceinline__ void dw_step_barrier() {
+    if (MNAS_DW_NOBARRIER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else dma_barrier();
+}
 
 #ifndef MNAS_DW_RA
 #define MNAS_DW_RA 1         // 1: the window of row j+1 is read from LDS before row j is computed (0: A/B builds)
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
         dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, -PAD, x0, c0, wave, nwaves);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
-            dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
+            dw_step_barrier();                       // group s landed (every wave's own DMA) + readers of group s-1 retired
             if (s + 1 < nsteps) dw_dma_rows<KS, G>(a, plan, ring, (const uint4*)in.data, n, r0 + G, x0, c0, wave, nwaves);
             if (!active || MNAS_DW_NOCOMP) continue;
             // One image row: scatter its window into the register ring, emit the completed output row, shift the ring.
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
         load_xn(-PAD);
         for (int s = 0; s < nsteps; ++s) {
             const int r0 = -PAD + s * G;
-            dma_barrier();                           // group s landed (every wave's own DMA) + readers of group s-1 retired
+            dw_step_barrier();                       // group s landed (every wave's own DMA) + readers of group s-1 retired
             if constexpr (REDG) {
 #pragma unroll
                 for (int j = 0; j < G; ++j)

@@ -1128,7 +1128,9 @@ class Engine:
         self.se_fused_mlp = True         # the squeeze-excite MLP as mnas_se_fc_fwd / mnas_se_fc_bwd (1 + 2 kernels per block instead of 3 + 4)
         self.pw_bwd_segments = 512       # > 0: the project convs' fused backward at >= 800 k pixels walks contiguous pixel segments,
                                          # at most this many workgroups (0: tiles strided over the grid everywhere)
-        self.dw_bwd_parts = 1024         # upper bound on the persistent workgroups of a depthwise backward launch
+        self.dw_bwd_parts = 2048         # upper bound on the persistent workgroups of a depthwise backward launch (round 6: 1024 made
+                                         # the 1280-item launches of the 14x14 / 7x7 stages walk 1.25 items per workgroup on 1020
+                                         # workgroups; one item per workgroup: step 10.15 vs 10.19 ms, three interleaved pairs)
         self.pw_bwd_parts_large = 1024   # ... on the 112x112 / 56x56 stages
         self.pw_bwd_parts_mid = 512      # ... on the 28x28 stage
         self.pw_bwd_parts_small = 80     # persistent pixel-workgroups of the fused 1x1 backward on the 14x14 stage (x 6 channel slices): a
@@ -1182,7 +1184,7 @@ class Engine:
                     wmax = max(wmax, 64 * ci.cout * ci.cin)        # fused block backward: one slab per image group (<= 64)
             elif ci.kind == "dw":
                 ci.w_fwd = torch.empty(nbytes(L.PACK_DW, ci.cout, 1, ci.k, ci.k), dtype=torch.uint8, device=device)
-                wmax = max(wmax, 1024 * ci.k * ci.k * ci.cout)
+                wmax = max(wmax, max(1024, self.dw_bwd_parts) * ci.k * ci.k * ci.cout)      # wpartial[rows <= nparts][k*k][C]
             else:
                 ci.w_fwd = torch.empty(nbytes(L.PACK_FWD, ci.cout, 27, 1, 1), dtype=torch.uint8, device=device)
                 wmax = max(wmax, _STEM_WGRAD_PARTS_MAX * ci.cout * 27)   # k_stem_wgrad writes partial[nparts][Co][27]
