@@ -17,11 +17,13 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -fno-slp-ve
 LINK=""
 for f in *.hip; do
     o=$OBJ/${f%.hip}.o
+    SCHED="-mllvm -amdgpu-sched-strategy=max-ilp"            # as the Makefile: every file but the depthwise sweeps
+    [ "$f" = "mnas_dw.hip" ] && SCHED=""
     if [ "$f" = "$SRC" ] && [ $# -gt 0 ]; then
         o=$OBJ/${f%.hip}.alt.o
-        /opt/rocm/bin/hipcc $FLAGS "$@" -c $f -o $o &
-    elif [ ! -f $o ] || [ $f -nt $o ] || [ mnas_common.h -nt $o ] || [ ../../include/mnas.h -nt $o ]; then
-        /opt/rocm/bin/hipcc $FLAGS -c $f -o $o &
+        /opt/rocm/bin/hipcc $FLAGS $SCHED "$@" -c $f -o $o &
+    elif [ ! -f $o ] || [ $f -nt $o ] || [ mnas_common.h -nt $o ] || [ ../../include/mnas.h -nt $o ] || [ Makefile -nt $o ]; then
+        /opt/rocm/bin/hipcc $FLAGS $SCHED -c $f -o $o &
     fi
     LINK="$LINK $o"
 done

@@ -12,11 +12,13 @@ cat "$ALT" > $OBJ/old_$NAME
 LINK=""
 for f in *.hip; do
     o=$OBJ/${f%.hip}.o
+    SCHED="-mllvm -amdgpu-sched-strategy=max-ilp"            # as the Makefile: every file but the depthwise sweeps
+    [ "$f" = "mnas_dw.hip" ] && SCHED=""
     if [ "$f" = "$NAME" ]; then
         o=$OBJ/${f%.hip}.old.o
-        /opt/rocm/bin/hipcc $FLAGS -c $OBJ/old_$NAME -o $o &
-    elif [ ! -f $o ] || [ $f -nt $o ] || [ mnas_common.h -nt $o ] || [ ../../include/mnas.h -nt $o ]; then
-        /opt/rocm/bin/hipcc $FLAGS -c $f -o $o &
+        /opt/rocm/bin/hipcc $FLAGS $SCHED -c $OBJ/old_$NAME -o $o &
+    elif [ ! -f $o ] || [ $f -nt $o ] || [ mnas_common.h -nt $o ] || [ ../../include/mnas.h -nt $o ] || [ Makefile -nt $o ]; then
+        /opt/rocm/bin/hipcc $FLAGS $SCHED -c $f -o $o &
     fi
     LINK="$LINK $o"
 done
