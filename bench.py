@@ -571,6 +571,9 @@ def apply_overrides(eng):
 
 def main():
     args = parse()
+    # multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC): RCCL and cross-process tensor sharing
+    # fail with hipIpcGetMemHandle otherwise.  The driver exports it; keep it for the ranks this script starts itself.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks as a CHILD torch.distributed.run (nothing has touched the GPU
         # in this process yet; never exec from a process that has) and hand its exit code back
