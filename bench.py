@@ -550,6 +550,8 @@ OVERRIDES = [
     ("MNAS_DW5_SPLIT", "two-launch backward for the 5x5 depthwise layers", lambda e: setattr(e, "dw_fused_k", (3,))),
     ("MNAS_NO_SE_ONLOAD", "squeeze-excite through the materialised a*s tensor (k_se_scale) instead of on load", lambda e: setattr(e, "se_on_load", not _ov_int("MNAS_NO_SE_ONLOAD"))),
     ("MNAS_PWB_SEGMENTS", "fused 1x1 backward over contiguous pixel segments with at most this many workgroups", lambda e: setattr(e, "pw_bwd_segments", _ov_int("MNAS_PWB_SEGMENTS"))),
+    ("MNAS_IGF_PARTS", "upper bound on the persistent workgroups of a k_igemm forward launch", lambda e: setattr(e, "igemm_fwd_parts", _ov_int("MNAS_IGF_PARTS"))),
+    ("MNAS_IGD_PARTS", "upper bound on the persistent workgroups of a k_igemm input-gradient launch", lambda e: setattr(e, "igemm_dgrad_parts", _ov_int("MNAS_IGD_PARTS"))),
     ("MNAS_DWB_PARTS", "upper bound on the persistent workgroups of a depthwise backward launch", lambda e: setattr(e, "dw_bwd_parts", _ov_int("MNAS_DWB_PARTS"))),
     ("MNAS_LIB_PATH", "alternative build of libmnas_hip.so (tools/build_alt.sh)", lambda e: None),
 ]

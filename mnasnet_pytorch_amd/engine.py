@@ -458,7 +458,7 @@ class Program:
         bias = conv.bias.data_ptr() if conv.bias is not None else None
         nparts = lib.mnas_conv_gemm_parts(0, M, ci.cin, ci.cout, ci.k * ci.k) if ci.kind in ("pw", "dense") else -1
         if nparts < 1:
-            nparts = max(1, min(1024, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
+            nparts = max(1, min(eng.igemm_fwd_parts, _cdiv(M, 128 if M >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(M, ci.cout, ci.k * ci.k * ci.cin))))
         if ci.kind == "dense":       # small maps: one image per workgroup (csrc/mnas_dimg.hip)
             ip = lib.mnas_conv_img_parts(0, N, Hi, Wi, ci.cin, Ho, Wo, ci.cout, ci.k, ci.stride, ci.pad)
             nparts = ip if ip > 0 else nparts
@@ -739,7 +739,7 @@ class Program:
                 Min = N * Hi * Wi
                 nparts = lib.mnas_conv_gemm_parts(1, Min, Co, ci.cin, ci.k * ci.k)
                 if nparts < 1:
-                    nparts = max(1, min(1024, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
+                    nparts = max(1, min(eng.igemm_dgrad_parts, _cdiv(Min, 128 if Min >= _SMALL_M else lib.mnas_conv_gemm_tile_pixels(Min, ci.cin, ci.k * ci.k * Co))))
                 tconv = (eng.use_tconv and ci.kind == "dense" and self._tconv_ok.get(id(ci), False) and gyd is not gy and resid is None
                          and Hi == 2 * Ho and Wi == 2 * Wo)
                 if tconv:
@@ -1128,6 +1128,8 @@ class Engine:
         self.se_fused_mlp = True         # the squeeze-excite MLP as mnas_se_fc_fwd / mnas_se_fc_bwd (1 + 2 kernels per block instead of 3 + 4)
         self.pw_bwd_segments = 512       # > 0: the project convs' fused backward at >= 800 k pixels walks contiguous pixel segments,
                                          # at most this many workgroups (0: tiles strided over the grid everywhere)
+        self.igemm_fwd_parts = 1024      # upper bound on the persistent pixel-workgroups of a k_igemm forward / input-gradient launch
+        self.igemm_dgrad_parts = 1024
         self.dw_bwd_parts = 2048         # upper bound on the persistent workgroups of a depthwise backward launch (round 6: 1024 made
                                          # the 1280-item launches of the 14x14 / 7x7 stages walk 1.25 items per workgroup on 1020
                                          # workgroups; one item per workgroup: step 10.15 vs 10.19 ms, three interleaved pairs)
