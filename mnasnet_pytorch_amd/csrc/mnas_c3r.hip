@@ -34,19 +34,26 @@ struct C3rArgs {
     const float* red_bn;
 };
 
-template <int MODE, int NT, int KSW, int PTW>
+// KQ (round 6): ways the reduction dimension is split over the 8 waves.  4: two wave groups split the four pixel tiles (PTW = 2).
+// 8: every wave takes an eighth of K for all four tiles (PTW = 4) -- the input gradient of 192 -> 320 (K = 2880) then keeps TWO cout
+// tiles of weights in registers (2 x 12 fragments) where the 4-way split could hold one (24): a B fragment read from LDS feeds two
+// MFMAs, the launch needs half as many passes over the images (6 channel slices instead of 12); the image tile is single-buffered
+// (the next image is written after the barrier that ends the MFMA phase anyway) to make room for the eight partial tiles.
+template <int MODE, int NT, int KSW, int PTW, int KQ = 4>
 __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NB = NT * 16, NCH = NB / 4, PROWS = 512 / NCH, PT = 2 * PTW, PP = NB + 4;
+    static_assert((8 / KQ) * PTW == 4, "four 16-pixel tiles per image");
+    constexpr int NB = NT * 16, NCH = NB / 4, PROWS = 512 / NCH, PT = (8 / KQ) * PTW, PP = NB + 4;
+    constexpr int NIMG = KQ == 8 ? 1 : 2;                          // image tiles in LDS
     constexpr int MAXS = 6;                                        // image chunks (16 B) per thread
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kq = wave & 3, ph = wave >> 2;
+    const int kq = wave % KQ, ph = wave / KQ;
     const int l15 = lane & 15, lg = lane >> 4;
     const int img_elems = ((a.Hi + 2) * a.LW * a.Cp + 7) & ~7;
-    uint16_t* img = (uint16_t*)smem;                               // [2][img_elems]
-    float* part = (float*)(img + 2 * img_elems);                   // [4][PT*16][PP]
-    float* lds_coef = part + 4 * PT * 16 * PP;                     // [2][Ci] act-on-load scale / shift
+    uint16_t* img = (uint16_t*)smem;                               // [NIMG][img_elems]
+    float* part = (float*)(img + NIMG * img_elems);                // [KQ][PT*16][PP]
+    float* lds_coef = part + KQ * PT * 16 * PP;                    // [2][Ci] act-on-load scale / shift
     float* lds_rc = lds_coef + 2 * a.Ci;                           // MODE 1: [4][NB] reduce coefficients
     float* lds_fin = part;                                         // end of kernel: [PROWS][2][NB]
     const int co0 = blockIdx.y * NB;
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
 
     for (int i = tid; i < 2 * a.Ci; i += 512)
         lds_coef[i] = has_coef ? (i < a.Ci ? a.act.scale[i] : a.act.shift[i - a.Ci]) : 0.f;
-    for (int i = tid; i < (2 * img_elems) >> 3; i += 512) ((uint4*)img)[i] = make_uint4(0, 0, 0, 0);     // zero borders (and interiors)
+    for (int i = tid; i < (NIMG * img_elems) >> 3; i += 512) ((uint4*)img)[i] = make_uint4(0, 0, 0, 0);  // zero borders (and interiors)
     if (do_red)
         for (int i = tid; i < 4 * NB; i += 512) {
             const int r = i / NB, cc = co0 + i % NB;
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
     bf16x8_t wf[NT][KSW];
 #pragma unroll
     for (int j = 0; j < KSW; ++j) {
-        const int ks = kq + 4 * j;
+        const int ks = kq + KQ * j;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int row = co0 + nt * 16 + l15;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
                 if (p < npix && coe < a.Co) ypre[e] = *(const uint2*)((const uint16_t*)a.red_y + (size_t)n * npix * a.Co + (size_t)p * a.Co + coe);
             }
         }
-        const uint16_t* im = img + (it & 1) * img_elems;
+        const uint16_t* im = img + (NIMG == 2 ? (it & 1) : 0) * img_elems;
         f32x4_t acc[PTW][NT];
 #pragma unroll
         for (int t = 0; t < PTW; ++t)
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < KSW; ++j) {
-            const int ks = kq + 4 * j;
+            const int ks = kq + KQ * j;
             if (ks >= a.ksteps) break;                             // uniform per wave
             // this lane's 8 consecutive k: channels ci0.. of tap `tap` (k = tap*Ci + ci)
             const int k = ks * 32 + lg * 8;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
             const float* src = part + (size_t)p * PP + c4 * 4;
             float4 v = *(const float4*)src;
 #pragma unroll
-            for (int q = 1; q < 4; ++q) {
+            for (int q = 1; q < KQ; ++q) {
                 const float4 x = *(const float4*)(src + (size_t)q * PT * 16 * PP);
                 v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
             }
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
                 }
             }
         }
-        if (nn < a.N) place((it + 1) & 1);                         // that tile was last read in the MFMA phase of image n-1
+        if (nn < a.N) place(NIMG == 2 ? ((it + 1) & 1) : 0);       // that tile was last read in an MFMA phase that ended before the barrier above
     }
     if ((MODE == 0 || do_red) && a.stats) {
         // the PROWS pixel-rows of a cout chunk combined in row order (deterministic)
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-struct C3rPlan { int nt, ksw, ptw, slices, parts; size_t lds; };
+struct C3rPlan { int nt, ksw, ptw, kq, slices, parts; size_t lds; };
 
 int mnas_c3r_enabled() {
     static int on = -1;
@@ -265,12 +272,17 @@ static bool c3r_plan(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, in
     // (192 -> 320 and its input gradient; 96 -> 192 stride 2 forward)
     if ((long long)9 * Ci * Co < 128 * 1024) return false;
     const int ksteps = (9 * Ci + 31) / 32;
-    const int ksw = (ksteps + 3) / 4;
-    p->ptw = 2;
-    // cout tiles per workgroup: 2 while the fragments fit (NT*KSW*4 registers), else 1
+    int ksw = (ksteps + 3) / 4;
+    p->ptw = 2; p->kq = 4;
+    // cout tiles per workgroup: 2 while the fragments fit (NT*KSW*4 registers), else 1 -- or (round 6, MNAS_C3R_KQ8) the
+    // reduction split eight ways with two cout tiles (192 -> 320 input gradient: 90 k-steps = 8 x 12)
     p->nt = ksw <= 14 ? 2 : 1;
-    if (p->nt * ksw > 28 && !(p->nt == 1 && ksw <= 24)) return false;
-    p->ksw = ksw <= 14 ? 14 : 24;
+    if (p->nt == 1 && (ksteps + 7) / 8 <= 12 && mnas_diag_env("MNAS_C3R_KQ8", 1)) {
+        p->kq = 8; p->ptw = 4; p->nt = 2; ksw = (ksteps + 7) / 8; p->ksw = 12;
+    } else {
+        if (p->nt * ksw > 28 && !(p->nt == 1 && ksw <= 24)) return false;
+        p->ksw = ksw <= 14 ? 14 : 24;
+    }
     const int nb = p->nt * 16;
     p->slices = (Co + nb - 1) / nb;
     int parts = 256 / p->slices;                                   // one workgroup per CU (139 KB of LDS at most), one round
@@ -278,9 +290,10 @@ static bool c3r_plan(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, in
     if (parts > N) parts = N;
     p->parts = parts;
     const size_t img = (((size_t)(Hi + 2) * (Wi + 2) * (Ci + 8) + 7) & ~(size_t)7) * 2;
-    p->lds = 2 * img + (size_t)4 * 2 * p->ptw * 16 * (nb + 4) * 4 + (size_t)2 * Ci * 4 + (size_t)4 * nb * 4;
+    const size_t partb = (size_t)p->kq * 64 * (nb + 4) * 4;        // [KQ][4 tiles x 16 pixels][NB + 4]
+    p->lds = (p->kq == 8 ? 1 : 2) * img + partb + (size_t)2 * Ci * 4 + (size_t)4 * nb * 4;
     const size_t fin = (size_t)(512 / (nb / 4)) * 2 * nb * 4;     // lives in the partial area
-    if (fin > (size_t)4 * 2 * p->ptw * 16 * (nb + 4) * 4) return false;
+    if (fin > partb) return false;
     if ((size_t)Hi * Wi * (Ci / 8) > 512 * 6) return false;        // image chunks per thread
     return p->lds <= 160 * 1024;
 }
@@ -309,12 +322,18 @@ int mnas_c3r_run(const MnasConvGemm* c, void* stream) {
     const dim3 grid(c->nparts, p.slices);                // workgroups beyond N only write their (zero) statistics column
     hipStream_t s = (hipStream_t)stream;
 #define MNAS_C3R(M_, NT_, K_) \
-    if (c->mode == M_ && p.nt == NT_ && p.ksw == K_) { \
+    if (c->mode == M_ && p.kq == 4 && p.nt == NT_ && p.ksw == K_) { \
         hipLaunchKernelGGL((k_c3r<M_, NT_, K_, 2>), grid, dim3(512), p.lds, s, a); \
         MNAS_CHECK_LAUNCH(); \
         return MNAS_OK; \
     }
     MNAS_C3R(0, 2, 14) MNAS_C3R(1, 2, 14) MNAS_C3R(0, 1, 24) MNAS_C3R(1, 1, 24)
 #undef MNAS_C3R
+    if (p.kq == 8 && p.nt == 2 && p.ksw == 12) {
+        if (c->mode == 0) hipLaunchKernelGGL((k_c3r<0, 2, 12, 4, 8>), grid, dim3(512), p.lds, s, a);
+        else hipLaunchKernelGGL((k_c3r<1, 2, 12, 4, 8>), grid, dim3(512), p.lds, s, a);
+        MNAS_CHECK_LAUNCH();
+        return MNAS_OK;
+    }
     return MNAS_EINVAL;
 }
