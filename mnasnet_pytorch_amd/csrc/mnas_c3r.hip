@@ -101,6 +101,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
     }
     // ---- epilogue role: thread -> 4 consecutive couts c4 of pixel rows prow + PROWS*i, fixed for the whole kernel
     const int c4 = tid % NCH, prow = tid / NCH;
+    const bool epi_ok = prow < PROWS;                              // (NB = 48: 12 chunks x 42 rows = 504 of the 512 threads)
     const int coe = co0 + c4 * 4;
     float bias4[4], s1[4], s2[4];
 #pragma unroll
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
             for (int e = 0; e < NEP; ++e) {
                 const int p = prow + e * PROWS;
                 ypre[e] = make_uint2(0, 0);
-                if (p < npix && coe < a.Co) ypre[e] = *(const uint2*)((const uint16_t*)a.red_y + (size_t)n * npix * a.Co + (size_t)p * a.Co + coe);
+                if (epi_ok && p < npix && coe < a.Co) ypre[e] = *(const uint2*)((const uint16_t*)a.red_y + (size_t)n * npix * a.Co + (size_t)p * a.Co + coe);
             }
         }
         const uint16_t* im = img + (NIMG == 2 ? (it & 1) : 0) * img_elems;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
 #pragma unroll
         for (int e = 0; e < NEP; ++e) {
             const int p = prow + e * PROWS;
-            if (p >= npix || coe >= a.Co) continue;
+            if (!epi_ok || p >= npix || coe >= a.Co) continue;
             const float* src = part + (size_t)p * PP + c4 * 4;
             float4 v = *(const float4*)src;
 #pragma unroll
@@ -240,10 +241,12 @@ __global__ __launch_bounds__(512) void k_c3r(C3rArgs a) {
     if ((MODE == 0 || do_red) && a.stats) {
         // the PROWS pixel-rows of a cout chunk combined in row order (deterministic)
         __syncthreads();
+        if (epi_ok) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            lds_fin[(prow * 2 + 0) * NB + c4 * 4 + r] = s1[r];
-            lds_fin[(prow * 2 + 1) * NB + c4 * 4 + r] = s2[r];
+            for (int r = 0; r < 4; ++r) {
+                lds_fin[(prow * 2 + 0) * NB + c4 * 4 + r] = s1[r];
+                lds_fin[(prow * 2 + 1) * NB + c4 * 4 + r] = s2[r];
+            }
         }
         __syncthreads();
         for (int i = tid; i < 2 * NB; i += 512) {
@@ -279,6 +282,10 @@ static bool c3r_plan(int mode, int N, int Hi, int Wi, int Ci, int Ho, int Wo, in
     p->nt = ksw <= 14 ? 2 : 1;
     if (p->nt == 1 && (ksteps + 7) / 8 <= 12 && mnas_diag_env("MNAS_C3R_KQ8", 1)) {
         p->kq = 8; p->ptw = 4; p->nt = 2; ksw = (ksteps + 7) / 8; p->ksw = 12;
+    } else if (p->nt == 2 && (ksteps + 7) / 8 <= 7 && (Co + 47) / 48 < (Co + 31) / 32 && stride == 1 && mnas_diag_env("MNAS_C3R_KQ8", 1) >= 1 &&
+               mnas_diag_env("MNAS_C3R_NT3", 1)) {
+        // three cout tiles with the 8-way split where that saves passes (192 -> 320 forward: 7 slices of 48 instead of 10 of 32)
+        p->kq = 8; p->ptw = 4; p->nt = 3; ksw = (ksteps + 7) / 8; p->ksw = 7;
     } else {
         if (p->nt * ksw > 28 && !(p->nt == 1 && ksw <= 24)) return false;
         p->ksw = ksw <= 14 ? 14 : 24;
@@ -329,6 +336,12 @@ int mnas_c3r_run(const MnasConvGemm* c, void* stream) {
     }
     MNAS_C3R(0, 2, 14) MNAS_C3R(1, 2, 14) MNAS_C3R(0, 1, 24) MNAS_C3R(1, 1, 24)
 #undef MNAS_C3R
+    if (p.kq == 8 && p.nt == 3 && p.ksw == 7) {
+        if (c->mode == 0) hipLaunchKernelGGL((k_c3r<0, 3, 7, 4, 8>), grid, dim3(512), p.lds, s, a);
+        else hipLaunchKernelGGL((k_c3r<1, 3, 7, 4, 8>), grid, dim3(512), p.lds, s, a);
+        MNAS_CHECK_LAUNCH();
+        return MNAS_OK;
+    }
     if (p.kq == 8 && p.nt == 2 && p.ksw == 12) {
         if (c->mode == 0) hipLaunchKernelGGL((k_c3r<0, 2, 12, 4, 8>), grid, dim3(512), p.lds, s, a);
         else hipLaunchKernelGGL((k_c3r<1, 2, 12, 4, 8>), grid, dim3(512), p.lds, s, a);
