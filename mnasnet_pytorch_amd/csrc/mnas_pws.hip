@@ -16,6 +16,9 @@
 // Bytes in flight: KSW KB per wave and tensor -> 40-80 KB per CU with two workgroups resident: enough to cover HBM latency
 // without any software pipeline.  Roofline: HBM.
 #include "mnas_common.h"
+#ifndef MNAS_PWS_D2
+#define MNAS_PWS_D2 1        // fragments loaded TWO pixel groups ahead (0: one, A/B builds)
+#endif
 
 struct PwsArgs {
     int M, K, N;             // pixels, reduction length (input channels of this GEMM), outputs
@@ -102,7 +105,30 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
 
     const int ngroups = (a.M + 15) >> 4;
     uint4 v0[KSW], v1[MODE == 1 ? KSW : 1];
+    // D2 (round 6): a second register set, filled TWO groups ahead.  A group's arithmetic (<= 18 MFMAs, the partial exchange) is
+    // ~1 us, a global load under load 2-4 us, and with 8 waves x ~200 VGPRs there is one workgroup per CU: with the loads only
+    // one group ahead every iteration waited for them (SQ: the waves wait 60 % of their cycles, profiles/r06_sq_counters.txt).
+    // Input-gradient mode only: the forward forms (4 waves, two workgroups per CU) LOSE with it (class 1.79 vs 1.75 ms).
+    constexpr bool D2 = MNAS_PWS_D2 && !GATE && MODE == 1;
+    uint4 w0[D2 ? KSW : 1], w1[(D2 && MODE == 1) ? KSW : 1];
     float gq[GATE ? KSW : 1][8];                             // GATE: the fragment's 8 multipliers, fetched with it
+    auto issue_to = [&](int g, uint4* d0, uint4* d1) {
+        const int m = g * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) {
+            const int k = (wave + NW * j) * 32 + lg * 8;
+            d0[j] = make_uint4(0, 0, 0, 0);
+            if (MODE == 1) d1[j] = make_uint4(0, 0, 0, 0);
+            if (m < a.M && k < a.K) {
+                const size_t off = (size_t)m * a.K + k;
+                if (MODE == 0) d0[j] = *(const uint4*)((const uint16_t*)a.act.data + off);
+                else {
+                    d0[j] = *(const uint4*)((const uint16_t*)a.grad.g + off);
+                    d1[j] = *(const uint4*)((const uint16_t*)a.grad.y + off);
+                }
+            }
+        }
+    };
     auto issue = [&](int g) {
         const int m = g * 16 + l15;
         const float* grow = GATE ? a.gate + (size_t)(m / a.hw) * a.K : nullptr;
@@ -127,7 +153,8 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
         }
     };
     int it = 0;
-    if ((int)blockIdx.x < ngroups) issue(blockIdx.x);
+    if ((int)blockIdx.x < ngroups) { if constexpr (D2) issue_to(blockIdx.x, v0, v1); else issue(blockIdx.x); }
+    if constexpr (D2) { if ((int)(blockIdx.x + gridDim.x) < ngroups) issue_to(blockIdx.x + gridDim.x, w0, w1); }
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x, ++it) {
         const int m0 = g * 16;
         // ---- fragments of this group (transform in registers), then the next group's loads go out
@@ -161,7 +188,11 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
             if (a.resid) rpre = *(const uint4*)((const uint16_t*)a.resid + o);
             if (do_red) ypre = *(const uint4*)((const uint16_t*)a.red_y + o);
         }
-        if (g + (int)gridDim.x < ngroups) issue(g + gridDim.x);
+        if constexpr (D2) {                                  // the set filled one group ago becomes current; refill two groups ahead
+#pragma unroll
+            for (int j = 0; j < KSW; ++j) { v0[j] = w0[j]; if (MODE == 1) v1[j] = w1[j]; }
+            if (g + 2 * (int)gridDim.x < ngroups) issue_to(g + 2 * gridDim.x, w0, w1);
+        } else if (g + (int)gridDim.x < ngroups) issue(g + gridDim.x);
         f32x4_t acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
