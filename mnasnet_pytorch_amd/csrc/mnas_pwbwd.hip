@@ -196,6 +196,9 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     // of tile t, instead of standing exposed at the top of every tile.  Per-launch, round 5 (us without -> with): 576->96 72.6 ->
     // 65.9, 480->80 64 -> 58, 240->40 98 -> 89, 72->24 88 -> 81, 24->72 75 -> 70, 48->16 199 -> 172, 16->48 161 -> 148.  Not for
     // 40->240 (16 more uint4 per thread: 255 VGPRs + spills, 74 -> 80) and 32->16 (131 -> 140): launch_pw_bwd picks.
+    // (the zero fills below are redundant for the results -- the staging zeroes what was not loaded by its own predicates -- but not
+    // for the schedule: without them the registers are undefined on the not-loaded path and the compiler sinks the loads to their
+    // use in the next tile's staging, i.e. un-does the prefetch: class 2.36 -> 2.67 ms, round 6; the same in k_wgrad_t)
     uint4 ng[ND], ny[ND], nx[NX];
     auto issue = [&](int t0) {
 #pragma unroll

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_t(WgradArgs a) {
     }
 #endif
     // (a slot that is not loaded goes to the tile as zeros from zero-initialised registers: leaving the registers alone and
-    // branching in stage() measured 25 % slower; one 8-channel group per thread for all its dy slots -- the coefficient rows read
+    // branching in stage() measured 25 % slower -- undefined on the not-loaded path, the loads may be sunk to their use = no prefetch; one 8-channel group per thread for all its dy slots -- the coefficient rows read
     // from LDS once per chunk instead of once per slot, 240 threads x 6 slots for the 160-channel slab -- measured equal: round 6)
     auto issue = [&](int pc) {
         okd = 0; oka = 0;
