@@ -20,6 +20,27 @@ static inline int mnas_diag_env(const char* name, int dflt) { const char* e = ge
 
 #define MNAS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+// MNAS_EARLY (1): a kernel's FIRST tile / group loads are issued before its one-time setup (coefficient tables, resident weights)
+// instead of behind the setup's barrier: one exposed memory round trip less per workgroup (0: A/B builds)
+#ifndef MNAS_EARLY
+#define MNAS_EARLY 1
+#endif
+// dst[i] = f(i), i = tid, tid + nth, ... < n with FOUR values fetched before the first is written: a setup table of a few
+// iterations per thread costs one memory round trip instead of one per iteration (MNAS_EARLY = 0: the plain loop)
+template <class F>
+__device__ __forceinline__ void mnas_fill_table(float* dst, int n, int tid, int nth, F f) {
+#if MNAS_EARLY
+    for (int i0 = tid; i0 < n; i0 += 4 * nth) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (i0 + j * nth < n) ? f(i0 + j * nth) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i0 + j * nth < n) dst[i0 + j * nth] = v[j];
+    }
+#else
+    for (int i = tid; i < n; i += nth) dst[i] = f(i);
+#endif
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float bf_to_f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -1,6 +1,9 @@
 // BatchNorm bookkeeping, residual add, layout conversions, weight packing, wgrad reductions, fused Adam.
 // All of these are HBM- or latency-bound helpers around the conv kernels; see include/mnas.h for the ABI.
 #include "mnas_common.h"
+#ifndef MNAS_FIN_HOIST
+#define MNAS_FIN_HOIST 1
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm forward finalize  (ATen native_batch_norm's statistics step; mnasnet.py:55,60)
@@ -57,20 +60,31 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(
     if (c < C) {
         float s, t;
         if (training) {
+            // everything the tail needs is loaded BEFORE the partial sums: these launches are chains of memory round trips, and
+            // gamma / beta / the running statistics after the reduce were a second one (MNAS_FIN_HOIST=0: A/B builds)
+#if MNAS_FIN_HOIST
+            const float g0 = gamma[c], b0 = beta[c], rm0 = running_mean[c], rv0 = running_var[c];
+#endif
             double s1, s2;
             bn_partial_sums<TPC>(partial, nparts, C, c, s1, s2);
+#if !MNAS_FIN_HOIST
+            const float g0 = gamma[c], b0 = beta[c];
+#endif
             const double mean = s1 / count;
             double var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
             const double invstd = 1.0 / sqrt(var + (double)eps);
-            s = (float)((double)gamma[c] * invstd);
-            t = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+            s = (float)((double)g0 * invstd);
+            t = (float)((double)b0 - mean * (double)g0 * invstd);
             if (lane == 0) {
+#if !MNAS_FIN_HOIST
+                const float rm0 = running_mean[c], rv0 = running_var[c];
+#endif
                 bnbuf[5 * C + c] = (float)mean;
                 bnbuf[6 * C + c] = (float)invstd;
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+                running_mean[c] = (float)((1.0 - momentum) * (double)rm0 + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * (double)rv0 + momentum * unbiased);
             }
         } else {
             const float invstd = 1.0f / sqrtf(running_var[c] + eps);
@@ -209,16 +223,25 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const float* __restrict__ p
     const int lane = threadIdx.x % TPC;
     const int c = (TPC == 256) ? blk : blk * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
+#if MNAS_FIN_HOIST
+    // (loaded ahead of the partial sums: see k_bn_fwd_finalize)
+    const float fs = bnbuf[0 * C + c], fmean = bnbuf[5 * C + c], finv = bnbuf[6 * C + c];
+    const float dg0 = (dgamma && accumulate) ? dgamma[c] : 0.f, db0 = (dbeta && accumulate) ? dbeta[c] : 0.f;
+#endif
     double s1, s2;
     bn_partial_sums<TPC>(partial, nparts, C, c, s1, s2);
     if (lane == 0) {
-        const double s = bnbuf[0 * C + c], mean = bnbuf[5 * C + c], invstd = bnbuf[6 * C + c];
+#if !MNAS_FIN_HOIST
+        const float fs = bnbuf[0 * C + c], fmean = bnbuf[5 * C + c], finv = bnbuf[6 * C + c];
+        const float dg0 = (dgamma && accumulate) ? dgamma[c] : 0.f, db0 = (dbeta && accumulate) ? dbeta[c] : 0.f;
+#endif
+        const double s = fs, mean = fmean, invstd = finv;
         const double md = s1 / count, mx = s2 / count;
         bnbuf[2 * C + c] = (float)s;
         bnbuf[3 * C + c] = (float)(-s * invstd * mx);
         bnbuf[4 * C + c] = (float)(s * (mean * invstd * mx - md));
-        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+        if (dgamma) dgamma[c] = dg0 + (float)s2;
+        if (dbeta) dbeta[c] = db0 + (float)s1;
     }
 }
 template <int TPC>
@@ -565,6 +588,22 @@ __device__ __forceinline__ void wgrad_finalize_body(float* __restrict__ partial,
     const int i = bx * 32 + tx;
     const int p0 = FOLD ? by * FIN_SPLITS : 0, p1 = FOLD ? min(nsplit, p0 + FIN_SPLITS) : nsplit;
     float s = 0.f;
+#if MNAS_FIN_HOIST
+    // the destination (two divisions) and its old value are formed BEFORE the partial rows are read (see k_bn_fwd_finalize)
+    float* d = nullptr;
+    float dold = 0.f;
+    if (!FOLD && ty == 0 && i < total) {
+        if (DW) {          // wpartial rows are [taps][C]; reference layout [C][1][kh][kw]
+            const int tap = i / Co, c = i % Co;
+            d = grad + (size_t)c * taps + tap;
+        } else {           // partial rows are [Co][taps*Ci]; reference layout [Co][Ci][kh][kw]
+            const int co = i / K, k = i % K;
+            const int tap = k / Ci, ci = k % Ci;
+            d = grad + ((size_t)co * Ci + ci) * taps + tap;
+        }
+        if (accumulate) dold = *d;
+    }
+#endif
     if (i < total) {
         const float* src = partial + i;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -590,6 +629,9 @@ __device__ __forceinline__ void wgrad_finalize_body(float* __restrict__ partial,
             partial[(size_t)p0 * total + i] = s;
             return;
         }
+#if MNAS_FIN_HOIST
+        *d = dold + s;
+#else
         float* d;
         if (DW) {          // wpartial rows are [taps][C]; reference layout [C][1][kh][kw]
             const int tap = i / Co, c = i % Co;
@@ -600,6 +642,7 @@ __device__ __forceinline__ void wgrad_finalize_body(float* __restrict__ partial,
             d = grad + ((size_t)co * Ci + ci) * taps + tap;
         }
         *d = (accumulate ? *d : 0.f) + s;
+#endif
     }
 }
 template <bool DW, bool FOLD>

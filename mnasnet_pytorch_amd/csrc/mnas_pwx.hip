@@ -44,29 +44,6 @@ __global__ __launch_bounds__(64 * NW) void k_pwx(PwxArgs a) {
     const int cb0 = blockIdx.y * NW * WC;                          // first cout of this workgroup's block (grid.y: wide outputs)
     const int cw0 = cb0 + wave * WC;                               // first cout of this wave
 
-    for (int i = tid; i < 2 * a.Kpad; i += NTH) {
-        const int r = i / a.Kpad, c = i - r * a.Kpad;
-        lds_coef[i] = (has_coef && c < a.Ci) ? (r == 0 ? a.act.scale[c] : a.act.shift[c]) : 0.f;
-    }
-    for (int i = tid; i < NW * WC; i += NTH) lds_bias[i] = (a.bias && cb0 + i < a.Co) ? a.bias[cb0 + i] : 0.f;
-    // ---- this wave's cout tiles, full K: A fragments [cout l15][k = ks*32 + lg*8 ..]
-    bf16x8_t wf[TPW][KS];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int row = cw0 + t * 16 + l15;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < a.co_pad16) v = *(const uint4*)(a.w + (size_t)row * a.Kpad + ks * 32 + lg * 8);
-            wf[t][ks] = *(const bf16x8_t*)&v;
-        }
-    float s1[TPW][4], s2[TPW][4];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
-    __syncthreads();                                               // coefficient / bias tables visible (the only barrier)
-
     uint16_t* st = stage + wave * 16 * SP;
     const int ngroups = (a.M + 15) >> 4;
     uint4 v0[KS];
@@ -79,7 +56,31 @@ __global__ __launch_bounds__(64 * NW) void k_pwx(PwxArgs a) {
             if (m < a.M && k < a.Ci) v0[ks] = *(const uint4*)((const uint16_t*)a.act.data + (size_t)m * a.Ci + k);
         }
     };
-    if ((int)blockIdx.x < ngroups) issue(blockIdx.x);
+    if (MNAS_EARLY && (int)blockIdx.x < ngroups) issue(blockIdx.x);    // ahead of the setup: (data, weights, tables) share one round trip
+    // ---- this wave's cout tiles, full K: A fragments [cout l15][k = ks*32 + lg*8 ..]
+    bf16x8_t wf[TPW][KS];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int row = cw0 + t * 16 + l15;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < a.co_pad16) v = *(const uint4*)(a.w + (size_t)row * a.Kpad + ks * 32 + lg * 8);
+            wf[t][ks] = *(const bf16x8_t*)&v;
+        }
+    mnas_fill_table(lds_coef, 2 * a.Kpad, tid, NTH, [&](int i) {
+        const int r = i / a.Kpad, c = i - r * a.Kpad;
+        return (has_coef && c < a.Ci) ? (r == 0 ? a.act.scale[c] : a.act.shift[c]) : 0.f;
+    });
+    mnas_fill_table(lds_bias, NW * WC, tid, NTH, [&](int i) { return (a.bias && cb0 + i < a.Co) ? a.bias[cb0 + i] : 0.f; });
+    float s1[TPW][4], s2[TPW][4];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+    __syncthreads();                                               // coefficient / bias tables visible (the only barrier)
+    if (!MNAS_EARLY && (int)blockIdx.x < ngroups) issue(blockIdx.x);
+
     constexpr int CPP = TPW * 2;                                   // 16-byte chunks per pixel of this wave's cout range
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int m0 = g * 16;
