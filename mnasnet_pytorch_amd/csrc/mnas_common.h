@@ -41,6 +41,28 @@ __device__ __forceinline__ void mnas_fill_table(float* dst, int n, int tid, int 
     for (int i = tid; i < n; i += nth) dst[i] = f(i);
 #endif
 }
+// row r of a fused-reduce coefficient table (s, t, invstd, -mean*invstd of channel c, from a bnbuf of C channels): both loads
+// unconditional -- as a chain of if / else every row was its own branch with its own wait
+__device__ __forceinline__ float mnas_red_coef(const float* red_bn, int C, int r, int c) {
+    const int row = r == 0 ? 0 : (r == 1 ? 1 : (r == 2 ? 6 : 5));
+    const float v = red_bn[(size_t)row * C + c], w = red_bn[(size_t)6 * C + c];
+    return r == 3 ? -v * w : v;
+}
+// the same for 16-byte items: store(i, load(i)), i = tid, tid + nth, ... < n, four loads in flight before the first store
+template <class L, class S>
+__device__ __forceinline__ void mnas_copy_items(int n, int tid, int nth, L load, S store) {
+#if MNAS_EARLY
+    for (int i0 = tid; i0 < n; i0 += 4 * nth) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (i0 + j * nth < n) ? load(i0 + j * nth) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i0 + j * nth < n) store(i0 + j * nth, v[j]);
+    }
+#else
+    for (int i = tid; i < n; i += nth) store(i, load(i));
+#endif
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float bf_to_f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

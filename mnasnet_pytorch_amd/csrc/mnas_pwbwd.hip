@@ -102,48 +102,6 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
     const int ci0 = blockIdx.y * CIP;
     const int cis = min(CIP, a.Ci - ci0);                    // valid channels of this slice (multiple of 8)
 
-    // ---- one-time setup: coefficient tables, resident weights, zeroed tiles / statistics
-    for (int i = tid; i < 5 * COP; i += 256) {
-        const int r = i / COP, c = i % COP;
-        lds_cd[i] = (c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
-    }
-    for (int i = tid; i < 2 * CIP; i += 256) {
-        const int r = i / CIP, c = i % CIP;
-        lds_cx[i] = (hasx && c < cis) ? (r == 0 ? a.x.scale[ci0 + c] : a.x.shift[ci0 + c]) : 0.f;
-    }
-    for (int i = tid; i < 4 * CIP; i += 256) {
-        const int r = i / CIP, c = i % CIP;
-        float v = 0.f;
-        if (do_red && c < cis) {
-            const int cg = ci0 + c;
-            if (r == 0) v = a.red_bn[0 * a.Ci + cg];
-            else if (r == 1) v = a.red_bn[1 * a.Ci + cg];
-            else if (r == 2) v = a.red_bn[6 * a.Ci + cg];
-            else v = -a.red_bn[5 * a.Ci + cg] * a.red_bn[6 * a.Ci + cg];
-        }
-        lds_rc[i] = v;
-    }
-    for (int i = tid; i < 8 * CIP; i += 256) lds_st[i] = 0.f;
-    {
-        const int kc8n = a.Kd >> 3;
-        for (int q = tid; q < CIP * kc8n; q += 256) {
-            const int r = q / kc8n, kc8 = q - r * kc8n;
-            *(uint4*)(lds_w + r * ldw + kc8 * 8) = *(const uint4*)(a.w + (size_t)(ci0 + r) * a.Kd + kc8 * 8);
-        }
-        const int nz = (BP * ldd + BP * lda) / 8;            // both tiles are contiguous; row strides are multiples of 8
-        for (int i = tid; i < nz; i += 256) ((uint4*)tile_d)[i] = make_uint4(0, 0, 0, 0);
-        if constexpr (FORM == 2) {
-            const int kf8 = a.Kf >> 3, cop16 = (a.Co + 15) / 16 * 16;
-            for (int q = tid; q < COP * kf8; q += 256) {
-                const int r = q / kf8, k8 = q - r * kf8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (r < cop16) v = *(const uint4*)(a.w_fwd + (size_t)r * a.Kf + k8 * 8);
-                *(uint4*)(lds_wf + r * ldf + k8 * 8) = v;
-            }
-            for (int i = tid; i < COP; i += 256) lds_bf[i] = (a.b_fwd && i < a.Co) ? a.b_fwd[i] : 0.f;
-        }
-    }
-
     // ---- staging plan (tile-invariant): slot -> (pixel in tile, 16-byte channel chunk)
     const int cwd = a.Co >> 3, cwa = cis >> 3;
     int pd[ND], cd8[ND], pa[NX], ca8[NX];
@@ -164,27 +122,6 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
             if (pa[i] >= BP) pa[i] = -1;
         }
     }
-
-    f32x4_t acc_w[NOWN][NOTH];
-#pragma unroll
-    for (int i = 0; i < NOWN; ++i)
-#pragma unroll
-        for (int j = 0; j < NOTH; ++j) acc_w[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // BatchNorm-backward partial sums: per lane in registers across all tiles when there are few cin tiles (one shuffle tree
-    // at the very end), per tile through LDS otherwise (15 cin tiles would need 120 registers)
-    // OS copy-out role: thread -> fixed 16-byte channel column c8 of the out-stage rows orow0 + k*OROWS
-    const int oc8 = tid % NCH8, orow0 = tid / NCH8;
-    const bool ocol_ok = tid < TCOLS && oc8 * 8 < cis;
-    float r1[8], r2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; }
-    constexpr bool REGSTAT = NTI <= 6;
-    float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
-#pragma unroll
-    for (int i = 0; i < (REGSTAT ? NTI : 1); ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { rs1[i][r] = 0.f; rs2[i][r] = 0.f; }
 
     // Tile walk: workgroups stride over the 64*PT-pixel tiles of the whole tensor, or (seg_px > 0, "segment mode") workgroup b
     // owns the contiguous pixels [b*seg_px, (b+1)*seg_px) -- its weight-gradient partial is then the sum over a known pixel
@@ -218,7 +155,65 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(PwBwdArgs a) {
         }
     };
     const int tfirst = a.seg_px ? (int)blockIdx.x * a.seg_px : (int)blockIdx.x * BP;
-    if (PF) issue(tfirst);
+    if (PF && MNAS_EARLY) issue(tfirst);                     // ahead of the setup: the first tile's loads share its round trip
+    // ---- one-time setup: coefficient tables, resident weights, zeroed tiles / statistics (every table / copy with four loads in
+    // flight: as plain loops each iteration was a memory round trip of its own, ~10 in a row before the first tile)
+    {
+        const int kc8n = a.Kd >> 3;
+        mnas_copy_items(CIP * kc8n, tid, 256,
+                        [&](int q) { const int r = q / kc8n, kc8 = q - r * kc8n; return *(const uint4*)(a.w + (size_t)(ci0 + r) * a.Kd + kc8 * 8); },
+                        [&](int q, const uint4& v) { const int r = q / kc8n, kc8 = q - r * kc8n; *(uint4*)(lds_w + r * ldw + kc8 * 8) = v; });
+        if constexpr (FORM == 2) {
+            const int kf8 = a.Kf >> 3, cop16 = (a.Co + 15) / 16 * 16;
+            mnas_copy_items(COP * kf8, tid, 256,
+                            [&](int q) { const int r = q / kf8, k8 = q - r * kf8;
+                                         return r < cop16 ? *(const uint4*)(a.w_fwd + (size_t)r * a.Kf + k8 * 8) : make_uint4(0, 0, 0, 0); },
+                            [&](int q, const uint4& v) { const int r = q / kf8, k8 = q - r * kf8; *(uint4*)(lds_wf + r * ldf + k8 * 8) = v; });
+            mnas_fill_table(lds_bf, COP, tid, 256, [&](int i) { return (a.b_fwd && i < a.Co) ? a.b_fwd[i] : 0.f; });
+        }
+    }
+    mnas_fill_table(lds_cd, 5 * COP, tid, 256, [&](int i) {
+        const int r = i / COP, c = i % COP;
+        return (c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
+    });
+    mnas_fill_table(lds_cx, 2 * CIP, tid, 256, [&](int i) {
+        const int r = i / CIP, c = i % CIP;
+        return (hasx && c < cis) ? (r == 0 ? a.x.scale[ci0 + c] : a.x.shift[ci0 + c]) : 0.f;
+    });
+    mnas_fill_table(lds_rc, 4 * CIP, tid, 256, [&](int i) {
+        const int r = i / CIP, c = i % CIP;
+        return (do_red && c < cis) ? mnas_red_coef(a.red_bn, a.Ci, r, ci0 + c) : 0.f;
+    });
+    for (int i = tid; i < 8 * CIP; i += 256) lds_st[i] = 0.f;
+    {
+        // (the dy tile rows past the staged slots and the pad columns are read by the MFMA fragments: zero once.  The first tile's
+        // staging writes come after the barrier at the top of the tile loop, i.e. after these)
+        const int nz = (BP * ldd + BP * lda) / 8;            // both tiles are contiguous; row strides are multiples of 8
+        for (int i = tid; i < nz; i += 256) ((uint4*)tile_d)[i] = make_uint4(0, 0, 0, 0);
+    }
+
+    f32x4_t acc_w[NOWN][NOTH];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+        for (int j = 0; j < NOTH; ++j) acc_w[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // BatchNorm-backward partial sums: per lane in registers across all tiles when there are few cin tiles (one shuffle tree
+    // at the very end), per tile through LDS otherwise (15 cin tiles would need 120 registers)
+    // OS copy-out role: thread -> fixed 16-byte channel column c8 of the out-stage rows orow0 + k*OROWS
+    const int oc8 = tid % NCH8, orow0 = tid / NCH8;
+    const bool ocol_ok = tid < TCOLS && oc8 * 8 < cis;
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r1[j] = 0.f; r2[j] = 0.f; }
+    constexpr bool REGSTAT = NTI <= 6;
+    float rs1[REGSTAT ? NTI : 1][4], rs2[REGSTAT ? NTI : 1][4];
+#pragma unroll
+    for (int i = 0; i < (REGSTAT ? NTI : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rs1[i][r] = 0.f; rs2[i][r] = 0.f; }
+
+    if (PF && !MNAS_EARLY) issue(tfirst);
     for (int tile0 = tfirst; tile0 < mend; tile0 += tstep) {
         __syncthreads();                                     // previous tile's fragments consumed (first pass: setup visible)
         if (!PF) issue(tile0);

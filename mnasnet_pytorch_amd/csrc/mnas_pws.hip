@@ -57,52 +57,6 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
     const bool has_coef = MODE == 1 || a.act.scale != nullptr;
     const bool do_red = MODE == 1 && a.red_y != nullptr;
 
-    for (int i = tid; i < CROWS * a.Kpad; i += NTH) {
-        const int r = i / a.Kpad, c = i - r * a.Kpad;
-        float v = 0.f;
-        if (c < a.K) {
-            if (MODE == 1) v = a.grad.coef[(size_t)r * a.K + c];
-            else if (has_coef) v = r == 0 ? a.act.scale[c] : a.act.shift[c];
-        }
-        lds_coef[i] = v;
-    }
-    if (do_red)
-        for (int i = tid; i < 4 * NB; i += NTH) {
-            const int r = i / NB, co = n0 + i % NB;
-            float v = 0.f;
-            if (co < a.N) {
-                if (r == 0) v = a.red_bn[0 * a.N + co];
-                else if (r == 1) v = a.red_bn[1 * a.N + co];
-                else if (r == 2) v = a.red_bn[6 * a.N + co];
-                else v = -a.red_bn[5 * a.N + co] * a.red_bn[6 * a.N + co];
-            }
-            lds_redc[i] = v;
-        }
-    // ---- this wave's slice of the weight block: A fragments [cout l15][k = ks*32 + lg*8 ..], k-steps ks = wave + NW*j
-    bf16x8_t wf[NT][KSW];
-#pragma unroll
-    for (int j = 0; j < KSW; ++j) {
-        const int ks = wave + NW * j;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int row = n0 + nt * 16 + l15;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ks < a.ksteps && row < a.n_pad16) v = *(const uint4*)(a.w + (size_t)row * a.Kpad + ks * 32 + lg * 8);
-            wf[nt][j] = *(const bf16x8_t*)&v;
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue role: thread te = p * chunks + c8 (p = pixel of the group, c8 = 8-channel chunk), fixed for the whole kernel
-    const bool epi = tid < 16 * chunks;
-    const int ep = epi ? tid / chunks : 0, ec8 = epi ? tid - ep * chunks : 0;
-    float bias8[8], s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bias8[j] = (MODE == 0 && epi && a.bias) ? a.bias[n0 + ec8 * 8 + j] : 0.f;
-        s1[j] = 0.f; s2[j] = 0.f;
-    }
-
     const int ngroups = (a.M + 15) >> 4;
     uint4 v0[KSW], v1[MODE == 1 ? KSW : 1];
     // D2 (round 6): a second register set, filled TWO groups ahead.  A group's arithmetic (<= 18 MFMAs, the partial exchange) is
@@ -153,8 +107,51 @@ __global__ __launch_bounds__(64 * NW) void k_pws(PwsArgs a) {
         }
     };
     int it = 0;
-    if ((int)blockIdx.x < ngroups) { if constexpr (D2) issue_to(blockIdx.x, v0, v1); else issue(blockIdx.x); }
-    if constexpr (D2) { if ((int)(blockIdx.x + gridDim.x) < ngroups) issue_to(blockIdx.x + gridDim.x, w0, w1); }
+    auto first_issue = [&]() {
+        if ((int)blockIdx.x < ngroups) { if constexpr (D2) issue_to(blockIdx.x, v0, v1); else issue(blockIdx.x); }
+        if constexpr (D2) { if ((int)(blockIdx.x + gridDim.x) < ngroups) issue_to(blockIdx.x + gridDim.x, w0, w1); }
+    };
+    if (MNAS_EARLY) first_issue();           // the first groups' loads, the weights and the tables below share one round trip
+    // ---- this wave's slice of the weight block: A fragments [cout l15][k = ks*32 + lg*8 ..], k-steps ks = wave + NW*j
+    bf16x8_t wf[NT][KSW];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        const int ks = wave + NW * j;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int row = n0 + nt * 16 + l15;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ks < a.ksteps && row < a.n_pad16) v = *(const uint4*)(a.w + (size_t)row * a.Kpad + ks * 32 + lg * 8);
+            wf[nt][j] = *(const bf16x8_t*)&v;
+        }
+    }
+    mnas_fill_table(lds_coef, CROWS * a.Kpad, tid, NTH, [&](int i) {
+        const int r = i / a.Kpad, c = i - r * a.Kpad;
+        float v = 0.f;
+        if (c < a.K) {
+            if (MODE == 1) v = a.grad.coef[(size_t)r * a.K + c];
+            else if (has_coef) v = r == 0 ? a.act.scale[c] : a.act.shift[c];
+        }
+        return v;
+    });
+    if (do_red)
+        mnas_fill_table(lds_redc, 4 * NB, tid, NTH, [&](int i) {
+            const int r = i / NB, co = n0 + i % NB;
+            return co < a.N ? mnas_red_coef(a.red_bn, a.N, r, co) : 0.f;
+        });
+    __syncthreads();
+    if (!MNAS_EARLY) first_issue();
+
+    // ---- epilogue role: thread te = p * chunks + c8 (p = pixel of the group, c8 = 8-channel chunk), fixed for the whole kernel
+    const bool epi = tid < 16 * chunks;
+    const int ep = epi ? tid / chunks : 0, ec8 = epi ? tid - ep * chunks : 0;
+    float bias8[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bias8[j] = (MODE == 0 && epi && a.bias) ? a.bias[n0 + ec8 * 8 + j] : 0.f;
+        s1[j] = 0.f; s2[j] = 0.f;
+    }
+
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x, ++it) {
         const int m0 = g * 16;
         // ---- fragments of this group (transform in registers), then the next group's loads go out

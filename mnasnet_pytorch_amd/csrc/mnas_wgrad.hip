@@ -269,16 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_t(WgradArgs a) {
     uint16_t* tile_a = tile_d + 2 * WT_BP * LDD;          // [2][64][LDA]
 
     const bool hasdy = a.dy.coef != nullptr;              // false: dy.g is a materialised dy
-    for (int i = tid; i < 5 * COT; i += 256) {
-        const int r = i / COT, c = co0 + i % COT;
-        lds_cd[i] = (hasdy && c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
-    }
     const bool hasx = a.x.scale != nullptr;
-    if (hasx)
-        for (int i = tid; i < 2 * xcols; i += 256) {
-            const int r = i / xcols, c = (a.taps == 1 ? kc0 : 0) + i % xcols;
-            lds_cx[i] = (c < a.Ci) ? (r == 0 ? a.x.scale[c] : a.x.shift[c]) : 0.f;
-        }
 
     // ---- per-thread staging plan (chunk-invariant): CT dy slots and KT x slots of 16 bytes; a slot outside the tensor's
     // channels writes zeros, so the MFMA tiles past the slab's valid edge multiply zeros
@@ -422,9 +413,19 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_t(WgradArgs a) {
             *(uint4*)(ta + pa[i] * LDA + ca8[i] * 8) = v;
         }
     };
+    if (MNAS_EARLY && nch > 0) issue(p_begin);                // the first chunk's loads and the coefficient tables share one round trip
+    mnas_fill_table(lds_cd, 5 * COT, tid, 256, [&](int i) {
+        const int r = i / COT, c = co0 + i % COT;
+        return (hasdy && c < a.Co) ? a.dy.coef[(size_t)r * a.Co + c] : 0.f;
+    });
+    if (hasx)
+        mnas_fill_table(lds_cx, 2 * xcols, tid, 256, [&](int i) {
+            const int r = i / xcols, c = (a.taps == 1 ? kc0 : 0) + i % xcols;
+            return (c < a.Ci) ? (r == 0 ? a.x.scale[c] : a.x.shift[c]) : 0.f;
+        });
     __syncthreads();                                          // coefficient tables
     if (nch > 0) {
-        issue(p_begin);
+        if (!MNAS_EARLY) issue(p_begin);
         stage(0);
         if (nch > 1) issue(p_begin + WT_BP);
     }
