@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--smi", action="store_true", help="also keep a rocm-smi / amd-smi snapshot in the box object: a CHILD process, started before this "
                                                       "process touches the GPU and never when a profiler / tool library is preloaded")
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--auto-graphs", type=float, default=0.92,
+                    help="host-bound guard: if, after the warm-up, the host needs more than this share of a step's wall time to enqueue it "
+                         "(MAX over ranks), the launch lists are replayed as hipGraphs (Engine.use_graphs: 0.6 ms of host time per step at "
+                         "+0.5 %% GPU time) for the measurement; 0 disables the guard.  Reported as graph_mode.auto in the JSON line.")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed window until this much timed work exists; "
                                                                    "the median window is reported")
@@ -682,6 +686,35 @@ def main():
     for _ in range(args.warmup):
         trainer.step(x, target)
     barrier()
+    # ---- host-bound guard: a step is ~400 launches enqueued by one Python thread (6.4-7.4 ms against 9.9 ms of GPU time on the
+    # hosts seen so far); on a slower or busier host (8 ranks on one node) the enqueue could become the step.  Measured here, on
+    # every rank, decided on the MAX over ranks: above --auto-graphs the launch lists are replayed as hipGraphs instead.
+    auto_graph = None
+    if args.auto_graphs > 0 and not eng.use_graphs:
+        t0 = time.perf_counter()
+        for _ in range(8):
+            trainer.step(x, target)
+        h_dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        share = h_dt / max(time.perf_counter() - t0, 1e-9)
+        if distributed:
+            import torch.distributed as dist
+            tt = torch.tensor([share], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            share = float(tt)
+        auto_graph = {"host_share_of_step": round(share, 3), "threshold": args.auto_graphs, "switched": False}
+        if share > args.auto_graphs:
+            try:
+                eng.use_graphs = True
+                eng.reset_programs()
+                for _ in range(2):
+                    trainer.step(x, target)
+                auto_graph["switched"] = True
+            except Exception as e:                # stay on the per-launch path rather than lose the measurement
+                eng.use_graphs = False
+                eng.reset_programs()
+                auto_graph["error"] = repr(e)
+        barrier()
     # ---- roofline calibration (untimed, rank 0): bracket EVERY conv-kernel launch with HIP events for two steps, find the
     # kernel class with the largest time, then bracket only that class inside the timed region (bracketing all ~190
     # launches costs 7 % of the step rate; one class costs < 1 %)
@@ -820,8 +853,10 @@ def main():
             for key, ints, msv, nb_ in calib["detail"]:
                 sys.stderr.write("%-18s %-48s %8.1f us %8.1f GB/s\n" % (key, ",".join(map(str, ints)), msv * 1e3,
                                                                       nb_ / max(msv, 1e-9) / 1e6))
+    if auto_graph is not None:
+        res["host_bound_guard"] = auto_graph
     if eng.use_graphs:
-        res["graph_mode"] = {"captured_before_timed_region": True,
+        res["graph_mode"] = {"captured_before_timed_region": True, "auto": bool(auto_graph and auto_graph.get("switched")),
                              "per_launch_steps_per_window": 1 if profile else 0,
                              "note": "launch lists replayed as hipGraphs; the graphs are captured in an untimed step before the first "
                                      "window" + ("; the LAST step of every %d-step window runs per-launch (its dominant-class "

@@ -172,6 +172,32 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["roofline"]["launches_per_step"] >= 1 and any("--one-device" in o for o in d["overrides"])
 
 
+def _bench_line(cmd, timeout=600):
+    import json
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_host_bound_guard_switches_to_graphs():
+    """bench.py's host-bound guard (round 6): with the threshold forced to 1 % of a step the launch lists must be replayed as
+    hipGraphs for the measurement -- on one rank and on two (the decision is the MAX over ranks) -- and the line must say so; with
+    the default threshold on this host (enqueue ~65 % of a step) nothing switches."""
+    root = os.path.dirname(HERE)
+    base = ["--steps", "3", "--warmup", "2", "--batch", "32", "--size", "64", "--min-seconds", "0", "--no-box", "--no-cpu-baseline"]
+    d = _bench_line([sys.executable, os.path.join(root, "bench.py"), *base, "--auto-graphs", "0.01"])
+    assert d["host_bound_guard"]["switched"] is True and d["graph_mode"]["auto"] is True and d["value"] > 0
+    assert "error" not in d["host_bound_guard"]
+    d = _bench_line([sys.executable, os.path.join(root, "bench.py"), *base, "--auto-graphs", "0"])
+    assert "host_bound_guard" not in d and "graph_mode" not in d
+    d = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", *base[:-1], "--one-device",
+                     "--auto-graphs", "0.01"])
+    assert d["n_gpus"] == 2 and d["host_bound_guard"]["switched"] is True and d["graph_mode"]["auto"] is True and d["value"] > 0
+
+
 # ---- world 8 on one device (round 6): the day an 8-GPU node exists, the first real run must not fail on plumbing -----------------
 def test_real_engine_world8_one_gpu(tmp_path):
     """Eight real Trainer(distributed=True) ranks on cuda:0 over gloo (ranks 2..7 have never existed before round 6): ranks start
