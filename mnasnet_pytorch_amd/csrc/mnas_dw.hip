@@ -46,6 +46,9 @@ __device__ __forceinline__ void dw_step_barrier() {
     else dma_barrier();
 }
 
+#ifndef MNAS_DW_XCD
+#define MNAS_DW_XCD 1        // 1: consecutive items (the channel blocks / neighbouring strips of one image: shared lines, shared halos) run
+#endif                       //    on ONE XCD, i.e. behind one L2 (hardware places workgroup b on XCD b % 8); 0: A/B builds
 #ifndef MNAS_DW_RA
 #define MNAS_DW_RA 1         // 1: the window of row j+1 is read from LDS before row j is computed (0: A/B builds)
 #endif
@@ -315,7 +318,8 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
-    for (int item = blockIdx.x; item < a.items; item += a.geff) {
+    const int bid = MNAS_DW_XCD ? (int)xcd_remap(blockIdx.x, a.geff) : (int)blockIdx.x;     // logical workgroup id
+    for (int item = bid; item < a.items; item += a.geff) {
         int n, x0, c0;
         dw_item(a, item, n, x0, c0);
         const int ch = c0 + 2 * cp;
@@ -420,8 +424,8 @@ __global__ __launch_bounds__(256, (KS == 3 ? 4 : 3)) void k_dw_fwd(DwArgs a, Mna
     if (stats) {
         // stats table is float[2][C][rows], rows = geff / cblocks: workgroup b owns column b / cblocks of its own
         // channel block (b % cblocks), so every (channel, column) is written exactly once -- no zero fill, no atomics
-        const int rows = a.geff / a.cblocks, col = blockIdx.x / a.cblocks;
-        const int cb0 = (blockIdx.x % a.cblocks) * cblk;
+        const int rows = a.geff / a.cblocks, col = bid / a.cblocks;
+        const int cb0 = (bid % a.cblocks) * cblk;
         const f2 sv[2] = {s1, s2};
         const bool any = cur_c0 >= 0;
         dw_block_reduce<2>((float*)ring, sv, cp, sxi, a.sx, cblk, active, [&](int r, int cl, float v) {
@@ -467,7 +471,8 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
     const int nsteps = (a.H + 2 * PAD + G - 1) / G;
     const int ps = a.cpw;
 
-    for (int item = blockIdx.x; item < a.items; item += a.geff) {
+    const int bid = MNAS_DW_XCD ? (int)xcd_remap(blockIdx.x, a.geff) : (int)blockIdx.x;     // logical workgroup id
+    for (int item = bid; item < a.items; item += a.geff) {
         int n, x0, c0;
         dw_item(a, item, n, x0, c0);
         const int ch = c0 + 2 * cp;
@@ -645,8 +650,8 @@ __global__ __launch_bounds__(256, ((KS == 5 && DG && (WG || RED)) ? 2 : 3)) void
             }
         }
     }
-    const int row = blockIdx.x / a.cblocks, rows = a.geff / a.cblocks;
-    const int cb0 = (blockIdx.x % a.cblocks) * cblk;
+    const int row = bid / a.cblocks, rows = a.geff / a.cblocks;
+    const int cb0 = (bid % a.cblocks) * cblk;
     const bool any = cur_c0 >= 0;
     if constexpr (RED) {      // fused-reduce table float[2][C][rows]
         const f2 sv[2] = {s1, s2};
