@@ -11,7 +11,7 @@ P2="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST
 P3="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVES"
 n=1
 for P in "$P1" "$P2" "$P3"; do
-  rocprofv3 --pmc $P -d /tmp/prof_sq$n -o sq -- python3 $R/bench.py --steps 2 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-box --no-roofline > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1
+  rocprofv3 --pmc $P -d /tmp/prof_sq$n -o sq -- python3 $R/bench.py --steps 2 --warmup 2 --min-seconds 0 --auto-graphs 0 --no-cpu-baseline --no-box --no-roofline > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1
   DB=$(find /tmp/prof_sq$n -name "*.db" | head -1)
   python3 $R/tools/rocpd_stats.py --pmc $DB 4 > $R/gpurun_out/pmc_${TAG}_$n.txt
   n=$((n+1))
