@@ -19,7 +19,11 @@ def key(name):
     m = re.match(r"void k_dimg<(\d)", name)
     if m:
         return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"
-    if name.startswith("void k_tconv"): return "k_igemm<dgrad>"
+    m = re.match(r"void k_c3r<(\d)", name)
+    if m:
+        return "k_igemm<dgrad>" if m.group(1) == "1" else "k_igemm<fwd>"
+    if name.startswith("void k_pwx<") or name.startswith("void k_c3x<"): return "k_igemm<fwd>"
+    if name.startswith("void k_tconv") or name.startswith("void k_tcx<") or name.startswith("void k_tcr<"): return "k_igemm<dgrad>"
     if name.startswith("k_stem_fwd"): return "k_igemm<stem>"
     if name.startswith("k_stem_wgrad"): return "k_wgrad<stem>"
     if name.startswith("k_dy_mat"): return "k_dy_mat"
