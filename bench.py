@@ -61,6 +61,10 @@ def parse():
                     help="FUNCTIONAL TEST ONLY (tests/test_gpu_world2.py): every rank on cuda:0, backend gloo on device tensors (RCCL "
                          "refuses two ranks on one device) -- exercises this script's multi-rank code path on a 1-GPU box; the line "
                          "says so in `overrides` and its numbers mean nothing")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="FUNCTIONAL TEST ONLY: with --gpus 1, run the N > 1 code path (process group on backend nccl = RCCL with "
+                         "device_id, Trainer(distributed=True), barriers, the float64 MAX reduce, destroy) as a one-rank job; recorded in "
+                         "`overrides`")
     ap.add_argument("--dump-state", type=str, default="",
                     help="TESTS: after the timed windows every rank writes <dir>/rank<r>.json (sha256 of its flat parameter buffer, "
                          "the bucket schedule of its last step, whether it ran the roofline calibration)")
@@ -600,7 +604,12 @@ def main():
                  "plain `python bench.py --gpus %d`)" % (args.gpus, world, args.gpus, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
+    if args.force_distributed and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     # opt-in child process, BEFORE anything in this process touches the GPU and never with a tool library mapped (smi_snapshot
     # refuses by itself: rocprofv3's preloaded library has initialised the GPU before main() runs)
     smi = smi_snapshot() if (rank == 0 and args.smi and not args.no_box) else None
@@ -650,6 +659,8 @@ def main():
     overrides = apply_overrides(eng)          # diagnosis switches (environment); every honoured one is echoed in the JSON line
     if args.one_device:
         overrides.append("--one-device (functional test of the multi-rank path: all ranks on cuda:0 over gloo; NOT a measurement)")
+    if args.force_distributed:
+        overrides.append("--force-distributed (functional test: the multi-rank code path as a one-rank RCCL job)")
     profile = (not args.no_roofline) and rank == 0
     ALL_OPS = {L.OP_CONV_GEMM, L.OP_CONV_WGRAD, L.OP_DW_FWD, L.OP_DW_BWD, L.OP_BN_BWD_REDUCE, L.OP_STEM_FWD, L.OP_STEM_WGRAD,
                L.OP_ADD_ACT, L.OP_PW_BWD, L.OP_POOL_ACT, L.OP_POOL_BWD, L.OP_DY_MAT, L.OP_TCONV_DGRAD,

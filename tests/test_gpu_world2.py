@@ -198,6 +198,18 @@ def test_bench_host_bound_guard_switches_to_graphs():
     assert d["n_gpus"] == 2 and d["host_bound_guard"]["switched"] is True and d["graph_mode"]["auto"] is True and d["value"] > 0
 
 
+def test_bench_distributed_path_on_rccl_one_rank():
+    """bench.py's N > 1 branches on the REAL backend: `--gpus 1 --force-distributed` initialises the process group on "nccl" (= RCCL)
+    with device_id, builds Trainer(distributed=True) (rank-0 broadcast, two gradient buckets all-reduced asynchronously on RCCL's
+    stream), runs barrier + synchronize around every window, reduces the window time with a float64 MAX all-reduce on the device
+    and destroys the group -- as a one-rank job, the only RCCL job one GPU allows.  What it cannot show is ranks >= 1."""
+    root = os.path.dirname(HERE)
+    d = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-distributed", "--steps", "3", "--warmup", "2",
+                     "--batch", "32", "--size", "64", "--min-seconds", "0", "--no-box", "--no-cpu-baseline", "--auto-graphs", "0"])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and any("--force-distributed" in o for o in d["overrides"])
+    assert d["config"]["parallelism"] == "dp1"
+
+
 # ---- world 8 on one device (round 6): the day an 8-GPU node exists, the first real run must not fail on plumbing -----------------
 def test_real_engine_world8_one_gpu(tmp_path):
     """Eight real Trainer(distributed=True) ranks on cuda:0 over gloo (ranks 2..7 have never existed before round 6): ranks start
