@@ -605,8 +605,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or args.force_distributed
-    if args.force_distributed and "MASTER_PORT" not in os.environ:
-        import socket
+    if args.force_distributed and "RANK" not in os.environ:       # not under a launcher: a port of our own (an inherited MASTER_PORT
+        import socket                                              # may belong to a live process group of the parent process)
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(sk.getsockname()[1])

@@ -174,7 +174,8 @@ def test_bench_multi_rank_path_on_one_gpu():
 
 def _bench_line(cmd, timeout=600):
     import json
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
